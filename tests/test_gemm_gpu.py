@@ -1,0 +1,134 @@
+"""GPU parity of the MFMA GEMM / implicit-conv kernels against PyTorch fp64
+references of the same op (the oracle's building blocks).  Runs on the MI355X."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch.device("cuda:0")
+
+
+def _tol(dtype):
+    return dict(atol=2e-5, rtol=2e-5) if dtype == torch.float32 else dict(atol=3e-2, rtol=3e-2)
+
+
+def _rnd(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (1, 8, 8), (577 * 2, 2304, 768), (70, 96, 1536)])
+def test_gemm_nt_plain(dtype, M, N, K):
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    A = _rnd((M, K), dtype, dev, 1)
+    B = _rnd((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 3)
+    aux = _rnd((M, N), dtype, dev, 4)
+    ref = A.double() @ B.double().t() + bias.double()
+    out = ops.gemm_nt(A, B, bias)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype))
+    # gelu + second output (pre-activation)
+    out, pre = ops.gemm_nt(A, B, bias, act=L.ACT_GELU, c2_mode=2)
+    torch.testing.assert_close(pre.double(), ref, **_tol(dtype))
+    torch.testing.assert_close(out.double(), F.gelu(ref), **_tol(dtype))
+    # residual add + relu copy
+    out, r = ops.gemm_nt(A, B, bias, aux=aux, c2_mode=1)
+    torch.testing.assert_close(out.double(), ref + aux.double(), **_tol(dtype))
+    torch.testing.assert_close(r.double(), F.relu(out.double()), **_tol(dtype))
+    # relu-mask and dgelu-mask epilogues (backward forms), f32 output
+    out = ops.gemm_nt(A, B, None, aux=aux, mask_relu=True, out_f32=True)
+    torch.testing.assert_close(out.double(), (A.double() @ B.double().t()) * (aux.double() > 0), **_tol(dtype))
+    x = aux.double().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    out = ops.gemm_nt(A, B, None, aux=aux, mask_dgelu=True)
+    torch.testing.assert_close(out.double(), (A.double() @ B.double().t()) * x.grad, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_nt_rowbias_and_strided(dtype):
+    from unmore_amd import ops
+    dev = _dev()
+    Bn, Ntok, D = 3, 17, 128
+    tok = _rnd((Bn, Ntok, D), dtype, dev, 5)
+    Wt = _rnd((D, D), dtype, dev, 6, D ** -0.5)
+    rb = _rnd((Bn, D), torch.float32, dev, 7)
+    A = tok.reshape(-1, D)
+    out = ops.gemm_nt(A, Wt, None, rowbias=rb, rows_per_batch=Ntok)
+    ref = A.double() @ Wt.double().t() + rb.double().repeat_interleave(Ntok, 0)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype))
+    # strided A (lda > K) and strided output
+    big = _rnd((40, 3 * D), dtype, dev, 8)
+    outbig = torch.zeros((40, 2 * D), dtype=dtype, device=dev)
+    ops.gemm_nt(big[:, D:2 * D], Wt, None, out=outbig[:, D:])
+    torch.testing.assert_close(outbig[:, D:].double(), big[:, D:2 * D].double() @ Wt.double().t(), **_tol(dtype))
+    assert outbig[:, :D].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nb,H,W,Cin,Cout,stride", [(2, 8, 8, 64, 128, 1), (1, 13, 9, 96, 40, 1), (2, 6, 4, 32, 256, 1),
+                                                     (2, 12, 12, 128, 128, 2), (1, 7, 5, 64, 64, 2), (1, 24, 24, 256, 256, 1)])
+def test_conv3x3_fwd(dtype, nb, H, W, Cin, Cout, stride):
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((nb, H, W, Cin), dtype, dev, 11)
+    w = _rnd((Cout, Cin, 3, 3), dtype, dev, 12, (9 * Cin) ** -0.5)
+    bias = _rnd((Cout,), torch.float32, dev, 13)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    out = ops.gemm_nt(x, wp, bias, conv=2 if stride == 2 else 1)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=stride, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    torch.testing.assert_close(out.double(), ref, **_tol(dtype))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 200, 136), (5000, 768, 768), (33, 8, 16)])
+def test_gemm_tn_plain(dtype, M, N, K):
+    from unmore_amd import ops
+    dev = _dev()
+    dY = _rnd((M, N), dtype, dev, 21)
+    X = _rnd((M, K), dtype, dev, 22)
+    db = torch.empty(N, dtype=torch.float32, device=dev)
+    dW = ops.gemm_tn(dY, X, dbias=db)
+    ref = dY.double().t() @ X.double()
+    tol = dict(atol=2e-4 * M ** 0.5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2 * M ** 0.5, rtol=2e-2)
+    torch.testing.assert_close(dW.double(), ref, **tol)
+    torch.testing.assert_close(db.double(), dY.double().sum(0), **tol)
+    dW2 = ops.gemm_tn(dY, X, dW=dW.clone(), accumulate=True)
+    torch.testing.assert_close(dW2.double(), 2 * ref, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nb,H,W,Cin,Cout,stride", [(2, 8, 8, 64, 128, 1), (1, 13, 9, 96, 40, 1), (2, 12, 12, 128, 128, 2),
+                                                     (3, 24, 24, 256, 256, 1)])
+def test_conv3x3_wgrad(dtype, nb, H, W, Cin, Cout, stride):
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((nb, H, W, Cin), dtype, dev, 31)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    dy = _rnd((nb, Ho, Wo, Cout), dtype, dev, 32)
+    db = torch.empty(Cout, dtype=torch.float32, device=dev)
+    dW = ops.gemm_tn(dy, x, dbias=db, conv=2 if stride == 2 else 1)
+    xr = x.double().permute(0, 3, 1, 2)
+    wr = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, device=dev, requires_grad=True)
+    out = F.conv2d(xr, wr, None, stride=stride, padding=1)
+    out.backward(dy.double().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    M = nb * Ho * Wo
+    tol = dict(atol=2e-4 * M ** 0.5, rtol=1e-4) if dtype == torch.float32 else dict(atol=2e-2 * M ** 0.5, rtol=2e-2)
+    torch.testing.assert_close(dW.double(), ref, **tol)
+    torch.testing.assert_close(db.double(), dy.double().sum((0, 1, 2)), **tol)
+
+
+def test_invalid_arguments_raise():
+    from unmore_amd import ops
+    dev = _dev()
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros((4, 10), device=dev), torch.zeros((8, 10), device=dev))
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(torch.zeros((4, 8)), torch.zeros((8, 8)))  # CPU tensors: no fallback

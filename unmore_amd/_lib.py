@@ -1,0 +1,64 @@
+"""ctypes binding of the C-ABI library (include/umr.h).  Fails loudly when the
+HIP library is missing: there is no CPU / PyTorch fallback in the product path."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libumr.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS = 1, 2, 4, 8, 16, 32, 64
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+
+_vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [("A", _vp), ("B", _vp), ("C", _vp), ("C2", _vp), ("bias", _vp), ("aux", _vp),
+                ("aux2", _vp), ("rowbias", _vp),
+                ("lda", _i64), ("ldb", _i64), ("ldc", _i64), ("ldc2", _i64), ("ldaux", _i64), ("ldaux2", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("dtype", _i32),
+                ("flags", _i32), ("act", _i32), ("c2_mode", _i32), ("rows_per_batch", _i32),
+                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32)]
+
+
+class GemmTnDesc(ctypes.Structure):
+    _fields_ = [("dY", _vp), ("X", _vp), ("dW", _vp), ("dbias", _vp), ("workspace", _vp),
+                ("workspace_bytes", _i64), ("lddy", _i64), ("ldx", _i64), ("lddw", _i64),
+                ("M", _i32), ("N", _i32), ("K", _i32), ("dtype", _i32), ("accumulate", _i32),
+                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32)]
+
+
+def build(verbose=False, jobs=8):
+    """Compile every HIP source for gfx950 into unmore_amd/lib/libumr.so (hipcc
+    cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, f"-j{jobs}"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-8000:])
+    if r.returncode != 0:
+        raise RuntimeError("building libumr.so failed")
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the product has no CPU fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.umr_last_error_string.restype = ctypes.c_char_p
+        _lib.umr_gemm_tn_workspace.restype = ctypes.c_int64
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"{what} failed with status {status}: {lib().umr_last_error_string().decode()}")

@@ -1,0 +1,284 @@
+// Weight-gradient GEMM ("TN", reduction over rows), gfx950 MFMA.
+//   dW[N,K] (f32) = sum_m dY[m,N]^T . X[m,K]        (+ dbias[N] = sum_m dY[m,N])
+// Both operands are row-major with the REDUCTION index m as the row, so neither can
+// be read as an MFMA fragment directly.  Tiles are staged as they lie in memory
+// ([rows m][128 columns], 16-byte LDS-DMA) and transposed on the way to the registers:
+//   bf16: ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group -> column-major),
+//         LDS rows of 256 B with chunk XOR ((r&3)<<2 | (r>>2)&3) on source + read;
+//   f32 : ds_read_b32 (one element per lane, v_mfma_f32_16x16x4_f32).
+// 128 (n) x 128 (k) outputs per 256-thread workgroup, 4 waves as 2x2; the row range is
+// split over `splits` workgroups which write f32 slabs reduced in fixed order by a
+// second kernel (bitwise reproducible, no float atomics).
+// Implicit 3x3 conv: X row for (m, tap) = input pixel (oy*s+ky-1, ox*s+kx-1); the
+// K index is (tap, ci), so dW comes out as [N][3][3][Cin].
+// dbias rides along on workgroups with k-tile 0: one extra MFMA against an all-ones
+// fragment per n-tile and k-step.
+#include "umr_common.h"
+
+namespace {
+
+constexpr int TN_BN = 128, TN_BK = 128;
+constexpr int TN_LDS = 65536;
+
+template <typename T> struct TnTr;
+template <> struct TnTr<bf16_t> { static constexpr int ROWS = 64, ROWB = 256, RPI = 4; };  // rows/stage, bytes/row, rows per glds
+template <> struct TnTr<float> { static constexpr int ROWS = 32, ROWB = 512, RPI = 2; };
+
+__device__ __forceinline__ int tn_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+template <typename T, int CONV>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc p, int tiles_k, int rows_per_split,
+                                                         float* slab, float* bslab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWS = TnTr<T>::ROWS, ROWB = TnTr<T>::ROWB, RPI = TnTr<T>::RPI;
+    constexpr int EPC = 16 / sizeof(T);
+    constexpr int TILE = ROWS * ROWB;  // 16 KiB
+    constexpr int STAGE = 2 * TILE;
+    constexpr int CPR = ROWB / 16;  // chunks per row: 16 (bf16) / 32 (f32)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * TN_BN, k0 = tk * TN_BK;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(p.M, m_begin + rows_per_split);
+    const char* zero = (const char*)umr_zero_page;
+    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+
+    // ---- staging roles: per stage each wave issues 4 glds per operand; instruction i of
+    // wave w covers rows (w*4+i)*RPI + lane/CPR, chunk position lane%CPR.
+    const int lrow = lane / CPR, lchk = lane % CPR;
+    int gch[4];
+    bool n_ok[4], k_ok[4];
+    int k_tap[4], k_ci[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (w * 4 + i) * RPI + lrow;
+        gch[i] = (sizeof(T) == 2) ? (lchk ^ tn_swz(r)) : lchk;
+        n_ok[i] = (n0 + gch[i] * EPC) < p.N;
+        const int kc = k0 + gch[i] * EPC;
+        k_ok[i] = kc < p.K;
+        k_tap[i] = 0;
+        k_ci[i] = kc;
+        if (CONV != 0 && k_ok[i]) {
+            k_tap[i] = kc / p.Cin;
+            k_ci[i] = kc - k_tap[i] * p.Cin;
+        }
+    }
+    const int stride = (CONV == 2) ? 2 : 1;
+
+    auto stage = [&](int mbase, int buf) {
+        char* sa = smem + buf * STAGE + w * 4096;  // dY tile
+        char* sb = sa + TILE;                      // X tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (w * 4 + i) * RPI + lrow;
+            const int m = mbase + r;
+            const bool mok = m < m_end;
+            const char* srcA = (mok && n_ok[i])
+                                   ? (const char*)p.dY + ((int64_t)m * p.lddy + n0 + gch[i] * EPC) * (int64_t)sizeof(T)
+                                   : zero;
+            const char* srcB = zero;
+            if (CONV == 0) {
+                if (mok && k_ok[i]) srcB = (const char*)p.X + ((int64_t)m * p.ldx + k_ci[i]) * (int64_t)sizeof(T);
+            } else {
+                if (mok && k_ok[i]) {
+                    const int hw = p.Ho * p.Wo;
+                    const int b = m / hw, rem = m - b * hw;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    const int ky = k_tap[i] / 3, kx = k_tap[i] - ky * 3;
+                    const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                        srcB = (const char*)p.X + ((((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * (int64_t)sizeof(T);
+                }
+            }
+            glds16(srcA, sa + i * 1024);
+            glds16(srcB, sb + i * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int wn = w >> 1, wk = w & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int nstages = (m_end > m_begin) ? (m_end - m_begin + ROWS - 1) / ROWS : 0;
+    if (nstages > 0) stage(m_begin, 0);
+    for (int t = 0; t < nstages; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nstages) stage(m_begin + (t + 1) * ROWS, (t + 1) & 1);
+        const char* sA = smem + (t & 1) * STAGE;
+        const char* sB = sA + TILE;
+        if constexpr (sizeof(T) == 2) {
+            // lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of the block
+            const int q = li >> 2, pp = li & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int r = ks * 32 + g * 8 + half * 4 + q;
+                    const int sw = tn_swz(r);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int ca = (wn * 64 + i * 16) / 8 + (pp >> 1);
+                        const int cb = (wk * 64 + i * 16) / 8 + (pp >> 1);
+                        const char* pa = sA + r * ROWB + ((ca ^ sw) << 4) + ((pp & 1) << 3);
+                        const char* pb = sB + r * ROWB + ((cb ^ sw) << 4) + ((pp & 1) << 3);
+                        bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pa);
+                        bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            fa[i][half * 4 + e] = va[e];
+                            fb[i][half * 4 + e] = vb[e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kt], fa[nt], acc[nt][kt], 0, 0, 0);
+                if (do_bias) {
+                    bf16x8 ones;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[nt], accb[nt], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < ROWS / 4; ++ks) {
+                const int r = ks * 4 + g;
+                float fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    fa[i] = *(const float*)(sA + r * ROWB + (wn * 64 + i * 16 + li) * 4);
+                    fb[i] = *(const float*)(sB + r * ROWB + (wk * 64 + i * 16 + li) * 4);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+                        acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[kt], fa[nt], acc[nt][kt], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        accb[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, fa[nt], accb[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // D[i = k_local][j = n_local]: lane holds n = li, k = 4*g + reg
+    float* out = slab + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + li;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + g * 4;
+            if (k >= p.K) continue;
+            float* o = out + (int64_t)n * p.K + k;
+            if (k + 3 < p.K && (p.K & 3) == 0) *(f32x4*)o = acc[nt][kt];
+            else { for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[nt][kt][e]; }
+        }
+        if (do_bias && wk == 0 && g == 0) bslab[(int64_t)split * p.N + n] = accb[nt][0];
+    }
+}
+
+__global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int64_t lddw, int N, int K,
+                                 int splits, int accumulate, const float* __restrict__ bslab, float* __restrict__ dbias) {
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += slab[(int64_t)sp * total + i];
+        const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
+        float* o = dW + (int64_t)n * lddw + k;
+        *o = accumulate ? (*o + s) : s;
+    }
+    if (dbias != nullptr) {
+        for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+            float s = 0.f;
+            for (int sp = 0; sp < splits; ++sp) s += bslab[(int64_t)sp * N + n];
+            dbias[n] = accumulate ? (dbias[n] + s) : s;
+        }
+    }
+}
+
+struct TnPlan { int tiles_n, tiles_k, splits, rows_per_split; int64_t ws; };
+
+TnPlan tn_plan(const umr_gemm_tn_desc* d) {
+    TnPlan pl;
+    pl.tiles_n = (d->N + TN_BN - 1) / TN_BN;
+    pl.tiles_k = (d->K + TN_BK - 1) / TN_BK;
+    const int64_t tiles = (int64_t)pl.tiles_n * pl.tiles_k;
+    const int rows = d->dtype == UMR_BF16 ? 64 : 32;
+    int64_t want = (1536 + tiles - 1) / tiles;              // ~6 workgroups per CU in flight
+    const int64_t max_by_rows = ((int64_t)d->M + rows * 8 - 1) / (rows * 8);  // >= 8 stages per split
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    if (want > 4096) want = 4096;
+    int64_t rps = ((int64_t)d->M + want - 1) / want;
+    rps = (rps + rows - 1) / rows * rows;
+    pl.rows_per_split = (int)rps;
+    pl.splits = (int)(((int64_t)d->M + rps - 1) / rps);
+    pl.ws = ((int64_t)pl.splits * d->N * d->K + (int64_t)pl.splits * d->N) * 4;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t umr_gemm_tn_workspace(const umr_gemm_tn_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    return tn_plan(d).ws;
+}
+
+extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
+    UMR_CHECK_ARG(d != nullptr, "gemm_tn: null descriptor");
+    UMR_CHECK_ARG(d->dY && d->X && d->dW && d->workspace, "gemm_tn: null operand");
+    UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn: empty problem");
+    UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16, "gemm_tn: dtype");
+    const int epc = d->dtype == UMR_BF16 ? 8 : 4;
+    UMR_CHECK_ARG(d->N % epc == 0 && d->lddy % epc == 0, "gemm_tn: N/lddy must be multiples of 16 bytes");
+    UMR_CHECK_ARG(d->conv >= 0 && d->conv <= 2, "gemm_tn: conv mode");
+    if (d->conv == 0) {
+        UMR_CHECK_ARG(d->K % epc == 0 && d->ldx % epc == 0, "gemm_tn: K/ldx must be multiples of 16 bytes");
+    } else {
+        UMR_CHECK_ARG(d->Cin % epc == 0 && d->K == 9 * d->Cin, "gemm_tn: conv needs Cin % 16B == 0 and K == 9*Cin");
+        UMR_CHECK_ARG((int64_t)d->nb * d->Ho * d->Wo == d->M, "gemm_tn: conv M != nb*Ho*Wo");
+        const int s = d->conv == 2 ? 2 : 1;
+        UMR_CHECK_ARG(d->Ho == (d->H - 1) / s + 1 && d->Wo == (d->W - 1) / s + 1, "gemm_tn: conv output size");
+    }
+    const TnPlan pl = tn_plan(d);
+    UMR_CHECK_ARG(d->workspace_bytes >= pl.ws, "gemm_tn: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* slab = (float*)d->workspace;
+    float* bslab = slab + (int64_t)pl.splits * d->N * d->K;
+    dim3 g((unsigned)(pl.tiles_n * pl.tiles_k), (unsigned)pl.splits), b(256);
+#define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_tn_kernel<T, CV>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
+    if (d->dtype == UMR_BF16) {
+        if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
+    } else {
+        if (d->conv == 0) LAUNCH(float, 0); else if (d->conv == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
+    }
+#undef LAUNCH
+    UMR_LAUNCH_CHECK();
+    const int64_t total = (int64_t)d->N * d->K;
+    int rb = (int)((total + 255) / 256);
+    if (rb > 4096) rb = 4096;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
+                       d->accumulate, bslab, d->dbias);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -1,0 +1,72 @@
+// Shared device/host helpers for the unmore_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/umr.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define UMR_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define UMR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+// 16-byte async global -> LDS copy: LDS destination = wave-uniform base + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(UMR_GLOBAL_PTR(gsrc), UMR_LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 4 consecutive elements <-> registers
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ f32x4 load(const bf16_t* p) {
+        bf16x4 t = *(const bf16x4*)p;
+        f32x4 r = {(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        return r;
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, f32x4 v) {
+        bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *(bf16x4*)p = t;
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// zero page: source address for masked LDS-DMA lanes (one copy per translation unit;
+// the library is built without relocatable device code)
+static __device__ uint4 umr_zero_page[16];
+
+// host-side error plumbing (umr_api.hip)
+int umr_set_error(int code, const char* msg);
+#define UMR_CHECK_ARG(cond, msg) do { if (!(cond)) return umr_set_error(UMR_ERR_INVALID, msg); } while (0)
+#define UMR_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return umr_set_error(UMR_ERR_HIP - (int)e_, hipGetErrorString(e_)); } while (0)

@@ -57,6 +57,12 @@ typedef struct umr_gemm_desc {
     int32_t flags, act, c2_mode, rows_per_batch;
     int32_t conv;         /* 0 plain; 1 = 3x3 stride 1 pad 1; 2 = 3x3 stride 2 pad 1 */
     int32_t nb, H, W, Cin, Ho, Wo; /* conv geometry: A is [nb,H,W,Cin]; M = nb*Ho*Wo; K = 9*Cin */
+    /* optional row remaps (0 = identity): logical row m -> (m / rows_in) * rows_out + row_off + m % rows_in.
+     * a_*: rows of A (plain mode); c_*: rows of C, C2, aux, aux2 (token buffers with a class-token row per image,
+     * models/dpt/vit.py:87-88,188-193).  aux_mod > 0: aux row = m % aux_mod (broadcast over images: pos-embed add, vit.py:193) */
+    int32_t a_rows_in, a_rows_out, a_row_off;
+    int32_t c_rows_in, c_rows_out, c_row_off;
+    int32_t aux_mod;
 } umr_gemm_desc;
 
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
@@ -80,10 +86,68 @@ typedef struct umr_gemm_tn_desc {
     int32_t dtype;
     int32_t accumulate;   /* dW += instead of = */
     int32_t conv, nb, H, W, Cin, Ho, Wo;
+    /* optional row remaps (0 = identity), as in umr_gemm_desc: dy_* for dY rows, x_* for X rows (plain mode) */
+    int32_t dy_rows_in, dy_rows_out, dy_row_off;
+    int32_t x_rows_in, x_rows_out, x_row_off;
 } umr_gemm_tn_desc;
 
 int64_t umr_gemm_tn_workspace(const umr_gemm_tn_desc* d);
 int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream);
+
+/* ---- LayerNorm over rows of D (timm LayerNorm eps 1e-6 inside Block; vit.py:196-199) ----
+ * bwd: dx = LN'(dy) (+ dres if non-null: residual-branch gradient), dgamma/dbeta (f32, =/+= per `accumulate`). */
+int umr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int M, int D, float eps, int dtype, umr_stream_t stream);
+int64_t umr_layernorm_bwd_workspace(int M, int D);
+int umr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                      int64_t workspace_bytes, int M, int D, int dtype, umr_stream_t stream);
+
+/* ---- fused attention (timm Attention / F.scaled_dot_product_attention; scale head_dim^-0.5) ----
+ * qkv [B*N, 3*heads*64] as produced by the qkv GEMM; out [B*N, heads*64]; lse f32 [B*heads*N].
+ * bwd writes dqkv in the qkv layout; dsum_ws is f32 [B*heads*N] scratch. head_dim must be 64. */
+int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int head_dim, int dtype,
+                      umr_stream_t stream);
+int umr_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum_ws, void* dqkv,
+                      int B, int N, int heads, int head_dim, int dtype, umr_stream_t stream);
+
+/* ---- data movement / small ops ------------------------------------------------------------
+ * patchify: NCHW f32 image -> patch rows [B*gh*gw][ldk] (K order c,py,px = Conv2d weight order; vit.py:179)
+ * bilinear: NHWC resize, align_corners as given (blocks.py:155-172,377-379; vit.py:157) and its exact adjoint
+ * pixel_shuffle: ConvTranspose2d with kernel == stride as GEMM + scatter (vit.py:270-302); inverse gathers
+ * zero_stuff2: scatter for the data gradient of the stride-2 3x3 conv (vit.py:329-335)
+ * permute4: weight packing / unpacking (4-D permutation with arbitrary, possibly negative, source strides)
+ * segsum / fill_cls / cast: reductions over images, class-token row init (vit.py:188-193), dtype casts */
+int umr_patchify(const float* images, void* out, int B, int H, int W, int patch, int ldk, int dtype, umr_stream_t stream);
+int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, umr_stream_t stream);
+int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, umr_stream_t stream);
+int umr_pixel_shuffle(const void* src, void* dst, int B, int H, int W, int s, int C, int inverse, int dtype, umr_stream_t stream);
+int umr_zero_stuff2(const void* dy, void* out, int B, int H, int W, int Ho, int Wo, int C, int dtype, umr_stream_t stream);
+int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int64_t* src_strides, int64_t src_offset,
+                 int dtype_in, int dtype_out, int accumulate, umr_stream_t stream);
+int umr_segsum(const void* x, void* out, int R, int reps, int64_t rep_stride, int64_t seg_stride, int C, int dtype_in,
+               int out_f32, int accumulate, umr_stream_t stream);
+int umr_fill_cls(void* tokens, const float* cls, const float* pos0, int B, int64_t batch_stride, int D, int dtype, umr_stream_t stream);
+int umr_cast(const void* src, void* dst, int64_t n, float scale, int dtype_in, int dtype_out, umr_stream_t stream);
+
+/* ---- head output layer 1024 -> {1,2} (+tanh / sine=4), NCHW f32 output (objectness_net.py:116,133-134) ---- */
+int umr_head_out_fwd(const void* h, const float* w, const float* bias, float* out, int64_t M, int K, int Cout, int HW, int act,
+                     int dtype, umr_stream_t stream);
+int64_t umr_head_out_bwd_workspace(int64_t M, int K);
+int umr_head_out_bwd(const void* h, const float* w, const float* dout, const float* yout, void* dh, float* dw, float* db,
+                     void* workspace, int64_t workspace_bytes, int64_t M, int K, int Cout, int HW, int act, int relu_mask,
+                     int dtype, umr_stream_t stream);
+
+/* ---- fused 4-term loss, value + gradient (train_objectness_net.py:215-254) -----------------
+ * all maps NCHW f32; out5 = [total, center, sdf, sdf-gradient, bce]; d_center / d_sdf may be NULL (value only). */
+int64_t umr_loss_workspace(void);
+int umr_objectness_loss(const float* pred_center, const float* pred_sdf, const float* gt_center, const float* gt_sdf,
+                        const float* gt_saliency, float* d_center, float* d_sdf, float* out5, void* workspace, int B, int H,
+                        int W, int center_l2, int sdf_l2, int use_grad, int use_bce, float grad_scale, umr_stream_t stream);
+
+/* ---- Adam on a flat f32 parameter buffer (torch.optim.Adam defaults; train_objectness_net.py:96,260) ---- */
+int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                  int step, float grad_scale, umr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,236 @@
+"""GPU parity of the non-GEMM kernels (LayerNorm, attention, resize, shuffles, head
+output layer, loss, Adam) against PyTorch fp64 references / the CPU oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch.device("cuda:0")
+
+
+def _rnd(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev).to(dtype)
+
+
+def _tol(dtype, f32=2e-5, bf=3e-2):
+    return dict(atol=f32, rtol=f32) if dtype == torch.float32 else dict(atol=bf, rtol=bf)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,D", [(37, 128), (300, 768), (130, 1024), (5, 384)])
+def test_layernorm(dtype, M, D):
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((M, D), dtype, dev, 1, 2.0)
+    g = (1 + 0.1 * _rnd((D,), torch.float32, dev, 2))
+    b = 0.1 * _rnd((D,), torch.float32, dev, 3)
+    dy = _rnd((M, D), dtype, dev, 4)
+    dres = _rnd((M, D), dtype, dev, 5)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, eps=1e-6)
+    torch.testing.assert_close(y.double(), yr.detach(), **_tol(dtype))
+    yr.backward(dy.double())
+    dg = torch.empty(D, dtype=torch.float32, device=dev)
+    db = torch.empty(D, dtype=torch.float32, device=dev)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres)
+    torch.testing.assert_close(dx.double(), xr.grad + dres.double(), **_tol(dtype, 5e-5, 6e-2))
+    t = dict(atol=1e-3, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.3, rtol=5e-2)
+    torch.testing.assert_close(dg.double(), gr.grad, **t)
+    torch.testing.assert_close(db.double(), br.grad, **t)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,heads", [(2, 65, 2), (1, 577, 3), (3, 100, 1), (2, 17, 2)])
+def test_attention(dtype, B, N, heads):
+    from unmore_amd import ops
+    dev = _dev()
+    D = heads * 64
+    qkv = _rnd((B * N, 3 * D), dtype, dev, 1, 1.0)
+    dout = _rnd((B * N, D), dtype, dev, 2)
+    out, lse = ops.attention_fwd(qkv, B, N, heads)
+    qr = qkv.double().requires_grad_(True)
+    t = qr.reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0], t[1], t[2]
+    att = ((q * 0.125) @ k.transpose(-2, -1)).softmax(-1)
+    ref = (att @ v).transpose(1, 2).reshape(B * N, D)
+    torch.testing.assert_close(out.double(), ref.detach(), **_tol(dtype, 2e-5, 2e-2))
+    ref.backward(dout.double())
+    dqkv = ops.attention_bwd(qkv, out, dout, lse, B, N, heads)
+    torch.testing.assert_close(dqkv.double(), qr.grad, **_tol(dtype, 5e-5, 5e-2))
+
+
+def test_attention_large_scores_f32():
+    """online-softmax rescale path: one key dominates late in the sequence."""
+    from unmore_amd import ops
+    dev = _dev()
+    B, N, heads = 1, 130, 1
+    qkv = _rnd((B * N, 192), torch.float32, dev, 3, 0.5)
+    qkv[100, 64:128] = qkv[7, 0:64] * 40.0  # key 100 aligned with query 7
+    out, _ = ops.attention_fwd(qkv, B, N, heads)
+    t = qkv.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, 64)
+    torch.testing.assert_close(out.double(), ref, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p,H,W", [(16, 64, 96), (14, 42, 28)])
+def test_patchify(dtype, p, H, W):
+    from unmore_amd import ops
+    dev = _dev()
+    img = torch.rand((2, 3, H, W), generator=torch.Generator().manual_seed(0)).to(dev)
+    k = 3 * p * p
+    ldk = (k + 7) // 8 * 8
+    out = ops.patchify(img, p, dtype, ldk)
+    ref = F.unfold(img, kernel_size=p, stride=p).transpose(1, 2).reshape(-1, k)
+    torch.testing.assert_close(out[:, :k].float(), ref.to(dtype).float(), atol=0, rtol=0)
+    assert out[:, k:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Hi,Wi,Ho,Wo,align", [(6, 4, 12, 8, True), (12, 12, 24, 24, True), (24, 24, 8, 8, False),
+                                               (24, 24, 37, 30, False), (19, 19, 37, 37, True), (1, 1, 2, 2, True)])
+def test_bilinear(dtype, Hi, Wi, Ho, Wo, align):
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((2, Hi, Wi, 16), dtype, dev, 1)
+    dy = _rnd((2, Ho, Wo, 16), dtype, dev, 2)
+    y = ops.bilinear_fwd(x, Ho, Wo, align)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=align)
+    torch.testing.assert_close(y.double(), yr.detach().permute(0, 2, 3, 1), **_tol(dtype, 1e-5, 2e-2))
+    yr.backward(dy.double().permute(0, 3, 1, 2))
+    dx = ops.bilinear_bwd(dy, Hi, Wi, align)
+    torch.testing.assert_close(dx.double(), xr.grad.permute(0, 2, 3, 1), **_tol(dtype, 2e-5, 3e-2))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("s", [2, 4])
+def test_convtranspose_as_gemm_plus_shuffle(dtype, s):
+    from unmore_amd import ops
+    dev = _dev()
+    B, H, W, C = 2, 3, 5, 32
+    x = _rnd((B, H, W, C), dtype, dev, 1)
+    w = _rnd((C, C, s, s), dtype, dev, 2, C ** -0.5)  # ConvTranspose2d weight [in, out, kh, kw]
+    bias = _rnd((C,), torch.float32, dev, 3)
+    wp = w.permute(2, 3, 1, 0).reshape(s * s * C, C).contiguous()  # [(i,j,co)][ci]
+    y = ops.gemm_nt(x.reshape(-1, C), wp, bias.repeat(s * s))
+    y = ops.pixel_shuffle(y, B, H, W, s, C)
+    ref = F.conv_transpose2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=s).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y.double(), ref, **_tol(dtype))
+    back = ops.pixel_shuffle(y, B, H, W, s, C, inverse=True)
+    y2 = ops.pixel_shuffle(back, B, H, W, s, C)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,W", [(12, 12), (7, 5)])
+def test_stride2_dgrad_via_zero_stuffing(dtype, H, W):
+    from unmore_amd import ops
+    dev = _dev()
+    B, C = 2, 64
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w = _rnd((C, C, 3, 3), dtype, dev, 1, (9 * C) ** -0.5)
+    dy = _rnd((B, Ho, Wo, C), dtype, dev, 2)
+    xr = torch.zeros((B, C, H, W), dtype=torch.float64, device=dev, requires_grad=True)
+    F.conv2d(xr, w.double(), None, stride=2, padding=1).backward(dy.double().permute(0, 3, 1, 2))
+    wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * C).contiguous()  # [ci][ky'][kx'][co]
+    dx = ops.gemm_nt(ops.zero_stuff2(dy, H, W), wd, None, conv=1)
+    torch.testing.assert_close(dx.double().reshape(B, H, W, C), xr.grad.permute(0, 2, 3, 1), **_tol(dtype))
+
+
+def test_permute4_pack_and_flip():
+    from unmore_amd import ops
+    dev = _dev()
+    w = _rnd((8, 6, 3, 3), torch.float32, dev, 1)
+    dst = torch.empty((8, 3, 3, 6), dtype=torch.bfloat16, device=dev)
+    st = w.stride()
+    ops.permute4(w, dst, (8, 3, 3, 6), (st[0], st[2], st[3], st[1]))
+    assert torch.equal(dst, w.permute(0, 2, 3, 1).to(torch.bfloat16))
+    # dgrad packing: [ci][2-ky][2-kx][co]
+    dst2 = torch.empty((6, 3, 3, 8), dtype=torch.float32, device=dev)
+    ops.permute4(w, dst2, (6, 3, 3, 8), (st[1], -st[2], -st[3], st[0]), src_offset=2 * st[2] + 2 * st[3])
+    assert torch.equal(dst2, w.flip(2, 3).permute(1, 2, 3, 0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Cout,act", [(2, 0), (1, 3)])
+def test_head_out(dtype, Cout, act):
+    from unmore_amd import ops
+    dev = _dev()
+    B, H, W, K = 2, 9, 7, 1024
+    h = _rnd((B * H * W, K), dtype, dev, 1).relu()
+    w = _rnd((Cout, K), torch.float32, dev, 2, K ** -0.5)
+    b = _rnd((Cout,), torch.float32, dev, 3)
+    dout = _rnd((B, Cout, H, W), torch.float32, dev, 4)
+    out = ops.head_out_fwd(h, w, b, B, H, W, act)
+    hr = h.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    pre = (hr @ wr.t() + br).reshape(B, H, W, Cout).permute(0, 3, 1, 2)
+    ref = torch.tanh(pre) if act == 3 else pre
+    torch.testing.assert_close(out.double(), ref.detach(), atol=2e-5, rtol=2e-5)
+    ref.backward(dout.double())
+    dw = torch.empty_like(w)
+    db = torch.empty_like(b)
+    dh = ops.head_out_bwd(h, w, dout, out, act, True, dw, db)
+    torch.testing.assert_close(dh.double(), hr.grad * (h.double() > 0), **_tol(dtype, 2e-5, 2e-2))
+    torch.testing.assert_close(dw.double(), wr.grad, atol=2e-3, rtol=1e-3)
+    torch.testing.assert_close(db.double(), br.grad, atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("center_l2,sdf_l2,use_grad,use_bce", [(True, False, True, True), (False, True, True, False),
+                                                               (True, False, False, False)])
+def test_loss_matches_oracle(center_l2, sdf_l2, use_grad, use_bce):
+    from unmore_amd import ops
+    from oracle import objectness_oracle as orc
+    dev = _dev()
+    B, H, W = 3, 11, 13
+    g = torch.Generator().manual_seed(0)
+    pc = torch.randn((B, 2, H, W), generator=g)
+    ps = torch.tanh(torch.randn((B, 1, H, W), generator=g))
+    gc = torch.randn((B, 2, H, W), generator=g)
+    gs = torch.tanh(torch.randn((B, 1, H, W), generator=g))
+    sal = (torch.rand((B, 1, H, W), generator=g) > 0.5).float()
+    pcr, psr = pc.clone().requires_grad_(True), ps.clone().requires_grad_(True)
+    total, terms = orc.loss_terms({"center_fields": pcr, "sdf_maps": psr}, gc, gs, sal,
+                                  "l2" if center_l2 else "l1", "l2" if sdf_l2 else "l1", use_grad, use_bce)
+    total.backward()
+    out5, dpc, dps = ops.objectness_loss(pc.to(dev), ps.to(dev), gc.to(dev), gs.to(dev), sal.to(dev),
+                                         center_l2, sdf_l2, use_grad, use_bce)
+    out5 = out5.cpu()
+    assert abs(out5[0].item() - total.item()) < 1e-5
+    names = [0, 1] + ([2] if use_grad else []) + ([3] if use_bce else [])
+    for t, i in zip(terms, names):
+        assert abs(out5[1 + i].item() - t.item()) < 1e-5
+    torch.testing.assert_close(dpc.cpu(), pcr.grad, atol=1e-7, rtol=1e-5)
+    torch.testing.assert_close(dps.cpu(), psr.grad, atol=1e-7, rtol=1e-5)
+
+
+def test_adam_matches_oracle():
+    from unmore_amd import ops
+    from oracle import objectness_oracle as orc
+    dev = _dev()
+    g0 = torch.Generator().manual_seed(0)
+    p = torch.randn(1000, generator=g0)
+    m, v = torch.zeros(1000), torch.zeros(1000)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    for step in (1, 2, 3):
+        g = torch.randn(1000, generator=g0)
+        orc.adam_update(p, g, m, v, step)
+        ops.adam_step(pd, g.to(dev), md, vd, step)
+    torch.testing.assert_close(pd.cpu(), p, atol=1e-7, rtol=1e-6)
+    ref = torch.nn.Parameter(torch.zeros(4))
+    opt = torch.optim.Adam([ref], 1e-4)
+    ref.grad = torch.ones(4)
+    opt.step()
+    mine = torch.zeros(4, device=dev)
+    ops.adam_step(mine, torch.ones(4, device=dev), torch.zeros(4, device=dev), torch.zeros(4, device=dev), 1)
+    torch.testing.assert_close(mine.cpu(), ref.detach(), atol=1e-9, rtol=1e-6)

@@ -21,14 +21,18 @@ class GemmDesc(ctypes.Structure):
                 ("lda", _i64), ("ldb", _i64), ("ldc", _i64), ("ldc2", _i64), ("ldaux", _i64), ("ldaux2", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("dtype", _i32),
                 ("flags", _i32), ("act", _i32), ("c2_mode", _i32), ("rows_per_batch", _i32),
-                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32)]
+                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
+                ("a_rows_in", _i32), ("a_rows_out", _i32), ("a_row_off", _i32),
+                ("c_rows_in", _i32), ("c_rows_out", _i32), ("c_row_off", _i32), ("aux_mod", _i32)]
 
 
 class GemmTnDesc(ctypes.Structure):
     _fields_ = [("dY", _vp), ("X", _vp), ("dW", _vp), ("dbias", _vp), ("workspace", _vp),
                 ("workspace_bytes", _i64), ("lddy", _i64), ("ldx", _i64), ("lddw", _i64),
                 ("M", _i32), ("N", _i32), ("K", _i32), ("dtype", _i32), ("accumulate", _i32),
-                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32)]
+                ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
+                ("dy_rows_in", _i32), ("dy_rows_out", _i32), ("dy_row_off", _i32),
+                ("x_rows_in", _i32), ("x_rows_out", _i32), ("x_row_off", _i32)]
 
 
 def build(verbose=False, jobs=8):
@@ -45,6 +49,44 @@ def build(verbose=False, jobs=8):
 
 _lib = None
 
+_f32 = ctypes.c_float
+_SIGS = {
+    "umr_gemm_nt": [_vp, _vp],
+    "umr_gemm_tn": [_vp, _vp],
+    "umr_gemm_tn_workspace": [_vp],
+    "umr_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
+    "umr_layernorm_bwd_workspace": [_i32, _i32],
+    "umr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
+    "umr_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_bilinear_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_bilinear_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_pixel_shuffle": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_zero_stuff2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_permute4": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "umr_segsum": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
+    "umr_fill_cls": [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "umr_cast": [_vp, _vp, _i64, _f32, _i32, _i32, _vp],
+    "umr_head_out_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_head_out_bwd_workspace": [_i64, _i32],
+    "umr_head_out_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_loss_workspace": [],
+    "umr_objectness_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "umr_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "umr_version": [],
+    "umr_last_error_string": [],
+}
+
+
+def _set_argtypes(l):
+    for name, sig in _SIGS.items():
+        getattr(l, name).argtypes = sig
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
 
 def lib():
     global _lib
@@ -55,7 +97,9 @@ def lib():
                 "(the product has no CPU fallback)")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.umr_last_error_string.restype = ctypes.c_char_p
-        _lib.umr_gemm_tn_workspace.restype = ctypes.c_int64
+        _set_argtypes(_lib)
+        for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace"):
+            getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 
 

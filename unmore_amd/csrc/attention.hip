@@ -1,0 +1,376 @@
+// Fused scaled-dot-product attention for the ViT blocks (timm Attention: softmax(q k^T
+// * hd^-0.5) v; models/dpt/vit.py:196-197 via timm Block), head dim 64, forward and backward,
+// flash-style (scores never reach HBM), MFMA 16x16 (bf16 x32 / exact f32 x4).
+//
+// Layout: qkv is the qkv-GEMM output [B*N, 3*D] (q | k | v, heads contiguous inside each),
+// the output is [B*N, D]; gradients come back in the same [B*N, 3*D] layout.
+//
+// Forward / dQ kernels: one wave = 16 query rows, workgroup = 64 query rows; K/V tiles of
+// 32 keys staged in LDS.  Scores are computed TRANSPOSED (S^T = K Q^T) so that a lane owns
+// one query column: the online-softmax row reduction is 7 in-register max/adds plus two
+// shuffles, and the f32 score accumulator is already the B operand of the next MFMA
+// (O^T += V^T P^T) -- no LDS round trip for P.  V^T / K^T fragments come from the row-major
+// LDS tile by ds_read_b64_tr_b16 (bf16) or per-lane ds_read_b32 (f32).
+// dK/dV kernel: one wave = 16 keys (K, V fragments live in registers), loops over 32-query
+// tiles of Q and dO in LDS; S = Q K^T has the query on the accumulator rows, so P and dS
+// feed dV^T += dO^T P and dK^T += Q^T dS directly.  dQ and dK/dV are separate kernels
+// (no atomics: bitwise reproducible).
+// hd^-0.5 = 1/8 is folded into Q (K in the dK/dV kernel): exact in bf16 and f32.
+#include "umr_common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int KT = 32;  // keys (or queries) per LDS tile
+
+template <typename T> struct AT;
+template <> struct AT<bf16_t> { static constexpr int ROWB = 128, NF = 2; typedef bf16x8 frag_t; };
+template <> struct AT<float> { static constexpr int ROWB = 256, NF = 4; typedef f32x4 frag_t; };
+
+template <typename T> __device__ __forceinline__ int kswz(int r) { return sizeof(T) == 2 ? ((r >> 1) & 7) : (r & 15); }
+
+template <typename T> struct RowFrag { typename AT<T>::frag_t v[AT<T>::NF]; };
+
+// fragment of one row (64 head-dim values) for lane group g: chunks (4*i + g)
+template <typename T>
+__device__ __forceinline__ RowFrag<T> rowfrag_global(const T* row, int g, float scale) {
+    RowFrag<T> f;
+#pragma unroll
+    for (int i = 0; i < AT<T>::NF; ++i) {
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 t;
+            for (int e = 0; e < 8; ++e) t[e] = (bf16_t)0.f;
+            if (row) t = *(const bf16x8*)(row + (4 * i + g) * 8);
+            for (int e = 0; e < 8; ++e) f.v[i][e] = (bf16_t)((float)t[e] * scale);
+        } else {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (row) t = *(const f32x4*)(row + (4 * i + g) * 4);
+            f.v[i] = t * scale;
+        }
+    }
+    return f;
+}
+
+template <typename T>
+__device__ __forceinline__ RowFrag<T> rowfrag_lds(const char* tile, int r, int g) {
+    RowFrag<T> f;
+    const int sw = kswz<T>(r);
+#pragma unroll
+    for (int i = 0; i < AT<T>::NF; ++i)
+        f.v[i] = *(const typename AT<T>::frag_t*)(tile + r * AT<T>::ROWB + (((4 * i + g) ^ sw) << 4));
+    return f;
+}
+
+// acc(16x16) += A(rows) . B(rows)^T over the 64 head-dim values; D[i = A row][j = B row]
+template <typename T>
+__device__ __forceinline__ f32x4 mma_rows(f32x4 acc, const RowFrag<T>& a, const RowFrag<T>& b) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[i], b.v[i], acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[i][e], b.v[i][e], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// acc[dt](16 d x 16 cols) += X^T[d][r] . P[r][col], r over the 32 tile rows.  p0/p1 are the
+// accumulators of the two 16-row sub-tiles (lane group g holds rows 4g..4g+3 of each).
+template <typename T>
+__device__ __forceinline__ void mma_trans(f32x4 (&acc)[4], const char* tile, f32x4 p0, f32x4 p1, int lane) {
+    const int g = lane >> 4, li = lane & 15;
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pb[e] = (bf16_t)p0[e]; pb[4 + e] = (bf16_t)p1[e]; }
+        const int q = li >> 2, pp = li & 3;
+        const int r0 = 4 * g + q, r1 = 16 + 4 * g + q;
+        const int s0 = kswz<T>(r0), s1 = kswz<T>(r1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const int c = dt * 2 + (pp >> 1);
+            const char* a0 = tile + r0 * 128 + ((c ^ s0) << 4) + ((pp & 1) << 3);
+            const char* a1 = tile + r1 * 128 + ((c ^ s1) << 4) + ((pp & 1) << 3);
+            bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+            bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
+            bf16x8 va;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = v0[e]; va[4 + e] = v1[e]; }
+            acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, acc[dt], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int r = 16 * sub + 4 * g + s;
+                const int sw = kswz<T>(r);
+                const float pv = sub == 0 ? p0[s] : p1[s];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int d = dt * 16 + li;
+                    const float a = *(const float*)(tile + r * 256 + (((d >> 2) ^ sw) << 4) + ((d & 3) << 2));
+                    acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, pv, acc[dt], 0, 0, 0);
+                }
+            }
+    }
+}
+
+// stage a [32 rows][64] tile (rows r0.. of one head) into LDS, swizzled; rows >= nrows are zero
+template <typename T>
+__device__ __forceinline__ void load_tile(char* tile, const T* base, int64_t ld, int r0, int nrows, int tid) {
+    constexpr int CPR = AT<T>::ROWB / 16;
+    constexpr int EPC = 16 / sizeof(T);
+    for (int c = tid; c < KT * CPR; c += 256) {
+        const int r = c / CPR, ch = c - r * CPR;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < nrows) v = *(const uint4*)(base + (int64_t)(r0 + r) * ld + ch * EPC);
+        *(uint4*)(tile + r * AT<T>::ROWB + ((ch ^ kswz<T>(r)) << 4)) = v;
+    }
+}
+
+template <typename T> __device__ __forceinline__ float fexp(float x) { return sizeof(T) == 2 ? __expf(x) : expf(x); }
+
+// ------------------------------------------------------------------ forward
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
+                                                       int N, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
+    char* sK = smem;
+    char* sV = smem + KT * AT<T>::ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const T* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const T* kb = qb + D;
+    const T* vb = qb + 2 * D;
+    const int q = blockIdx.x * 64 + w * 16 + li;
+    const RowFrag<T> qf = rowfrag_global<T>(q < N ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < N; k0 += KT) {
+        __syncthreads();
+        load_tile<T>(sK, kb, ld, k0, N, tid);
+        load_tile<T>(sV, vb, ld, k0, N, tid);
+        __syncthreads();
+        f32x4 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const RowFrag<T> kf = rowfrag_lds<T>(sK, 16 * sub + li, g);
+            s[sub] = mma_rows<T>(f32x4{0.f, 0.f, 0.f, 0.f}, kf, qf);  // D[i = key][j = query]
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k0 + 16 * sub + 4 * g + e >= N) s[sub][e] = -INFINITY;
+                mx = fmaxf(mx, s[sub][e]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fexp<T>(m_run - m_new);
+        float ps = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[sub][e] = fexp<T>(s[sub][e] - m_new); ps += s[sub][e]; }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        mma_trans<T>(o, sV, s[0], s[1], lane);  // O^T[d][query] += V^T[d][key] P^T[key][query]
+    }
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q < N) {
+        const float inv = 1.0f / l_run;
+        T* orow = out + ((int64_t)b * N + q) * D + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) Vec4<T>::store(orow + dt * 16 + 4 * g, o[dt] * inv);
+        if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run + logf(l_run);
+    }
+}
+
+// ------------------------------------------------------------------ backward prep: Dq = rowsum(dO * O)
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ dq_sum, int B, int N,
+                                     int heads) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, n, h)
+    const int64_t total = (int64_t)B * N * heads;
+    if (idx >= total) return;
+    const int h = (int)(idx % heads);
+    const int64_t bn = idx / heads;
+    const int b = (int)(bn / N), n = (int)(bn - (int64_t)b * N);
+    const T* po = o + bn * heads * HD + h * HD;
+    const T* pd = dout + bn * heads * HD + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+        const f32x4 a = Vec4<T>::load(po + c * 4), d = Vec4<T>::load(pd + c * 4);
+        s += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+    }
+    dq_sum[((int64_t)b * heads + h) * N + n] = s;
+}
+
+// ------------------------------------------------------------------ backward: dQ
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                          const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                          T* __restrict__ dqkv, int N, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
+    char* sK = smem;
+    char* sV = smem + KT * AT<T>::ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const T* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const T* kb = qb + D;
+    const T* vb = qb + 2 * D;
+    const int q = blockIdx.x * 64 + w * 16 + li;
+    const bool qok = q < N;
+    const RowFrag<T> qf = rowfrag_global<T>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+    const RowFrag<T> dof = rowfrag_global<T>(qok ? dout + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
+    const float lse_q = qok ? lse[(int64_t)bh * N + q] : 0.f;
+    const float d_q = qok ? dsum[(int64_t)bh * N + q] : 0.f;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < N; k0 += KT) {
+        __syncthreads();
+        load_tile<T>(sK, kb, ld, k0, N, tid);
+        load_tile<T>(sV, vb, ld, k0, N, tid);
+        __syncthreads();
+        f32x4 ds[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const RowFrag<T> kf = rowfrag_lds<T>(sK, 16 * sub + li, g);
+            const RowFrag<T> vf = rowfrag_lds<T>(sV, 16 * sub + li, g);
+            const f32x4 s = mma_rows<T>(f32x4{0.f, 0.f, 0.f, 0.f}, kf, qf);    // S^T[key][query]
+            const f32x4 dp = mma_rows<T>(f32x4{0.f, 0.f, 0.f, 0.f}, vf, dof);  // dP^T[key][query]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool kok = (k0 + 16 * sub + 4 * g + e) < N;
+                const float p = kok ? fexp<T>(s[e] - lse_q) : 0.f;
+                ds[sub][e] = p * (dp[e] - d_q);
+            }
+        }
+        mma_trans<T>(acc, sK, ds[0], ds[1], lane);  // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+    }
+    if (qok) {
+        T* orow = dqkv + ((int64_t)b * N + q) * ld + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) Vec4<T>::store(orow + dt * 16 + 4 * g, acc[dt] * 0.125f);
+    }
+}
+
+// ------------------------------------------------------------------ backward: dK, dV
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           T* __restrict__ dqkv, int N, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
+    char* sQ = smem;
+    char* sO = smem + KT * AT<T>::ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const T* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const T* kb = qb + D;
+    const T* vb = qb + 2 * D;
+    const T* dob = dout + (int64_t)b * N * D + h * HD;
+    const int key = blockIdx.x * 64 + w * 16 + li;
+    const bool kok = key < N;
+    const RowFrag<T> kf = rowfrag_global<T>(kok ? kb + (int64_t)key * ld : nullptr, g, 0.125f);
+    const RowFrag<T> vf = rowfrag_global<T>(kok ? vb + (int64_t)key * ld : nullptr, g, 1.0f);
+    const float* lse_b = lse + (int64_t)bh * N;
+    const float* dsum_b = dsum + (int64_t)bh * N;
+
+    f32x4 accK[4], accV[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { accK[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int q0 = 0; q0 < N; q0 += KT) {
+        __syncthreads();
+        load_tile<T>(sQ, qb, ld, q0, N, tid);
+        load_tile<T>(sO, dob, (int64_t)D, q0, N, tid);
+        __syncthreads();
+        f32x4 p[2], ds[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const RowFrag<T> qf = rowfrag_lds<T>(sQ, 16 * sub + li, g);
+            const RowFrag<T> dof = rowfrag_lds<T>(sO, 16 * sub + li, g);
+            const f32x4 s = mma_rows<T>(f32x4{0.f, 0.f, 0.f, 0.f}, qf, kf);    // S[query][key]
+            const f32x4 dp = mma_rows<T>(f32x4{0.f, 0.f, 0.f, 0.f}, dof, vf);  // dP[query][key]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int qq = q0 + 16 * sub + 4 * g + e;
+                const bool qok = qq < N;
+                const float pe = qok ? fexp<T>(s[e] - lse_b[qok ? qq : 0]) : 0.f;
+                p[sub][e] = pe;
+                ds[sub][e] = pe * (dp[e] - (qok ? dsum_b[qq] : 0.f));
+            }
+        }
+        mma_trans<T>(accV, sO, p[0], p[1], lane);    // dV^T[d][key] += dO^T[d][query] P[query][key]
+        mma_trans<T>(accK, sQ, ds[0], ds[1], lane);  // dK^T[d][key] += Q^T[d][query] dS[query][key]
+    }
+    if (kok) {
+        T* krow = dqkv + ((int64_t)b * N + key) * ld + D + h * HD;
+        T* vrow = krow + D;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            Vec4<T>::store(krow + dt * 16 + 4 * g, accK[dt] * 0.125f);
+            Vec4<T>::store(vrow + dt * 16 + 4 * g, accV[dt]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int head_dim, int dtype,
+                                 umr_stream_t stream) {
+    UMR_CHECK_ARG(qkv && out, "attention_fwd: null pointer");
+    UMR_CHECK_ARG(B > 0 && N > 0 && heads > 0, "attention_fwd: empty problem");
+    if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g((N + 63) / 64, B * heads), b(256);
+    if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+    else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads);
+    else return umr_set_error(UMR_ERR_INVALID, "attention_fwd: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum_ws, void* dqkv,
+                                 int B, int N, int heads, int head_dim, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(qkv && out && dout && lse && dsum_ws && dqkv, "attention_bwd: null pointer");
+    UMR_CHECK_ARG(B > 0 && N > 0 && heads > 0, "attention_bwd: empty problem");
+    if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * N * heads;
+    dim3 gp((unsigned)((total + 255) / 256)), g((N + 63) / 64, B * heads), b(256);
+    if (dtype == UMR_BF16) {
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, gp, b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, dsum_ws, B, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);
+    } else if (dtype == UMR_F32) {
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, gp, b, 0, s, (const float*)out, (const float*)dout, dsum_ws, B, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads);
+    } else return umr_set_error(UMR_ERR_INVALID, "attention_bwd: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -1,0 +1,564 @@
+// HBM-bound helper kernels of the ObjectnessNet path: patch extraction, bilinear
+// resize (forward + exact adjoint), ConvTranspose pixel (un)shuffle, stride-2 zero
+// stuffing, weight packing (permute / flip / cast), small reductions, the 1024->{1,2}
+// head output layer, the fused 4-term loss (value + gradient in one pass), Adam.
+// All are coalesced over the channel (innermost) dimension with 16-byte accesses
+// where the layout allows; no atomics (every reduction is a fixed-order two-stage sum).
+#include "umr_common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ T cvt_out(float v) { return from_f32<T>(v); }
+
+// ---------------------------------------------------------------- patchify
+// images [B,3,H,W] f32 (NCHW) -> rows [B*gh*gw][ldk] T, K order (c, py, px); tail (ldk > 3*p*p) zero.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int p, int gh, int gw,
+                                int ldk) {
+    const int64_t total = (int64_t)B * gh * gw * 3 * p;  // one thread per (patch, c, py): p contiguous pixels
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // order: gx fastest among patches so that a wave reads consecutive p-pixel segments of one image row
+    const int gx = (int)(idx % gw);
+    int64_t r = idx / gw;
+    const int py = (int)(r % p); r /= p;
+    const int c = (int)(r % 3); r /= 3;
+    const int gy = (int)(r % gh);
+    const int b = (int)(r / gh);
+    const float* src = img + (((int64_t)b * 3 + c) * H + gy * p + py) * W + gx * p;
+    T* dst = out + ((int64_t)(b * gh + gy) * gw + gx) * ldk + (c * p + py) * p;
+    for (int x = 0; x < p; ++x) dst[x] = cvt_out<T>(src[x]);
+    if (c == 2 && py == p - 1) for (int k = 3 * p * p; k < ldk; ++k) out[((int64_t)(b * gh + gy) * gw + gx) * ldk + k] = cvt_out<T>(0.f);
+}
+
+// ---------------------------------------------------------------- bilinear resize, NHWC
+__device__ __forceinline__ void src_index(int o, float scale, int align, int in, int& i0, int& i1, float& l0, float& l1) {
+    float s = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.f - l1;
+}
+__device__ __forceinline__ float area_scale(int in, int out, int align) {
+    if (align) return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    return (float)in / (float)out;
+}
+
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        int64_t r = idx / cv;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
+        src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+        const T* base = x + (int64_t)b * Hi * Wi * C + c * 4;
+        const f32x4 v00 = Vec4<T>::load(base + ((int64_t)y0 * Wi + x0) * C), v01 = Vec4<T>::load(base + ((int64_t)y0 * Wi + x1) * C);
+        const f32x4 v10 = Vec4<T>::load(base + ((int64_t)y1 * Wi + x0) * C), v11 = Vec4<T>::load(base + ((int64_t)y1 * Wi + x1) * C);
+        f32x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+        Vec4<T>::store(y + idx * 4, o);
+    }
+}
+
+// exact adjoint by gathering: for input pixel (iy,ix) visit the few output pixels whose taps touch it
+__device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    lo = (int)floorf(((float)i - 1.f) / scale) - 1;
+    hi = (int)ceilf(((float)i + 1.f) / scale) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)B * Hi * Wi * cv;
+    const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        int64_t r = idx / cv;
+        const int ix = (int)(r % Wi); r /= Wi;
+        const int iy = (int)(r % Hi);
+        const int b = (int)(r / Hi);
+        int ylo, yhi, xlo, xhi;
+        out_range(iy, sh, Ho, ylo, yhi);
+        out_range(ix, sw, Wo, xlo, xhi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const T* base = dy + (int64_t)b * Ho * Wo * C + c * 4;
+        for (int oy = ylo; oy <= yhi; ++oy) {
+            int y0, y1; float ly0, ly1;
+            src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = xlo; ox <= xhi; ++ox) {
+                int x0, x1; float lx0, lx1;
+                src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                const f32x4 g = Vec4<T>::load(base + ((int64_t)oy * Wo + ox) * C);
+                acc += g * (wy * wx);
+            }
+        }
+        Vec4<T>::store(dx + idx * 4, acc);
+    }
+}
+
+// ---------------------------------------------------------------- pixel shuffle (ConvTranspose k == stride)
+// src [B*H*W][s*s*C] (column = (i*s+j)*C + c)  <->  dst [B, H*s, W*s, C];  inverse=1 gathers dst -> src layout
+template <typename T>
+__global__ void pixel_shuffle_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int s, int C, int inverse) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)B * H * W * s * s * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        int64_t r = idx / cv;
+        const int ij = (int)(r % (s * s)); r /= (s * s);
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const int i = ij / s, j = ij - i * s;
+        const int64_t a = idx * 4;  // [m][(i,j,c)] layout
+        const int64_t d = ((((int64_t)b * H * s + y * s + i) * W * s) + x * s + j) * C + c * 4;
+        if (inverse) Vec4<T>::store(dst + a, Vec4<T>::load(src + d));
+        else Vec4<T>::store(dst + d, Vec4<T>::load(src + a));
+    }
+}
+
+// dY [B,Ho,Wo,C] -> zero-stuffed [B,H,W,C] with out[2oy,2ox] = dY[oy,ox] (stride-2 conv data gradient)
+template <typename T>
+__global__ void zero_stuff2_kernel(const T* __restrict__ dy, T* __restrict__ out, int B, int H, int W, int Ho, int Wo, int C) {
+    const int cv = C >> 2;
+    const int64_t total = (int64_t)B * H * W * cv;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % cv);
+        int64_t r = idx / cv;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+            v = Vec4<T>::load(dy + (((int64_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * C + c * 4);
+        Vec4<T>::store(out + idx * 4, v);
+    }
+}
+
+// ---------------------------------------------------------------- generic 4-D permute (+flip) with cast
+struct PermDesc { int d[4]; int64_t sstride[4]; int64_t soff; };  // dst dims, src stride per dst dim (may be negative), src offset
+template <typename TI, typename TO>
+__global__ void permute4_kernel(const TI* __restrict__ src, TO* __restrict__ dst, PermDesc pd, int accumulate) {
+    const int64_t total = (int64_t)pd.d[0] * pd.d[1] * pd.d[2] * pd.d[3];
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = idx;
+        const int i3 = (int)(r % pd.d[3]); r /= pd.d[3];
+        const int i2 = (int)(r % pd.d[2]); r /= pd.d[2];
+        const int i1 = (int)(r % pd.d[1]);
+        const int i0 = (int)(r / pd.d[1]);
+        const float v = to_f32<TI>(src[pd.soff + i0 * pd.sstride[0] + i1 * pd.sstride[1] + i2 * pd.sstride[2] + i3 * pd.sstride[3]]);
+        if (accumulate) dst[idx] = from_f32<TO>(to_f32<TO>(dst[idx]) + v);
+        else dst[idx] = from_f32<TO>(v);
+    }
+}
+
+// ---------------------------------------------------------------- small reductions / fills
+// out[r][c] (f32 or T) = sum_{k<reps} x[(r*reps + k)*ld_rep + c]   (segment sum over `reps` consecutive row blocks)
+template <typename T, typename TO>
+__global__ void segsum_kernel(const T* __restrict__ x, TO* __restrict__ out, int R, int reps, int64_t rep_stride, int64_t seg_stride,
+                              int C, int accumulate) {
+    const int64_t total = (int64_t)R * C;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const int r = (int)(idx / C);
+        const T* p = x + (int64_t)r * seg_stride + c;
+        float s = 0.f;
+        for (int k = 0; k < reps; ++k) s += to_f32<T>(p[(int64_t)k * rep_stride]);
+        if (accumulate) s += to_f32<TO>(out[idx]);
+        out[idx] = from_f32<TO>(s);
+    }
+}
+
+// tokens[b, 0, :] = cls + pos[0, :]
+template <typename T>
+__global__ void fill_cls_kernel(T* __restrict__ tokens, const float* __restrict__ cls, const float* __restrict__ pos0, int B, int64_t bstride, int D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, c = idx - b * D;
+    tokens[(int64_t)b * bstride + c] = from_f32<T>(cls[c] + pos0[c]);
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<TO>(to_f32<TI>(src[i]) * scale);
+}
+
+// ---------------------------------------------------------------- head output layer: 1024 -> {1,2} (+ activation), NCHW f32 out
+// one wave per pixel row: lanes split K, wave reduction.  out[b][c][hw]
+template <typename T>
+__global__ __launch_bounds__(256) void head_out_fwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int64_t M, int K, int Cout, int HW, int act) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t m = wave; m < M; m += nw) {
+        const T* row = h + m * K;
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = lane * 4; k < K; k += 256) {
+            const f32x4 v = Vec4<T>::load(row + k);
+            const f32x4 w0 = *(const f32x4*)(w + k);
+            s0 += v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+            if (Cout == 2) {
+                const f32x4 w1 = *(const f32x4*)(w + K + k);
+                s1 += v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+            }
+        }
+        s0 = wave_sum(s0);
+        if (Cout == 2) s1 = wave_sum(s1);
+        if (lane == 0) {
+            const int64_t b = m / HW, hw = m - b * HW;
+            float v0 = s0 + bias[0];
+            if (act == UMR_ACT_TANH) v0 = tanhf(v0); else if (act == 4) v0 = sinf(v0);
+            out[(b * Cout) * HW + hw] = v0;
+            if (Cout == 2) {
+                float v1 = s1 + bias[1];
+                if (act == UMR_ACT_TANH) v1 = tanhf(v1); else if (act == 4) v1 = sinf(v1);
+                out[(b * Cout + 1) * HW + hw] = v1;
+            }
+        }
+    }
+}
+
+// backward: g[m][c] = dout[b][c][hw] * act'(.);  dh[m][k] = sum_c g[m][c] w[c][k] (optionally * (h>0): fused ReLU
+// backward of the producer);  partial dW[c][k], db[c] per block -> workspace, reduced by head_out_reduce.
+template <typename T>
+__global__ __launch_bounds__(256) void head_out_bwd_kernel(const T* __restrict__ h, const float* __restrict__ w, const float* __restrict__ dout,
+                                                           const float* __restrict__ yout, T* __restrict__ dh, float* __restrict__ part,
+                                                           int64_t M, int K, int Cout, int HW, int act, int relu_mask, int rows_per_block) {
+    // thread t owns columns k = 4t..4t+3 (K <= 1024); loops rows of this block
+    const int t = threadIdx.x;
+    const int k = t * 4;
+    const bool kok = k < K;
+    f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0}, a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+    if (kok) { w0 = *(const f32x4*)(w + k); if (Cout == 2) w1 = *(const f32x4*)(w + K + k); }
+    float b0 = 0.f, b1 = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int64_t m = r0; m < r1; ++m) {
+        const int64_t b = m / HW, hw = m - b * HW;
+        float g0 = dout[(b * Cout) * HW + hw], g1 = 0.f;
+        if (act == UMR_ACT_TANH) { const float y = yout[(b * Cout) * HW + hw]; g0 *= (1.f - y * y); }
+        if (Cout == 2) {
+            g1 = dout[(b * Cout + 1) * HW + hw];
+            if (act == UMR_ACT_TANH) { const float y = yout[(b * Cout + 1) * HW + hw]; g1 *= (1.f - y * y); }
+        }
+        if (kok) {
+            const f32x4 hv = Vec4<T>::load(h + m * K + k);
+            f32x4 d = w0 * g0 + w1 * g1;
+            if (relu_mask) for (int j = 0; j < 4; ++j) d[j] = hv[j] > 0.f ? d[j] : 0.f;
+            Vec4<T>::store(dh + m * K + k, d);
+            a0 += hv * g0;
+            a1 += hv * g1;
+        }
+        b0 += g0;
+        b1 += g1;
+    }
+    float* p = part + (int64_t)blockIdx.x * (2 * K + 2);
+    if (kok) { *(f32x4*)(p + k) = a0; *(f32x4*)(p + K + k) = a1; }
+    if (t == 0) { p[2 * K] = b0; p[2 * K + 1] = b1; }
+}
+
+__global__ void head_out_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K, int Cout) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * K + 2;
+    if (idx >= per) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * per + idx];
+    if (idx < K) dw[idx] = s;
+    else if (idx < 2 * K) { if (Cout == 2) dw[idx] = s; }
+    else if (idx == 2 * K) db[0] = s;
+    else if (Cout == 2) db[1] = s;
+}
+
+// ---------------------------------------------------------------- fused loss (train_objectness_net.py:215-254)
+// partial sums of the four terms per block -> part[block][4]; gradients w.r.t. the predictions in the same pass.
+struct LossCfg { int B, H, W; int center_l2, sdf_l2, use_grad, use_bce; float gscale; };
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pc, const float* __restrict__ ps, const float* __restrict__ gc,
+                                                   const float* __restrict__ gs, const float* __restrict__ sal, float* __restrict__ dpc,
+                                                   float* __restrict__ dps, float* __restrict__ part, LossCfg cfg) {
+    __shared__ float red[4][4];
+    const int H = cfg.H, W = cfg.W;
+    const int64_t HW = (int64_t)H * W, total = (int64_t)cfg.B * HW;
+    const float n_c = 1.f / (float)(total * 2), n_s = 1.f / (float)total;
+    const float n_g = (H > 1 && W > 1) ? 1.f / (float)((int64_t)cfg.B * 2 * (H - 1) * (W - 1)) : 0.f;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = idx / HW, hw = idx - b * HW;
+        const int y = (int)(hw / W), x = (int)(hw - (int64_t)y * W);
+        // center term
+        for (int c = 0; c < 2; ++c) {
+            const int64_t o = (b * 2 + c) * HW + hw;
+            const float d = pc[o] - gc[o];
+            t0 += cfg.center_l2 ? d * d : fabsf(d);
+            if (dpc) dpc[o] = cfg.gscale * n_c * (cfg.center_l2 ? 2.f * d : sgn(d));
+        }
+        // sdf term
+        const int64_t o = b * HW + hw;
+        const float p = ps[o], d = p - gs[o];
+        t1 += cfg.sdf_l2 ? d * d : fabsf(d);
+        float g = n_s * (cfg.sdf_l2 ? 2.f * d : sgn(d));
+        // gradient-map term: e = (gt diff) - (pred diff) on the (H-1)x(W-1) interior
+        if (cfg.use_grad) {
+            const float* P = ps + b * HW;
+            const float* G = gs + b * HW;
+            auto f = [&](float e) { return cfg.sdf_l2 ? 2.f * e : sgn(e); };
+            if (y < H - 1 && x < W - 1) {
+                const float ey = (G[hw + W] - G[hw]) - (P[hw + W] - p);
+                const float ex = (G[hw + 1] - G[hw]) - (P[hw + 1] - p);
+                t2 += cfg.sdf_l2 ? ey * ey + ex * ex : fabsf(ey) + fabsf(ex);
+                g += n_g * (f(ey) + f(ex));  // d e / d p[y,x] = +1 for both
+            }
+            if (y > 0 && x < W - 1) {  // dy at (y-1, x): -(p[y,x] - p[y-1,x])
+                const float ey = (G[hw] - G[hw - W]) - (p - P[hw - W]);
+                g -= n_g * f(ey);
+            }
+            if (x > 0 && y < H - 1) {  // dx at (y, x-1)
+                const float ex = (G[hw] - G[hw - 1]) - (p - P[hw - 1]);
+                g -= n_g * f(ex);
+            }
+        }
+        if (cfg.use_bce) {
+            const float t = sal[o];
+            const float q = 1.f / (1.f + expf(-p));
+            const float lq = fmaxf(logf(q), -100.f), l1q = fmaxf(logf(1.f - q), -100.f);
+            t3 += -(t * lq + (1.f - t) * l1q);
+            const float gb = (q - t) / fmaxf((1.f - q) * q, 1e-12f);
+            g += n_s * gb * q * (1.f - q);
+        }
+        if (dps) dps[o] = cfg.gscale * g;
+    }
+    t0 = wave_sum(t0); t1 = wave_sum(t1); t2 = wave_sum(t2); t3 = wave_sum(t3);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = t0; red[wv][1] = t1; red[wv][2] = t2; red[wv][3] = t3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        const float nrm = threadIdx.x == 0 ? n_c : (threadIdx.x == 2 ? n_g : n_s);
+        part[(int64_t)blockIdx.x * 4 + threadIdx.x] = s * nrm;
+    }
+}
+
+__global__ void loss_reduce_kernel(const float* __restrict__ part, float* __restrict__ out5, int nblocks) {
+    // out5 = [total, center, sdf, grad, bce]
+    __shared__ float s[4];
+    if (threadIdx.x < 4) {
+        float a = 0.f;
+        for (int b = 0; b < nblocks; ++b) a += part[(int64_t)b * 4 + threadIdx.x];
+        s[threadIdx.x] = a;
+        out5[1 + threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) out5[0] = ((s[0] + s[1]) + s[2]) + s[3];
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam defaults; train_objectness_net.py:96)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] * b1 + gi * (1.f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
+    int64_t g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                                   \
+    if ((dtype) == UMR_BF16) { typedef bf16_t T; CALL; }          \
+    else if ((dtype) == UMR_F32) { typedef float T; CALL; }       \
+    else return umr_set_error(UMR_ERR_INVALID, "dtype");
+
+extern "C" int umr_patchify(const float* images, void* out, int B, int H, int W, int patch, int ldk, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(images && out, "patchify: null pointer");
+    UMR_CHECK_ARG(B > 0 && patch > 0 && H >= patch && W >= patch && ldk >= 3 * patch * patch, "patchify: bad geometry");
+    const int gh = H / patch, gw = W / patch;
+    const int64_t total = (int64_t)B * gh * gw * 3 * patch;
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, images, (T*)out, B, H, W, patch, gh, gw, ldk));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
+                                umr_stream_t stream) {
+    UMR_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
+                                umr_stream_t stream) {
+    UMR_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_pixel_shuffle(const void* src, void* dst, int B, int H, int W, int s_, int C, int inverse, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && B > 0 && H > 0 && W > 0 && s_ > 0 && C > 0 && C % 4 == 0, "pixel_shuffle: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * H * W * s_ * s_ * (C / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(pixel_shuffle_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)src, (T*)dst, B, H, W, s_, C, inverse));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_zero_stuff2(const void* dy, void* out, int B, int H, int W, int Ho, int Wo, int C, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(dy && out && B > 0 && C > 0 && C % 4 == 0, "zero_stuff2: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(zero_stuff2_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)out, B, H, W, Ho, Wo, C));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+// dst[i0,i1,i2,i3] (dims = dst_dims) = src[soff + sum_k i_k * sstride_k]; dtype_in/out in {F32,BF16}
+extern "C" int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int64_t* src_strides, int64_t src_offset,
+                            int dtype_in, int dtype_out, int accumulate, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && dst_dims && src_strides, "permute4: null pointer");
+    PermDesc pd;
+    int64_t total = 1;
+    for (int i = 0; i < 4; ++i) { pd.d[i] = dst_dims[i]; pd.sstride[i] = src_strides[i]; total *= dst_dims[i]; UMR_CHECK_ARG(dst_dims[i] > 0, "permute4: dims"); }
+    pd.soff = src_offset;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for(total, 256, 65536)), b(256);
+    if (dtype_in == UMR_F32 && dtype_out == UMR_F32) hipLaunchKernelGGL((permute4_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, pd, accumulate);
+    else if (dtype_in == UMR_F32 && dtype_out == UMR_BF16) hipLaunchKernelGGL((permute4_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, pd, accumulate);
+    else if (dtype_in == UMR_BF16 && dtype_out == UMR_F32) hipLaunchKernelGGL((permute4_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, pd, accumulate);
+    else if (dtype_in == UMR_BF16 && dtype_out == UMR_BF16) hipLaunchKernelGGL((permute4_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, pd, accumulate);
+    else return umr_set_error(UMR_ERR_INVALID, "permute4: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+// out[r][c] = sum_{k<reps} x[r*seg_stride + k*rep_stride + c]
+extern "C" int umr_segsum(const void* x, void* out, int R, int reps, int64_t rep_stride, int64_t seg_stride, int C, int dtype_in,
+                          int out_f32, int accumulate, umr_stream_t stream) {
+    UMR_CHECK_ARG(x && out && R > 0 && reps > 0 && C > 0, "segsum: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for((int64_t)R * C)), b(256);
+    if (dtype_in == UMR_BF16 && out_f32) hipLaunchKernelGGL((segsum_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)x, (float*)out, R, reps, rep_stride, seg_stride, C, accumulate);
+    else if (dtype_in == UMR_BF16) hipLaunchKernelGGL((segsum_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)x, (bf16_t*)out, R, reps, rep_stride, seg_stride, C, accumulate);
+    else if (dtype_in == UMR_F32) hipLaunchKernelGGL((segsum_kernel<float, float>), g, b, 0, s, (const float*)x, (float*)out, R, reps, rep_stride, seg_stride, C, accumulate);
+    else return umr_set_error(UMR_ERR_INVALID, "segsum: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_fill_cls(void* tokens, const float* cls, const float* pos0, int B, int64_t batch_stride, int D, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(tokens && cls && pos0 && B > 0 && D > 0, "fill_cls: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(fill_cls_kernel<T>, dim3((B * D + 255) / 256), dim3(256), 0, s, (T*)tokens, cls, pos0, B, batch_stride, D));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_cast(const void* src, void* dst, int64_t n, float scale, int dtype_in, int dtype_out, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && n > 0, "cast: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 g(grid_for(n, 256, 16384)), b(256);
+    if (dtype_in == UMR_F32 && dtype_out == UMR_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n, scale);
+    else if (dtype_in == UMR_BF16 && dtype_out == UMR_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n, scale);
+    else if (dtype_in == UMR_F32 && dtype_out == UMR_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n, scale);
+    else if (dtype_in == UMR_BF16 && dtype_out == UMR_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n, scale);
+    else return umr_set_error(UMR_ERR_INVALID, "cast: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_head_out_fwd(const void* h, const float* w, const float* bias, float* out, int64_t M, int K, int Cout, int HW, int act,
+                                int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(h && w && bias && out && M > 0 && K > 0 && K % 4 == 0 && (Cout == 1 || Cout == 2) && HW > 0 && M % HW == 0, "head_out_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_fwd_kernel<T>, dim3(grid_for((M + 3) / 4, 1, 16384)), dim3(256), 0, s, (const T*)h, w, bias, out, M, K, Cout, HW, act));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+static int head_out_blocks(int64_t M) { int64_t nb = (M + 255) / 256; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1; return (int)nb; }
+
+extern "C" int64_t umr_head_out_bwd_workspace(int64_t M, int K) { return (int64_t)head_out_blocks(M) * (2 * K + 2) * 4; }
+
+extern "C" int umr_head_out_bwd(const void* h, const float* w, const float* dout, const float* yout, void* dh, float* dw, float* db,
+                                void* workspace, int64_t workspace_bytes, int64_t M, int K, int Cout, int HW, int act, int relu_mask,
+                                int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(h && w && dout && dh && dw && db && workspace, "head_out_bwd: null pointer");
+    UMR_CHECK_ARG(M > 0 && K > 0 && K % 4 == 0 && K <= 1024 && (Cout == 1 || Cout == 2) && HW > 0 && M % HW == 0, "head_out_bwd: bad arguments");
+    UMR_CHECK_ARG(act == UMR_ACT_NONE || yout, "head_out_bwd: activation needs the forward output");
+    if (act == 4) return umr_set_error(UMR_ERR_UNSUPPORTED, "head_out_bwd: sine activation backward is not implemented");
+    UMR_CHECK_ARG(workspace_bytes >= umr_head_out_bwd_workspace(M, K), "head_out_bwd: workspace too small");
+    int nb = head_out_blocks(M);
+    const int rpb = (int)((M + nb - 1) / nb);
+    nb = (int)((M + rpb - 1) / rpb);
+    hipStream_t s = (hipStream_t)stream;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)h, w, dout, yout, (T*)dh, (float*)workspace, M, K, Cout, HW, act, relu_mask, rpb));
+    UMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_out_reduce_kernel, dim3((2 * K + 2 + 255) / 256), dim3(256), 0, s, (const float*)workspace, dw, db, nb, K, Cout);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int64_t umr_loss_workspace(void) { return 1024 * 4 * 4; }
+
+extern "C" int umr_objectness_loss(const float* pred_center, const float* pred_sdf, const float* gt_center, const float* gt_sdf,
+                                   const float* gt_saliency, float* d_center, float* d_sdf, float* out5, void* workspace, int B, int H,
+                                   int W, int center_l2, int sdf_l2, int use_grad, int use_bce, float grad_scale, umr_stream_t stream) {
+    UMR_CHECK_ARG(pred_center && pred_sdf && gt_center && gt_sdf && out5 && workspace, "loss: null pointer");
+    UMR_CHECK_ARG(!use_bce || gt_saliency, "loss: bce term needs the saliency mask");
+    UMR_CHECK_ARG(B > 0 && H > 0 && W > 0, "loss: empty");
+    LossCfg cfg{B, H, W, center_l2, sdf_l2, use_grad, use_bce, grad_scale};
+    const int64_t total = (int64_t)B * H * W;
+    const int nb = grid_for(total, 256, 1024);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(256), 0, s, pred_center, pred_sdf, gt_center, gt_sdf, gt_saliency, d_center, d_sdf, (float*)workspace, cfg);
+    UMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, out5, nb);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             int step, float grad_scale, umr_stream_t stream) {
+    UMR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -26,8 +26,11 @@ template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };
 
 template <typename T>
-__device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m, int n, f32x4 v) {
-    // v = 4 consecutive columns n..n+3 of row m
+__device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_logical, int n, f32x4 v) {
+    // v = 4 consecutive columns n..n+3 of logical row m_logical; C-shaped operands use the remapped row m
+    int m = m_logical;
+    if (p.c_rows_in > 0) m = (m_logical / p.c_rows_in) * p.c_rows_out + p.c_row_off + (m_logical % p.c_rows_in);
+    const int m_aux = p.aux_mod > 0 ? (m_logical % p.aux_mod) : m;
     const int nv = p.N - n;  // >0 guaranteed by caller
     const bool full = nv >= 4 && ((p.N & 3) == 0);
     if (p.flags & UMR_EPI_BIAS) {
@@ -35,12 +38,12 @@ __device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m, in
         else { for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j]; }
     }
     if (p.flags & UMR_EPI_ROWBIAS) {
-        const float* rb = p.rowbias + (int64_t)(m / p.rows_per_batch) * p.N + n;
+        const float* rb = p.rowbias + (int64_t)(m_logical / p.rows_per_batch) * p.N + n;
         if (full) { f32x4 b = *(const f32x4*)rb; v += b; }
         else { for (int j = 0; j < 4; ++j) if (j < nv) v[j] += rb[j]; }
     }
     if (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) {
-        const T* ap = (const T*)p.aux + (int64_t)m * p.ldaux + n;
+        const T* ap = (const T*)p.aux + (int64_t)m_aux * p.ldaux + n;
         f32x4 a;
         if (full && ((p.ldaux & 3) == 0)) a = Vec4<T>::load(ap);
         else { for (int j = 0; j < 4; ++j) a[j] = (j < nv) ? to_f32<T>(ap[j]) : 0.f; }
@@ -112,7 +115,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         const int m = m0 + r;
         a_ok[i] = m < p.M;
         if (CONV == 0) {
-            a_ptr[i] = (const char*)p.A + (int64_t)m * p.lda * (int64_t)sizeof(T);
+            int ar = m;
+            if (p.a_rows_in > 0) ar = (m / p.a_rows_in) * p.a_rows_out + p.a_row_off + (m % p.a_rows_in);
+            a_ptr[i] = (const char*)p.A + (int64_t)ar * p.lda * (int64_t)sizeof(T);
             a_y[i] = a_x[i] = 0;
         } else {
             const int hw = p.Ho * p.Wo;

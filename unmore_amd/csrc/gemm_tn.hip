@@ -75,12 +75,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
             const int r = (w * 4 + i) * RPI + lrow;
             const int m = mbase + r;
             const bool mok = m < m_end;
+            int my = m, mx = m;
+            if (p.dy_rows_in > 0) my = (m / p.dy_rows_in) * p.dy_rows_out + p.dy_row_off + (m % p.dy_rows_in);
+            if (CONV == 0 && p.x_rows_in > 0) mx = (m / p.x_rows_in) * p.x_rows_out + p.x_row_off + (m % p.x_rows_in);
             const char* srcA = (mok && n_ok[i])
-                                   ? (const char*)p.dY + ((int64_t)m * p.lddy + n0 + gch[i] * EPC) * (int64_t)sizeof(T)
+                                   ? (const char*)p.dY + ((int64_t)my * p.lddy + n0 + gch[i] * EPC) * (int64_t)sizeof(T)
                                    : zero;
             const char* srcB = zero;
             if (CONV == 0) {
-                if (mok && k_ok[i]) srcB = (const char*)p.X + ((int64_t)m * p.ldx + k_ci[i]) * (int64_t)sizeof(T);
+                if (mok && k_ok[i]) srcB = (const char*)p.X + ((int64_t)mx * p.ldx + k_ci[i]) * (int64_t)sizeof(T);
             } else {
                 if (mok && k_ok[i]) {
                     const int hw = p.Ho * p.Wo;

@@ -46,7 +46,7 @@ def _workspace(nbytes, device):
 
 def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbias=None, rows_per_batch=0,
             act=L.ACT_NONE, mask_relu=False, mask_dgelu=False, c2_mode=0, out_f32=False,
-            conv=0, conv_geom=None, M=None, lda=None):
+            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0):
     """C[M,N] = epi(A[M,K] . B[N,K]^T).  A: [M,K] (2-D, row stride lda) or NHWC
     [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci))."""
     _need_gpu(A, B)
@@ -100,19 +100,25 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     d.ldaux2 = (aux2.reshape(-1, N).stride(0) if aux2 is not None else 0)
     d.M, d.N, d.K, d.dtype = M_, N, K, dt
     d.flags, d.act, d.c2_mode, d.rows_per_batch, d.conv = flags, act, c2_mode, rows_per_batch, conv
+    if a_remap is not None:
+        d.a_rows_in, d.a_rows_out, d.a_row_off = a_remap
+    if c_remap is not None:
+        d.c_rows_in, d.c_rows_out, d.c_row_off = c_remap
+    d.aux_mod = aux_mod
     L.check(L.lib().umr_gemm_nt(ctypes.byref(d), _stream()), "umr_gemm_nt")
     return (out, out2) if c2_mode else out
 
 
-def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0):
+def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_remap=None, x_remap=None, lddy=None, ldx=None):
     """dW[N,K] f32 = sum_m dY[m,N]^T X[m,K]; X is NHWC [nb,H,W,Cin] when conv != 0
     (dY then is [nb*Ho*Wo, N] and dW is [N, 9*Cin] packed (ky,kx,ci))."""
     _need_gpu(dY, X)
     dt = _DT[X.dtype]
     assert dY.dtype == X.dtype
     d = L.GemmTnDesc()
-    dY2 = dY.reshape(-1, dY.shape[-1])
-    M, N = dY2.shape
+    dY2 = dY.reshape(-1, dY.shape[-1]) if dY.is_contiguous() else dY
+    N = dY2.shape[-1]
+    M = dY2.shape[0] if M is None else M
     if conv:
         nb, H, W, Cin = X.shape
         assert X.is_contiguous()
@@ -123,10 +129,9 @@ def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0):
         d.nb, d.H, d.W, d.Cin, d.Ho, d.Wo = nb, H, W, Cin, Ho, Wo
         d.ldx = Cin
     else:
-        X2 = X.reshape(-1, X.shape[-1])
-        assert X2.shape[0] == M
-        K = X2.shape[1]
-        d.ldx = X2.stride(0)
+        X2 = X.reshape(-1, X.shape[-1]) if X.is_contiguous() else X
+        K = X2.shape[-1]
+        d.ldx = X2.stride(0) if ldx is None else ldx
     if dW is None:
         dW = torch.empty((N, K), dtype=torch.float32, device=X.device)
         assert not accumulate
@@ -134,10 +139,191 @@ def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0):
     if dbias is not None:
         assert dbias.dtype == torch.float32 and dbias.numel() == N
     d.dY, d.X, d.dW, d.dbias = _p(dY2), _p(X), _p(dW), _p(dbias)
-    d.lddy, d.lddw = dY2.stride(0), (dW.stride(0) if dW.dim() == 2 else K)
+    d.lddy, d.lddw = (dY2.stride(0) if lddy is None else lddy), (dW.stride(0) if dW.dim() == 2 else K)
+    if dy_remap is not None:
+        d.dy_rows_in, d.dy_rows_out, d.dy_row_off = dy_remap
+    if x_remap is not None:
+        d.x_rows_in, d.x_rows_out, d.x_row_off = x_remap
     d.M, d.N, d.K, d.dtype, d.accumulate, d.conv = M, N, K, dt, int(accumulate), conv
     need = L.lib().umr_gemm_tn_workspace(ctypes.byref(d))
     ws = _workspace(need, X.device)
     d.workspace, d.workspace_bytes = _p(ws), ws.numel()
     L.check(L.lib().umr_gemm_tn(ctypes.byref(d), _stream()), "umr_gemm_tn")
     return dW
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-6):
+    _need_gpu(x)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    M = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    L.check(L.lib().umr_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _DT[x.dtype], _stream()),
+            "umr_layernorm_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, accumulate=False):
+    _need_gpu(dy, x)
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx = torch.empty_like(x)
+    need = L.lib().umr_layernorm_bwd_workspace(M, D)
+    ws = _workspace(need, x.device)
+    L.check(L.lib().umr_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
+                                      int(accumulate), _p(ws), ws.numel(), M, D, _DT[x.dtype], _stream()), "umr_layernorm_bwd")
+    return dx
+
+
+def attention_fwd(qkv, B, N, heads, need_lse=True):
+    _need_gpu(qkv)
+    D = heads * 64
+    assert qkv.is_contiguous() and qkv.numel() == B * N * 3 * D
+    out = torch.empty((B * N, D), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B * heads * N, dtype=torch.float32, device=qkv.device) if need_lse else None
+    L.check(L.lib().umr_attention_fwd(_p(qkv), _p(out), _p(lse), B, N, heads, 64, _DT[qkv.dtype], _stream()), "umr_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, B, N, heads):
+    _need_gpu(qkv, out, dout)
+    assert dout.is_contiguous() and out.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    dsum = torch.empty(B * heads * N, dtype=torch.float32, device=qkv.device)
+    L.check(L.lib().umr_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, N, heads, 64, _DT[qkv.dtype],
+                                      _stream()), "umr_attention_bwd")
+    return dqkv
+
+
+def patchify(images, patch, dtype, ldk=None):
+    _need_gpu(images)
+    assert images.dtype == torch.float32 and images.is_contiguous()
+    B, C, H, W = images.shape
+    assert C == 3
+    gh, gw = H // patch, W // patch
+    k = 3 * patch * patch
+    ldk = k if ldk is None else ldk
+    out = torch.empty((B * gh * gw, ldk), dtype=dtype, device=images.device)
+    L.check(L.lib().umr_patchify(_p(images), _p(out), B, H, W, patch, ldk, _DT[dtype], _stream()), "umr_patchify")
+    return out
+
+
+def bilinear_fwd(x, Ho, Wo, align_corners):
+    _need_gpu(x)
+    B, Hi, Wi, C = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    L.check(L.lib().umr_bilinear_fwd(_p(x), _p(y), B, Hi, Wi, Ho, Wo, C, int(align_corners), _DT[x.dtype], _stream()), "umr_bilinear_fwd")
+    return y
+
+
+def bilinear_bwd(dy, Hi, Wi, align_corners):
+    _need_gpu(dy)
+    B, Ho, Wo, C = dy.shape
+    assert dy.is_contiguous()
+    dx = torch.empty((B, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+    L.check(L.lib().umr_bilinear_bwd(_p(dy), _p(dx), B, Hi, Wi, Ho, Wo, C, int(align_corners), _DT[dy.dtype], _stream()), "umr_bilinear_bwd")
+    return dx
+
+
+def pixel_shuffle(src, B, H, W, s, C, inverse=False):
+    """forward: src [B*H*W, s*s*C] -> [B,H*s,W*s,C]; inverse: src [B,H*s,W*s,C] -> [B*H*W, s*s*C]"""
+    _need_gpu(src)
+    assert src.is_contiguous()
+    if inverse:
+        dst = torch.empty((B * H * W, s * s * C), dtype=src.dtype, device=src.device)
+    else:
+        dst = torch.empty((B, H * s, W * s, C), dtype=src.dtype, device=src.device)
+    L.check(L.lib().umr_pixel_shuffle(_p(src), _p(dst), B, H, W, s, C, int(inverse), _DT[src.dtype], _stream()), "umr_pixel_shuffle")
+    return dst
+
+
+def zero_stuff2(dy, H, W):
+    _need_gpu(dy)
+    B, Ho, Wo, C = dy.shape
+    out = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    L.check(L.lib().umr_zero_stuff2(_p(dy), _p(out), B, H, W, Ho, Wo, C, _DT[dy.dtype], _stream()), "umr_zero_stuff2")
+    return out
+
+
+def permute4(src, dst, dst_dims, src_strides, src_offset=0, accumulate=False):
+    """dst[i0,i1,i2,i3] = src.flat[src_offset + sum i_k*src_strides[k]] (cast to dst dtype)."""
+    _need_gpu(src, dst)
+    dims = (ctypes.c_int32 * 4)(*dst_dims)
+    strides = (ctypes.c_int64 * 4)(*src_strides)
+    L.check(L.lib().umr_permute4(_p(src), _p(dst), ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(strides, ctypes.c_void_p),
+                                 src_offset, _DT[src.dtype], _DT[dst.dtype], int(accumulate), _stream()), "umr_permute4")
+    return dst
+
+
+def segsum(x, R, reps, rep_stride, seg_stride, C, out=None, out_f32=True, accumulate=False):
+    _need_gpu(x)
+    if out is None:
+        out = torch.empty((R, C), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    L.check(L.lib().umr_segsum(_p(x), _p(out), R, reps, rep_stride, seg_stride, C, _DT[x.dtype], int(out.dtype == torch.float32),
+                               int(accumulate), _stream()), "umr_segsum")
+    return out
+
+
+def fill_cls(tokens, cls, pos0, B, batch_stride, D):
+    L.check(L.lib().umr_fill_cls(_p(tokens), _p(cls), _p(pos0), B, batch_stride, D, _DT[tokens.dtype], _stream()), "umr_fill_cls")
+
+
+def cast(src, dtype, scale=1.0, out=None):
+    _need_gpu(src)
+    assert src.is_contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    L.check(L.lib().umr_cast(_p(src), _p(out), src.numel(), scale, _DT[src.dtype], _DT[out.dtype], _stream()), "umr_cast")
+    return out
+
+
+ACT_SINE = 4
+
+
+def head_out_fwd(h, w, bias, B, H, W, act):
+    """h [B*H*W, K] -> NCHW f32 [B, Cout, H, W]; w f32 [Cout, K]."""
+    _need_gpu(h)
+    M, K = h.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=h.device)
+    L.check(L.lib().umr_head_out_fwd(_p(h), _p(w), _p(bias), _p(out), M, K, Cout, H * W, act, _DT[h.dtype], _stream()), "umr_head_out_fwd")
+    return out
+
+
+def head_out_bwd(h, w, dout, yout, act, relu_mask, dw, db):
+    _need_gpu(h)
+    M, K = h.shape
+    Cout = w.shape[0]
+    HW = dout.shape[-1] * dout.shape[-2]
+    dh = torch.empty_like(h)
+    need = L.lib().umr_head_out_bwd_workspace(M, K)
+    ws = _workspace(need, h.device)
+    L.check(L.lib().umr_head_out_bwd(_p(h), _p(w), _p(dout), _p(yout), _p(dh), _p(dw), _p(db), _p(ws), ws.numel(), M, K, Cout, HW,
+                                     act, int(relu_mask), _DT[h.dtype], _stream()), "umr_head_out_bwd")
+    return dh
+
+
+def objectness_loss(pc, ps, gc, gs, sal, center_l2=True, sdf_l2=False, use_grad=True, use_bce=True, need_grad=True, grad_scale=1.0):
+    _need_gpu(pc, ps, gc, gs)
+    B, _, H, W = pc.shape
+    for t in (pc, ps, gc, gs):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    out5 = torch.empty(5, dtype=torch.float32, device=pc.device)
+    dpc = torch.empty_like(pc) if need_grad else None
+    dps = torch.empty_like(ps) if need_grad else None
+    ws = _workspace(L.lib().umr_loss_workspace(), pc.device)
+    L.check(L.lib().umr_objectness_loss(_p(pc), _p(ps), _p(gc), _p(gs), _p(sal), _p(dpc), _p(dps), _p(out5), _p(ws), B, H, W,
+                                        int(center_l2), int(sdf_l2), int(use_grad), int(use_bce), grad_scale, _stream()),
+            "umr_objectness_loss")
+    return out5, dpc, dps
+
+
+def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _need_gpu(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    L.check(L.lib().umr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()),
+            "umr_adam_step")

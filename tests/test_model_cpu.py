@@ -1,0 +1,73 @@
+"""CPU checks of the host side: state-dict schema parity with the reference, the
+C-ABI library exports, and loud failure without a GPU."""
+import ctypes
+import os
+import re
+from argparse import Namespace
+
+import pytest
+import torch
+
+
+def _schema(path):
+    out = []
+    for line in open(path):
+        parts = line.split()
+        out.append((parts[0], tuple(int(x) for x in parts[1:])))
+    return out
+
+
+@pytest.mark.parametrize("backbone,fname", [("dpt_large", "schema_dpt_large.txt"), ("dpt_base", "schema_dpt_base.txt"),
+                                            ("dpt_tiny", "schema_dpt_tiny.txt")])
+def test_state_dict_schema_matches_reference(golden_dir, backbone, fname):
+    from unmore_amd.objectness_net import ObjectnessNet
+    args = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+    with torch.device("meta"):
+        net = ObjectnessNet("cpu", 128, backbone, args)
+    mine = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    assert mine == _schema(os.path.join(golden_dir, fname))
+
+
+def test_head_variants_and_errors():
+    from unmore_amd.objectness_net import ObjectnessNet
+    with torch.device("meta"):
+        n = ObjectnessNet("cpu", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="relu"))
+        assert "sdf_prediction_head.6.weight" in n.state_dict()
+        n = ObjectnessNet("cpu", 128, "dpt_tiny", Namespace(use_bg_sdf=False, sdf_activation="tanh"))
+        assert "sdf_prediction_head.6.weight" in n.state_dict()
+        n = ObjectnessNet("cpu", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation=None))
+        assert "sdf_prediction_head.3.weight" in n.state_dict()
+        with pytest.raises(NotImplementedError):
+            ObjectnessNet("cpu", 128, "no_such_backbone", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+        with pytest.raises(NotImplementedError):
+            ObjectnessNet("cpu", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="bogus"))
+
+
+def test_nograd_names_match_reference(golden_dir):
+    from unmore_amd.objectness_net import ObjectnessNet
+    with torch.device("meta"):
+        net = ObjectnessNet("cpu", 128, "dpt_large", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    ref = sorted(l.strip() for l in open(os.path.join(golden_dir, "nograd_dpt_large.txt")) if l.strip())
+    assert sorted(net.nograd_names()) == ref
+
+
+def test_cpu_tensors_fail_loudly():
+    from unmore_amd.objectness_net import ObjectnessNet
+    net = ObjectnessNet("cpu", 64, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(images=torch.zeros(1, 3, 64, 64))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports every function include/umr.h declares."""
+    from unmore_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "umr.h")).read()
+    declared = set(re.findall(r"\b(umr_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/umr.h but not exported"
+    assert declared == set(_lib.exported_symbols())
+    assert lib.umr_version() >= 100

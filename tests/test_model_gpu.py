@@ -1,0 +1,130 @@
+"""End-to-end parity of the HIP ObjectnessNet against the committed golden fixtures
+(made by the reference's own modules) and against the CPU oracle (forward + gradients).
+fp32 mode carries the 1e-4 contract; bf16 mode is checked at a documented looser bound."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import objectness_oracle as orc
+from unmore_amd.hashrng import hash_init, uniform01
+
+pytestmark = pytest.mark.gpu
+ARGS = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+
+
+def _net(backbone, tag, dtype=torch.float32, args=ARGS):
+    from unmore_amd.objectness_net import ObjectnessNet
+    assert torch.cuda.is_available()
+    net = ObjectnessNet("cuda:0", 128, backbone, args)
+    sd = {k: torch.from_numpy(hash_init(k, tuple(v.shape), tag)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0").to(torch.float32)
+    net.set_compute_dtype(dtype)
+    return net, sd
+
+
+@pytest.mark.parametrize("cfg,tag,img,fname,B,H,W", [
+    ("dpt_tiny", "tiny", "tiny64x64", "fwd_dpt_tiny_64x64.npz", 2, 64, 64),
+    ("dpt_tiny", "tiny", "tiny96x64", "fwd_dpt_tiny_96x64.npz", 2, 96, 64),
+    ("dpt_base", "base", "base128", "fwd_dpt_base_128.npz", 1, 128, 128),
+    ("dpt_large", "large", "large128", "fwd_dpt_large_128.npz", 1, 128, 128),
+])
+def test_forward_fp32_matches_reference_golden(golden_dir, cfg, tag, img, fname, B, H, W):
+    g = np.load(os.path.join(golden_dir, fname))
+    net, _ = _net(cfg, tag)
+    net.eval()
+    x = torch.from_numpy(uniform01(f"img:{img}", (B, 3, H, W))).cuda()
+    with torch.no_grad():
+        out = net(images=x)
+        out2 = net.get_prediction(x)
+    assert out["center_fields"].shape == (B, 2, H, W) and out["sdf_maps"].shape == (B, 1, H, W)
+    assert out["center_fields"].dtype == torch.float32 and out["center_fields"].is_cuda
+    # the north-star contract: within 1e-4 (fp32) of the reference CPU path
+    np.testing.assert_allclose(out["center_fields"].cpu().numpy(), g["center_fields"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["sdf_maps"].cpu().numpy(), g["sdf_maps"], atol=1e-4, rtol=0)
+    assert torch.equal(out["center_fields"], out2["center_fields"]) and torch.equal(out["sdf_maps"], out2["sdf_maps"])
+
+
+@pytest.mark.parametrize("cfg,tag,img,fname,B,H,W", [
+    ("dpt_tiny", "tiny", "tiny96x64", "fwd_dpt_tiny_96x64.npz", 2, 96, 64),
+    ("dpt_base", "base", "base128", "fwd_dpt_base_128.npz", 1, 128, 128),
+])
+def test_forward_bf16_close_to_reference_golden(golden_dir, cfg, tag, img, fname, B, H, W):
+    """bf16 storage / fp32 accumulate cannot meet 1e-4; bound: 3e-2 abs on O(1) fields (documented in DESIGN.md)."""
+    g = np.load(os.path.join(golden_dir, fname))
+    net, _ = _net(cfg, tag, torch.bfloat16)
+    net.eval()
+    x = torch.from_numpy(uniform01(f"img:{img}", (B, 3, H, W))).cuda()
+    with torch.no_grad():
+        out = net(images=x)
+    np.testing.assert_allclose(out["center_fields"].cpu().numpy(), g["center_fields"], atol=3e-2, rtol=0)
+    np.testing.assert_allclose(out["sdf_maps"].cpu().numpy(), g["sdf_maps"], atol=3e-2, rtol=0)
+
+
+def _labels(B, H, W, seed):
+    rng = np.random.RandomState(seed)
+    masks = np.zeros((B, H, W), np.uint8)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for b in range(B):
+        cy, cx = rng.uniform(0.25, 0.75) * H, rng.uniform(0.25, 0.75) * W
+        ry, rx = rng.uniform(H / 8, H / 3), rng.uniform(W / 8, W / 3)
+        masks[b] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1
+    cf, sdf, sal = orc.synth_labels(masks)
+    return torch.from_numpy(cf), torch.from_numpy(sdf).unsqueeze(1), torch.from_numpy(sal).unsqueeze(1)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (96, 64)])
+def test_backward_fp32_matches_oracle_autograd(H, W):
+    """Every parameter gradient of the 4-term loss vs the oracle's autograd (fp32)."""
+    from unmore_amd.loss import objectness_loss
+    B = 2
+    net, sd = _net("dpt_tiny", "tiny")
+    net.train()
+    x = torch.from_numpy(uniform01(f"img:tiny{H}x{W}", (B, 3, H, W)))
+    gc, gs, sal = _labels(B, H, W, 0)
+    # oracle
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_o = orc.forward(sdo, x, orc.CONFIGS["dpt_tiny"])
+    loss_o, terms_o = orc.loss_terms(out_o, gc, gs, sal)
+    loss_o.backward()
+    # HIP path through the autograd.Function boundary
+    out = net(images=x.cuda())
+    loss = objectness_loss(out, gc.cuda(), gs.cuda(), sal.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4
+    nograd = net.nograd_names()
+    worst = 0.0
+    for n, p in net.named_parameters():
+        if n in nograd:
+            assert p.grad is None and sdo[n].grad is None, n
+            continue
+        ref = sdo[n].grad
+        assert p.grad is not None, n
+        err = (p.grad.cpu() - ref).abs().max().item()
+        scale = ref.abs().max().item() + 1e-8
+        worst = max(worst, err / scale)
+        assert err <= 2e-4 * scale + 1e-7, f"{n}: err {err} scale {scale}"
+    print("worst relative gradient error", worst)
+
+
+def test_backward_bf16_gradients_are_close():
+    from unmore_amd.loss import objectness_loss
+    B, H, W = 2, 64, 64
+    net, sd = _net("dpt_tiny", "tiny", torch.bfloat16)
+    net.train()
+    x = torch.from_numpy(uniform01("img:tiny64x64", (B, 3, H, W)))
+    gc, gs, sal = _labels(B, H, W, 0)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_o, _ = orc.loss_terms(orc.forward(sdo, x, orc.CONFIGS["dpt_tiny"]), gc, gs, sal)
+    loss_o.backward()
+    loss = objectness_loss(net(images=x.cuda()), gc.cuda(), gs.cuda(), sal.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 2e-2
+    # cosine similarity of the full gradient vector
+    a = torch.cat([p.grad.flatten().cpu() for n, p in net.named_parameters() if p.grad is not None])
+    b = torch.cat([sdo[n].grad.flatten() for n, p in net.named_parameters() if p.grad is not None])
+    cos = torch.dot(a, b) / (a.norm() * b.norm())
+    assert cos > 0.99, cos

@@ -1,0 +1,483 @@
+"""Hand-scheduled forward / backward of the ObjectnessNet hot path on the HIP kernels.
+
+This is the host-side "graph": an explicit list of kernel launches (no tracing
+compiler, no autograd inside).  Activations are NHWC / [rows, channels]; weights
+are repacked from the reference's PyTorch layouts into the layouts the kernels want
+(cached per parameter version).  Reference op order and formulas:
+models/dpt/vit.py:165-201 (forward_flex), :86-90 (ProjectReadout), :104-145 +
+:259-336 (reassemble), models/dpt/blocks.py:290-313 (RCU), :362-383 (fusion),
+models/dpt/models.py:74-94 (DPT.forward), models/objectness_net.py:109-135,167-183
+(heads), timm Block semantics as restated in SURVEY.md section 8c.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+
+CONFIGS = {
+    # reference wiring: models/dpt/models.py:43-47, blocks.py:24-54, vit.py:515-543
+    "dpt_large": dict(D=1024, depth=24, heads=16, patch=16, pos_grid=24, hooks=[5, 11, 17, 23], features=[256, 512, 1024, 1024]),
+    "dpt_base": dict(D=768, depth=12, heads=12, patch=16, pos_grid=24, hooks=[2, 5, 8, 11], features=[96, 192, 384, 768]),
+    # extensions named by BASELINE.json
+    "dpt_small": dict(D=384, depth=12, heads=6, patch=16, pos_grid=24, hooks=[2, 5, 8, 11], features=[48, 96, 192, 384]),
+    "dpt_large14": dict(D=1024, depth=24, heads=16, patch=14, pos_grid=37, hooks=[5, 11, 17, 23], features=[256, 512, 1024, 1024]),
+    "dpt_tiny": dict(D=128, depth=4, heads=2, patch=16, pos_grid=24, hooks=[0, 1, 2, 3], features=[32, 64, 128, 128]),
+}
+
+_ACT = {None: L.ACT_NONE, "tanh": L.ACT_TANH, "sine": ops.ACT_SINE}
+
+
+class PackCache:
+    """Kernel-layout copies of parameters, rebuilt when the parameter changes."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, key, param, build):
+        ver = (param._version, param.data_ptr())
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = build()
+        self._c[key] = (ver, val)
+        return val
+
+    def clear(self):
+        self._c.clear()
+
+
+def _pack_linear(w, dt):  # [N,K] -> [N,K] T
+    return ops.cast(w.detach().reshape(w.shape[0], -1), dt)
+
+
+def _pack_linear_t(w2d, dt):  # [N,K] (possibly strided rows) -> [K,N] T
+    N, K = w2d.shape
+    out = torch.empty((K, N), dtype=dt, device=w2d.device)
+    return ops.permute4(w2d, out, (1, 1, K, N), (0, 0, w2d.stride(1), w2d.stride(0)), src_offset=0)
+
+
+def _pack_conv3(w, dt):  # [co,ci,3,3] -> [co][ky][kx][ci]
+    co, ci = w.shape[0], w.shape[1]
+    st = w.stride()
+    out = torch.empty((co, 9 * ci), dtype=dt, device=w.device)
+    return ops.permute4(w.detach(), out, (co, 3, 3, ci), (st[0], st[2], st[3], st[1]))
+
+
+def _pack_conv3_dgrad(w, dt):  # [co,ci,3,3] -> [ci][2-ky][2-kx][co]
+    co, ci = w.shape[0], w.shape[1]
+    st = w.stride()
+    out = torch.empty((ci, 9 * co), dtype=dt, device=w.device)
+    return ops.permute4(w.detach(), out, (ci, 3, 3, co), (st[1], -st[2], -st[3], st[0]), src_offset=2 * st[2] + 2 * st[3])
+
+
+def _unpack_conv3_grad(dwp, grad_out):  # [co][ky][kx][ci] f32 -> [co,ci,3,3] f32
+    co, ci = grad_out.shape[0], grad_out.shape[1]
+    return ops.permute4(dwp, grad_out, (co, ci, 3, 3), (9 * ci, 1, 3 * ci, ci))
+
+
+def _pack_convT(w, dt):  # ConvTranspose2d [ci,co,s,s] -> [(i,j,co)][ci]
+    ci, co, s, _ = w.shape
+    st = w.stride()
+    out = torch.empty((s * s * co, ci), dtype=dt, device=w.device)
+    return ops.permute4(w.detach(), out, (s, s, co, ci), (st[2], st[3], st[1], st[0]))
+
+
+def _pack_convT_dgrad(w, dt):  # -> [ci][(i,j,co)]
+    ci, co, s, _ = w.shape
+    st = w.stride()
+    out = torch.empty((ci, s * s * co), dtype=dt, device=w.device)
+    return ops.permute4(w.detach(), out, (ci, s, s, co), (st[0], st[2], st[3], st[1]))
+
+
+def _rep_bias(b, reps):
+    out = torch.empty(reps * b.numel(), dtype=torch.float32, device=b.device)
+    return ops.permute4(b.detach(), out, (1, 1, reps, b.numel()), (0, 0, 0, 1))
+
+
+class Engine:
+    def __init__(self, cfg, head_layouts, compute_dtype=torch.float32):
+        self.cfg = cfg
+        self.center_layout, self.sdf_layout = head_layouts
+        self.dt = compute_dtype
+        self.cache = PackCache()
+
+    # ------------------------------------------------------------------ helpers
+    def _w(self, P, name, kind):
+        p = P[name]
+        return self.cache.get((name, kind, self.dt), p, lambda: {
+            "lin": lambda: _pack_linear(p, self.dt),
+            "lin_t": lambda: _pack_linear_t(p.detach().reshape(p.shape[0], -1), self.dt),
+            "c3": lambda: _pack_conv3(p, self.dt),
+            "c3_d": lambda: _pack_conv3_dgrad(p, self.dt),
+            "ct": lambda: _pack_convT(p, self.dt),
+            "ct_d": lambda: _pack_convT_dgrad(p, self.dt),
+        }[kind]())
+
+    def _f32(self, P, name):
+        p = P[name].detach()
+        assert p.dtype == torch.float32, "parameters must be fp32 (call .to(torch.float32))"
+        return p
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, P, images, save):
+        """P: dict name -> fp32 parameter tensor on the GPU (reference state-dict names).
+        images: [B,3,H,W] fp32 on the GPU.  Returns (center [B,2,H,W] f32, sdf [B,1,H,W] f32, saved)."""
+        cfg, dt = self.cfg, self.dt
+        assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
+        images = images.contiguous()
+        B, _, H, W = images.shape
+        p, D, heads = cfg["patch"], cfg["D"], cfg["heads"]
+        gh, gw = H // p, W // p
+        assert gh >= 1 and gw >= 1
+        g, Nt = gh * gw, gh * gw + 1
+        m = "backbone.pretrained.model."
+        S = {"B": B, "H": H, "W": W, "gh": gh, "gw": gw} if save else None
+
+        # ---- patch embed + cls + pos (vit.py:168-193)
+        G = cfg["pos_grid"]
+        pos = self._f32(P, m + "pos_embed")[0]  # [1+G*G, D]
+        if (gh, gw) != (G, G):
+            pos_grid = ops.bilinear_fwd(pos[1:].reshape(1, G, G, D), gh, gw, False).reshape(g, D)
+        else:
+            pos_grid = pos[1:]
+        pos_t = pos_grid if dt == torch.float32 else ops.cast(pos_grid.contiguous(), dt)
+        K = 3 * p * p
+        ldk = (K + 7) // 8 * 8
+        patches = ops.patchify(images, p, dt, ldk)
+        wp = self._w(P, m + "patch_embed.proj.weight", "lin")
+        if ldk != K:
+            wpad = torch.zeros((D, ldk), dtype=dt, device=images.device)
+            wpad[:, :K] = wp
+            wp = wpad
+        tokens = torch.empty((B * Nt, D), dtype=dt, device=images.device)
+        ops.gemm_nt(patches, wp, self._f32(P, m + "patch_embed.proj.bias"), out=tokens, aux=pos_t.contiguous(), aux_mod=g,
+                    c_remap=(g, Nt, 1))
+        ops.fill_cls(tokens, self._f32(P, m + "cls_token").reshape(-1), pos[0].contiguous(), B, Nt * D, D)
+        if save:
+            S["patches"] = patches
+
+        # ---- transformer blocks (timm Block; only up to the last hooked block: later ones feed nothing, vit.py:107)
+        x = tokens
+        acts = []
+        blocks = []
+        for i in range(max(cfg["hooks"]) + 1):
+            b = m + f"blocks.{i}."
+            ln1, mean1, rstd1 = ops.layernorm_fwd(x, self._f32(P, b + "norm1.weight"), self._f32(P, b + "norm1.bias"))
+            qkv = ops.gemm_nt(ln1, self._w(P, b + "attn.qkv.weight", "lin"), self._f32(P, b + "attn.qkv.bias"))
+            att, lse = ops.attention_fwd(qkv, B, Nt, heads, need_lse=save)
+            x1 = ops.gemm_nt(att, self._w(P, b + "attn.proj.weight", "lin"), self._f32(P, b + "attn.proj.bias"), aux=x)
+            ln2, mean2, rstd2 = ops.layernorm_fwd(x1, self._f32(P, b + "norm2.weight"), self._f32(P, b + "norm2.bias"))
+            if save:
+                h, hpre = ops.gemm_nt(ln2, self._w(P, b + "mlp.fc1.weight", "lin"), self._f32(P, b + "mlp.fc1.bias"),
+                                      act=L.ACT_GELU, c2_mode=2)
+            else:
+                h, hpre = ops.gemm_nt(ln2, self._w(P, b + "mlp.fc1.weight", "lin"), self._f32(P, b + "mlp.fc1.bias"), act=L.ACT_GELU), None
+            x2 = ops.gemm_nt(h, self._w(P, b + "mlp.fc2.weight", "lin"), self._f32(P, b + "mlp.fc2.bias"), aux=x1)
+            if save:
+                blocks.append(dict(x=x, mean1=mean1, rstd1=rstd1, ln1=ln1, qkv=qkv, att=att, lse=lse, x1=x1, mean2=mean2,
+                                   rstd2=rstd2, ln2=ln2, hpre=hpre, h=h))
+            x = x2
+            if i in cfg["hooks"]:
+                acts.append(x)
+        if save:
+            S["blocks"] = blocks
+            S["acts"] = acts
+
+        # ---- readout + reassemble (vit.py:86-90,104-145,259-336)
+        pp = "backbone.pretrained."
+        Fs = cfg["features"]
+        layers = []
+        re_saved = []
+        for k in range(4):
+            a = pp + f"act_postprocess{k + 1}."
+            wname = a + "0.project.0.weight"
+            w_full = self.cache.get((wname, "lin", dt), P[wname], lambda: _pack_linear(P[wname], dt))  # [D, 2D]
+            tok = acts[k]
+            rb = ops.gemm_nt(tok, w_full[:, D:], self._f32(P, a + "0.project.0.bias"), M=B, lda=Nt * D, out_f32=True)  # cls part + bias
+            if save:
+                r, rpre = ops.gemm_nt(tok, w_full[:, :D], None, rowbias=rb, rows_per_batch=g, act=L.ACT_GELU, c2_mode=2, M=B * g,
+                                      a_remap=(g, Nt, 1))
+            else:
+                r, rpre = ops.gemm_nt(tok, w_full[:, :D], None, rowbias=rb, rows_per_batch=g, act=L.ACT_GELU, M=B * g,
+                                      a_remap=(g, Nt, 1)), None
+            f = ops.gemm_nt(r, self._w(P, a + "3.weight", "lin"), self._f32(P, a + "3.bias"))  # [B*g, F]
+            F_ = Fs[k]
+            if k in (0, 1):
+                s = 4 if k == 0 else 2
+                bname = a + "4.bias"
+                brep = self.cache.get((bname, "rep", s), P[bname], lambda: _rep_bias(P[bname], s * s))
+                y = ops.gemm_nt(f, self._w(P, a + "4.weight", "ct"), brep)
+                lay = ops.pixel_shuffle(y, B, gh, gw, s, F_)
+            elif k == 2:
+                lay = f.view(B, gh, gw, F_)
+            else:
+                lay = ops.gemm_nt(f.view(B, gh, gw, F_), self._w(P, a + "4.weight", "c3"), self._f32(P, a + "4.bias"), conv=2)
+                lay = lay.view(B, (gh - 1) // 2 + 1, (gw - 1) // 2 + 1, F_)
+            layers.append(lay)
+            if save:
+                re_saved.append(dict(r=r, rpre=rpre, f=f))
+        if save:
+            S["re"] = re_saved
+            S["layers"] = layers
+
+        # ---- scratch convs + refinenets (models.py:80-91, blocks.py:290-383)
+        sc = "backbone.scratch."
+        rn, rn_relu = [], []
+        for k in range(4):
+            lay = layers[k]
+            o, orl = ops.gemm_nt(lay, self._w(P, sc + f"layer{k + 1}_rn.weight", "c3"), None, conv=1, c2_mode=1)
+            rn.append(o.view(lay.shape[0], lay.shape[1], lay.shape[2], 256))
+            rn_relu.append(orl.view_as(rn[-1]))
+        fus_saved = {}
+        path = None
+        for k in (4, 3, 2, 1):
+            r_ = sc + f"refinenet{k}."
+            x1_, x1_relu = rn[k - 1], rn_relu[k - 1]
+            nb, hh, ww, _ = x1_.shape
+            fs = {}
+            if path is None:
+                s_, s_relu = x1_, x1_relu
+            else:
+                assert path.shape == x1_.shape, "fusion skip/size mismatch"
+                t1 = ops.gemm_nt(x1_relu, self._w(P, r_ + "resConfUnit1.conv1.weight", "c3"),
+                                 self._f32(P, r_ + "resConfUnit1.conv1.bias"), conv=1, act=L.ACT_RELU).view_as(x1_)
+                s_, s_relu = ops.gemm_nt(t1, self._w(P, r_ + "resConfUnit1.conv2.weight", "c3"),
+                                         self._f32(P, r_ + "resConfUnit1.conv2.bias"), conv=1, aux=x1_, aux2=path, c2_mode=1)
+                s_, s_relu = s_.view_as(x1_), s_relu.view_as(x1_)
+                fs.update(x1_relu=x1_relu, t1=t1)
+            t2 = ops.gemm_nt(s_relu, self._w(P, r_ + "resConfUnit2.conv1.weight", "c3"),
+                             self._f32(P, r_ + "resConfUnit2.conv1.bias"), conv=1, act=L.ACT_RELU).view_as(x1_)
+            u = ops.gemm_nt(t2, self._w(P, r_ + "resConfUnit2.conv2.weight", "c3"),
+                            self._f32(P, r_ + "resConfUnit2.conv2.bias"), conv=1, aux=s_).view_as(x1_)
+            if k > 1:
+                nxt = rn[k - 2].shape
+                Ho, Wo = nxt[1], nxt[2]  # == 2x for the reference's patch-16 configs
+            else:
+                Ho, Wo = 2 * hh, 2 * ww
+            up = ops.bilinear_fwd(u, Ho, Wo, True)
+            path = ops.gemm_nt(up.view(-1, 256), self._w(P, r_ + "out_conv.weight", "lin"), self._f32(P, r_ + "out_conv.bias"))
+            path = path.view(nb, Ho, Wo, 256)
+            if save:
+                fs.update(s_relu=s_relu, t2=t2, up=up, in_hw=(hh, ww))
+                fus_saved[k] = fs
+        feat = ops.bilinear_fwd(path, H, W, True)  # models.py:70-72 (x2; == input size for patch 16)
+        if save:
+            S["fus"] = fus_saved
+            S["rn_in"] = layers
+            S["path1_hw"] = (path.shape[1], path.shape[2])
+            S["feat"] = feat
+
+        # ---- heads (objectness_net.py:109-135)
+        outs = []
+        heads_saved = []
+        for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
+            idx = lay["conv_idx"]
+            act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
+            h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
+            h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
+                             conv=1, act=act)
+            h3 = ops.gemm_nt(h2, self._w(P, f"{name}.{idx[2]}.weight", "lin"), self._f32(P, f"{name}.{idx[2]}.bias"), act=act)
+            w4 = self._f32(P, f"{name}.{idx[3]}.weight")
+            out = ops.head_out_fwd(h3, w4.reshape(w4.shape[0], -1), self._f32(P, f"{name}.{idx[3]}.bias"), B, H, W, _ACT[lay["final"]])
+            outs.append(out)
+            if save:
+                heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=out))
+            del h1, h2, h3
+        if save:
+            S["heads"] = heads_saved
+        return outs[0], outs[1], S
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P, S, d_center, d_sdf, G):
+        """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
+        Parameters that receive no gradient are left untouched."""
+        cfg, dt = self.cfg, self.dt
+        B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
+        D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
+        g, Nt = gh * gw, gh * gw + 1
+        dev = d_center.device
+
+        def wgrad_lin(name, dy, x, bias_name=None, **kw):
+            ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw)
+
+        def wgrad_c3(name, dy, x_nhwc, bias_name=None, conv=1):
+            co = G[name].shape[0]
+            dwp = ops.gemm_tn(dy.reshape(-1, co), x_nhwc, dbias=(G[bias_name] if bias_name else None), conv=conv)
+            _unpack_conv3_grad(dwp, G[name])
+
+        # ---- heads
+        dfeat = None
+        feat = S["feat"]
+        for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
+                                               ("sdf_prediction_head", self.sdf_layout, d_sdf))):
+            hs = S["heads"][hi]
+            idx = lay["conv_idx"]
+            relu = lay["relu"]
+            w4 = self._f32(P, f"{name}.{idx[3]}.weight")
+            dh3 = ops.head_out_bwd(hs["h3"], w4.reshape(w4.shape[0], -1), dout.contiguous(), hs["out"], _ACT[lay["final"]], relu,
+                                   G[f"{name}.{idx[3]}.weight"].view(w4.shape[0], -1), G[f"{name}.{idx[3]}.bias"])
+            hs["h3"] = None
+            wgrad_lin(f"{name}.{idx[2]}.weight", dh3, hs["h2"], f"{name}.{idx[2]}.bias")
+            dh2 = ops.gemm_nt(dh3, self._w(P, f"{name}.{idx[2]}.weight", "lin_t"), None, aux=(hs["h2"] if relu else None), mask_relu=relu)
+            del dh3
+            h1 = hs["h1"].view(B, H, W, 512)
+            wgrad_c3(f"{name}.{idx[1]}.weight", dh2, h1, f"{name}.{idx[1]}.bias")
+            hs["h2"] = None
+            dh1 = ops.gemm_nt(dh2.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
+                              aux=(hs["h1"] if relu else None), mask_relu=relu)
+            del dh2
+            hs["h1"] = None
+            wgrad_lin(f"{name}.{idx[0]}.weight", dh1, feat.view(-1, 256), f"{name}.{idx[0]}.bias")
+            if dfeat is None:
+                dfeat = ops.gemm_nt(dh1, self._w(P, f"{name}.{idx[0]}.weight", "lin_t"), None)
+            else:
+                ops.gemm_nt(dh1, self._w(P, f"{name}.{idx[0]}.weight", "lin_t"), None, aux=dfeat, out=dfeat)
+            del dh1
+        S["feat"] = None
+        ph, pw = S["path1_hw"]
+        dpath = ops.bilinear_bwd(dfeat.view(B, H, W, 256), ph, pw, True)
+        del dfeat
+
+        # ---- refinenets + scratch convs
+        sc = "backbone.scratch."
+        d_rn = {}
+        for k in (1, 2, 3, 4):
+            r_ = sc + f"refinenet{k}."
+            fs = S["fus"][k]
+            hh, ww = fs["in_hw"]
+            nb = dpath.shape[0]
+            wgrad_lin(r_ + "out_conv.weight", dpath.reshape(-1, 256), fs["up"].view(-1, 256), r_ + "out_conv.bias")
+            dup = ops.gemm_nt(dpath.reshape(-1, 256), self._w(P, r_ + "out_conv.weight", "lin_t"), None)
+            du = ops.bilinear_bwd(dup.view(nb, dpath.shape[1], dpath.shape[2], 256), hh, ww, True)
+            del dup
+            # RCU2: u = conv2(relu(conv1(relu(s)))) + s
+            wgrad_c3(r_ + "resConfUnit2.conv2.weight", du, fs["t2"], r_ + "resConfUnit2.conv2.bias")
+            dt2 = ops.gemm_nt(du, self._w(P, r_ + "resConfUnit2.conv2.weight", "c3_d"), None, conv=1, aux=fs["t2"], mask_relu=True)
+            dt2 = dt2.view(nb, hh, ww, 256)
+            wgrad_c3(r_ + "resConfUnit2.conv1.weight", dt2, fs["s_relu"], r_ + "resConfUnit2.conv1.bias")
+            ds = ops.gemm_nt(dt2, self._w(P, r_ + "resConfUnit2.conv1.weight", "c3_d"), None, conv=1, aux=fs["s_relu"], mask_relu=True,
+                             aux2=du).view(nb, hh, ww, 256)
+            del dt2, du
+            if "t1" in fs:
+                # s = path_prev + RCU1(x1)
+                wgrad_c3(r_ + "resConfUnit1.conv2.weight", ds, fs["t1"], r_ + "resConfUnit1.conv2.bias")
+                dt1 = ops.gemm_nt(ds, self._w(P, r_ + "resConfUnit1.conv2.weight", "c3_d"), None, conv=1, aux=fs["t1"], mask_relu=True)
+                dt1 = dt1.view(nb, hh, ww, 256)
+                wgrad_c3(r_ + "resConfUnit1.conv1.weight", dt1, fs["x1_relu"], r_ + "resConfUnit1.conv1.bias")
+                dx1 = ops.gemm_nt(dt1, self._w(P, r_ + "resConfUnit1.conv1.weight", "c3_d"), None, conv=1, aux=fs["x1_relu"],
+                                  mask_relu=True, aux2=ds).view(nb, hh, ww, 256)
+                del dt1
+                d_rn[k] = dx1
+                dpath = ds  # gradient of the previous (coarser) path
+            else:
+                d_rn[k] = ds
+            S["fus"][k] = None
+
+        # ---- layerK_rn + reassemble + readout; token gradients collected per hook
+        pp = "backbone.pretrained."
+        Fs = cfg["features"]
+        d_hook = [None] * 4  # (d_rpre [B*g, D], sB) applied to the token gradient when the block is reached
+        for k in range(4):
+            lay_in = S["rn_in"][k]
+            dr = d_rn.pop(k + 1)
+            wgrad_c3(sc + f"layer{k + 1}_rn.weight", dr, lay_in, None)
+            dl = ops.gemm_nt(dr, self._w(P, sc + f"layer{k + 1}_rn.weight", "c3_d"), None, conv=1)
+            del dr
+            a = pp + f"act_postprocess{k + 1}."
+            F_ = Fs[k]
+            rs = S["re"][k]
+            f = rs["f"]
+            if k in (0, 1):
+                s = 4 if k == 0 else 2
+                dyu = ops.pixel_shuffle(dl.view(B, gh * s, gw * s, F_), B, gh, gw, s, F_, inverse=True)  # [B*g, s*s*F]
+                brep = torch.empty(s * s * F_, dtype=torch.float32, device=dev)
+                dwp = ops.gemm_tn(dyu, f, dbias=brep)  # [(i,j,co)][ci]
+                gw_ = G[a + "4.weight"]  # [ci, co, s, s]
+                ops.permute4(dwp, gw_, (F_, F_, s, s), (1, F_, s * F_ * F_, F_ * F_))
+                ops.segsum(brep, 1, s * s, F_, 0, F_, out=G[a + "4.bias"].view(1, F_))
+                df = ops.gemm_nt(dyu, self._w(P, a + "4.weight", "ct_d"), None)
+                del dyu
+            elif k == 2:
+                df = dl.view(-1, F_)
+            else:
+                ho, wo = (gh - 1) // 2 + 1, (gw - 1) // 2 + 1
+                wgrad_c3(a + "4.weight", dl, f.view(B, gh, gw, F_), a + "4.bias", conv=2)
+                stuffed = ops.zero_stuff2(dl.view(B, ho, wo, F_), gh, gw)
+                df = ops.gemm_nt(stuffed, self._w(P, a + "4.weight", "c3_d"), None, conv=1)
+                del stuffed
+            del dl
+            wgrad_lin(a + "3.weight", df, rs["r"], a + "3.bias")
+            d_rpre = ops.gemm_nt(df, self._w(P, a + "3.weight", "lin_t"), None, aux=rs["rpre"], mask_dgelu=True)  # [B*g, D]
+            del df
+            tok = S["acts"][k]
+            gfull = G[a + "0.project.0.weight"]  # [D, 2D]
+            ops.gemm_tn(d_rpre, tok, dW=gfull[:, :D], x_remap=(g, Nt, 1), M=B * g)
+            sB32 = ops.segsum(d_rpre, B, g, D, g * D, D)  # [B, D] f32: sum over patches
+            ops.segsum(sB32, 1, B, D, 0, D, out=G[a + "0.project.0.bias"].view(1, D))
+            sBt = sB32 if dt == torch.float32 else ops.cast(sB32, dt)
+            ops.gemm_tn(sBt, tok, dW=gfull[:, D:], M=B, ldx=Nt * D)
+            d_hook[k] = (d_rpre, sBt, a)
+            S["re"][k] = None
+
+        def add_hook_grad(k, dx):
+            d_rpre, sBt, a = d_hook[k]
+            wname = a + "0.project.0.weight"
+            w = P[wname].detach()
+            wa_t = self.cache.get((wname, "lin_t_a", dt), P[wname], lambda: _pack_linear_t(w[:, :D], dt))
+            wb_t = self.cache.get((wname, "lin_t_b", dt), P[wname], lambda: _pack_linear_t(w[:, D:], dt))
+            if dx is None:
+                dx = torch.zeros((B * Nt, D), dtype=dt, device=dev)
+            ops.gemm_nt(d_rpre, wa_t, None, out=dx, aux=dx, c_remap=(g, Nt, 1))
+            cls_rows = dx.view(B, Nt * D)[:, :D]  # token 0 of every image: row stride Nt*D
+            ops.gemm_nt(sBt, wb_t, None, out=cls_rows, aux=cls_rows)
+            d_hook[k] = None
+            return dx
+
+        # ---- transformer blocks
+        m = "backbone.pretrained.model."
+        dx = None
+        hooks = cfg["hooks"]
+        for i in range(max(hooks), -1, -1):
+            if i in hooks:
+                dx = add_hook_grad(hooks.index(i), dx)
+            b = m + f"blocks.{i}."
+            bs = S["blocks"][i]
+            wgrad_lin(b + "mlp.fc2.weight", dx, bs["h"], b + "mlp.fc2.bias")
+            dhp = ops.gemm_nt(dx, self._w(P, b + "mlp.fc2.weight", "lin_t"), None, aux=bs["hpre"], mask_dgelu=True)
+            wgrad_lin(b + "mlp.fc1.weight", dhp, bs["ln2"], b + "mlp.fc1.bias")
+            dln2 = ops.gemm_nt(dhp, self._w(P, b + "mlp.fc1.weight", "lin_t"), None)
+            del dhp
+            dx1 = ops.layernorm_bwd(dln2, bs["x1"], self._f32(P, b + "norm2.weight"), bs["mean2"], bs["rstd2"],
+                                    G[b + "norm2.weight"], G[b + "norm2.bias"], dres=dx)
+            del dln2
+            wgrad_lin(b + "attn.proj.weight", dx1, bs["att"], b + "attn.proj.bias")
+            datt = ops.gemm_nt(dx1, self._w(P, b + "attn.proj.weight", "lin_t"), None)
+            dqkv = ops.attention_bwd(bs["qkv"], bs["att"], datt, bs["lse"], B, Nt, heads)
+            del datt
+            wgrad_lin(b + "attn.qkv.weight", dqkv, bs["ln1"], b + "attn.qkv.bias")
+            dln1 = ops.gemm_nt(dqkv, self._w(P, b + "attn.qkv.weight", "lin_t"), None)
+            del dqkv
+            dx = ops.layernorm_bwd(dln1, bs["x"], self._f32(P, b + "norm1.weight"), bs["mean1"], bs["rstd1"],
+                                   G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1)
+            del dln1, dx1
+            S["blocks"][i] = None
+
+        # ---- embeddings (vit.py:179-193)
+        dpos = ops.segsum(dx, Nt, B, Nt * D, D, D)  # [Nt, D] f32, sum over images
+        G[m + "cls_token"].view(-1).copy_(dpos[0])
+        gpos = G[m + "pos_embed"]
+        Gd = cfg["pos_grid"]
+        gpos[0, 0].copy_(dpos[0])
+        if (gh, gw) == (Gd, Gd):
+            gpos[0, 1:].copy_(dpos[1:])
+        else:
+            gpos[0, 1:].copy_(ops.bilinear_bwd(dpos[1:].reshape(1, gh, gw, D).contiguous(), Gd, Gd, False).view(Gd * Gd, D))
+        K = 3 * p * p
+        gwp = G[m + "patch_embed.proj.weight"].view(D, K)
+        patches = S["patches"]
+        if patches.shape[1] == K:
+            ops.gemm_tn(dx, patches, dW=gwp, dbias=G[m + "patch_embed.proj.bias"], dy_remap=(g, Nt, 1), M=B * g)
+        else:
+            tmp = ops.gemm_tn(dx, patches, dbias=G[m + "patch_embed.proj.bias"], dy_remap=(g, Nt, 1), M=B * g)
+            gwp.copy_(tmp[:, :K])
+        S.clear()

@@ -78,36 +78,43 @@ def _labels(B, H, W, seed):
 
 @pytest.mark.parametrize("H,W", [(64, 64), (96, 64)])
 def test_backward_fp32_matches_oracle_autograd(H, W):
-    """Every parameter gradient of the 4-term loss vs the oracle's autograd (fp32)."""
+    """Every parameter gradient of the 4-term loss vs the oracle's autograd.  The oracle is
+    evaluated in float64 (ground truth) and in float32 (what the reference CPU path computes);
+    the HIP fp32 gradients must sit within 5e-4 of max|grad| of the truth and be no worse
+    than 2x the fp32 CPU path's own worst error."""
     from unmore_amd.loss import objectness_loss
     B = 2
     net, sd = _net("dpt_tiny", "tiny")
     net.train()
     x = torch.from_numpy(uniform01(f"img:tiny{H}x{W}", (B, 3, H, W)))
     gc, gs, sal = _labels(B, H, W, 0)
-    # oracle
-    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    out_o = orc.forward(sdo, x, orc.CONFIGS["dpt_tiny"])
-    loss_o, terms_o = orc.loss_terms(out_o, gc, gs, sal)
-    loss_o.backward()
+    grads = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        sdo = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd.items()}
+        out_o = orc.forward(sdo, x.to(dt), orc.CONFIGS["dpt_tiny"])
+        loss_o, terms_o = orc.loss_terms(out_o, gc.to(dt), gs.to(dt), sal.to(dt))
+        loss_o.backward()
+        grads[tag] = {k: v.grad for k, v in sdo.items()}
     # HIP path through the autograd.Function boundary
     out = net(images=x.cuda())
     loss = objectness_loss(out, gc.cuda(), gs.cuda(), sal.cuda())
     loss.backward()
     assert abs(loss.item() - loss_o.item()) < 1e-4
     nograd = net.nograd_names()
-    worst = 0.0
+    worst_mine, worst_cpu = 0.0, 0.0
     for n, p in net.named_parameters():
+        ref = grads["f64"][n]
         if n in nograd:
-            assert p.grad is None and sdo[n].grad is None, n
+            assert p.grad is None and ref is None, n
             continue
-        ref = sdo[n].grad
-        assert p.grad is not None, n
-        err = (p.grad.cpu() - ref).abs().max().item()
-        scale = ref.abs().max().item() + 1e-8
-        worst = max(worst, err / scale)
-        assert err <= 2e-4 * scale + 1e-7, f"{n}: err {err} scale {scale}"
-    print("worst relative gradient error", worst)
+        assert p.grad is not None and p.grad.shape == p.shape, n
+        scale = ref.abs().max().item() + 1e-12
+        e_m = (p.grad.cpu().double() - ref).abs().max().item() / scale
+        e_c = (grads["f32"][n].double() - ref).abs().max().item() / scale
+        worst_mine, worst_cpu = max(worst_mine, e_m), max(worst_cpu, e_c)
+        assert e_m <= 5e-4, f"{n}: HIP fp32 rel err {e_m} (cpu fp32 {e_c})"
+    print(f"worst relative gradient error: HIP fp32 {worst_mine:.2e}, reference-style CPU fp32 {worst_cpu:.2e}")
+    assert worst_mine <= max(2 * worst_cpu, 2e-4)
 
 
 def test_backward_bf16_gradients_are_close():

@@ -1,0 +1,197 @@
+"""Headline benchmark: images/sec of one ObjectnessNet training step (forward + 4-term
+loss + backward + gradient all-reduce + Adam) on synthetic 384x384 batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU (RCCL over xGMI for N > 1), weak scaling (fixed per-GPU batch).
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     -- the dominant kernel (bf16 implicit-GEMM 3x3 conv 512->512 of the heads),
+                  timed live with HIP events on its launch stream;
+  cpu_baseline -- the CPU oracle's train step on the host cores (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(backbone="dpt_base", H=384, W=384, batch=64, name="ObjectnessNet ViT-B/16 384x384 bf16 batch=64 train"),
+    "cfg4": dict(backbone="dpt_large14", H=518, W=518, batch=16, name="ObjectnessNet ViT-L/14 518x518 bf16 batch=16 train"),
+    "tiny": dict(backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
+}
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def forward_gflop_per_image(cfg, H, W):
+    """SURVEY.md section 8d formula (2*MAC, forward)."""
+    p, D, L_ = cfg["patch"], cfg["D"], max(cfg["hooks"]) + 1
+    Fs = cfg["features"]
+    gh, gw = H // p, W // p
+    g = gh * gw
+    N = g + 1
+    P = [16 * g, 4 * g, g, ((gh - 1) // 2 + 1) * ((gw - 1) // 2 + 1)]
+    out = H * W
+    fl = 2 * g * 3 * p * p * D + L_ * (24 * N * D * D + 4 * N * N * D) + 16 * g * D * D
+    fl += 2 * g * D * sum(Fs) + 2 * (16 * g * Fs[0] ** 2 + 4 * g * Fs[1] ** 2 + 9 * P[3] * Fs[3] ** 2)
+    fl += 2 * 9 * 256 * sum(P[i] * Fs[i] for i in range(4))
+    c3, c1 = 9 * 256 * 256, 256 * 256
+    fl += 2 * ((2 * c3 * P[3] + c1 * 4 * P[3]) + (4 * c3 * P[2] + c1 * P[1]) + (4 * c3 * P[1] + c1 * P[0]) + (4 * c3 * P[0] + c1 * 4 * P[0]))
+    fl += 2 * out * (2 * (256 * 512 + 9 * 512 * 512 + 512 * 1024) + 1024 * 3)
+    return fl / 1e9
+
+
+def cpu_baseline(workload, seconds_budget=30.0):
+    """Reference-style CPU path (the oracle: fp32 PyTorch ops, autograd, Adam) on the host cores."""
+    import torch
+    from oracle import objectness_oracle as orc
+    from unmore_amd import synth
+    from unmore_amd.hashrng import hash_init
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = orc.CONFIGS[workload["backbone"]]
+    H, W = workload["H"], workload["W"]
+    spec = orc.state_dict_spec(cfg)
+    sd = {k: torch.from_numpy(hash_init(k, s, "bench")).requires_grad_(True) for k, s in spec.items()}
+    img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(1, H, W, seed=123))
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+
+    def one(step):
+        for t in sd.values():
+            t.grad = None
+        loss, _ = orc.loss_terms(orc.forward(sd, img, cfg), cf, sdf, sal)
+        loss.backward()
+        with torch.no_grad():
+            for k, t in sd.items():
+                if t.grad is not None:
+                    orc.adam_update(t, t.grad, m[k], v[k], step)
+
+    t0 = time.perf_counter()
+    one(1)  # warm-up (also sizes the budget)
+    first = time.perf_counter() - t0
+    n = max(1, min(5, int(seconds_budget / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(2 + i)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} timed train steps (fwd+loss+bwd+Adam, fp32) at batch 1 of {workload['name'].split(' bf16')[0]}, after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from argparse import Namespace
+    from unmore_amd import ops, synth
+    from unmore_amd.engine import CONFIGS
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd.trainer import TrainStep
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    wl = WORKLOADS[a.workload]
+    B = a.batch or wl["batch"]
+    H, W = wl["H"], wl["W"]
+    cfg = CONFIGS[wl["backbone"]]
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    net = ObjectnessNet(dev, H, wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
+    net.set_compute_dtype(dt)
+    net.train()
+    step = TrainStep(net, lr=1e-4, center_field_loss_type="l2", sdf_loss_type="l1", use_sdf_gradient_loss=True,
+                     use_sdf_binary_mask_loss=True, lr_milestones=(10000, 20000), lr_gamma=0.1)
+    img, cf, sdf, sal = (torch.from_numpy(x).to(dev) for x in synth.make_batch(B, H, W, seed=rank))
+
+    # dominant kernel: 3x3 conv 512->512 over all B*H*W pixels (heads: 2 forward + 2 data-gradient launches / step)
+    def is_head_conv(d):
+        return d.conv == 1 and d.Cin == 512 and d.N == 512 and d.M == B * H * W
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step.step(img, cf, sdf, sal)
+    barrier()
+    ops.set_kernel_timer(is_head_conv)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(a.steps):
+        last = step.step(img, cf, sdf, sal)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    conv_ms = ops.kernel_timer_results_ms()
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(last[0].item())
+
+    if rank == 0:
+        fwd_gflop = forward_gflop_per_image(cfg, H, W)
+        conv_flop = 2.0 * B * H * W * 512 * 4608
+        avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        achieved = conv_flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        res = {
+            "metric": "images/sec (train fwd+bwd) ObjectnessNet ViT-B/16 384x384" if a.workload == "cfg2" else f"images/sec (train fwd+bwd) {wl['name']}",
+            "value": world * B * a.steps / elapsed,
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": wl["name"] if a.batch is None else wl["name"].replace(f"batch={wl['batch']}", f"batch={B}"),
+                       "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
+                       "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"},
+            "train_tflops_per_gpu": 3 * fwd_gflop * B * a.steps / elapsed / 1e3,
+            "final_loss": loss_val,
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<bf16,conv3x3> 512->512 (heads, fwd+dgrad)" if a.dtype == "bf16" else "gemm_nt_kernel<f32,conv3x3>",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop, "traffic": None},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -288,7 +288,7 @@ class Engine:
         return outs[0], outs[1], S
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P, S, d_center, d_sdf, G):
+    def backward(self, P, S, d_center, d_sdf, G, stage_cb=None):
         """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
         Parameters that receive no gradient are left untouched."""
         cfg, dt = self.cfg, self.dt
@@ -296,6 +296,7 @@ class Engine:
         D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
         g, Nt = gh * gw, gh * gw + 1
         dev = d_center.device
+        cb = stage_cb if stage_cb is not None else (lambda name: None)
 
         def wgrad_lin(name, dy, x, bias_name=None, **kw):
             ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw)
@@ -334,6 +335,7 @@ class Engine:
                 ops.gemm_nt(dh1, self._w(P, f"{name}.{idx[0]}.weight", "lin_t"), None, aux=dfeat, out=dfeat)
             del dh1
         S["feat"] = None
+        cb("heads")
         ph, pw = S["path1_hw"]
         dpath = ops.bilinear_bwd(dfeat.view(B, H, W, 256), ph, pw, True)
         del dfeat
@@ -373,6 +375,7 @@ class Engine:
                 d_rn[k] = ds
             S["fus"][k] = None
 
+        cb("refine")
         # ---- layerK_rn + reassemble + readout; token gradients collected per hook
         pp = "backbone.pretrained."
         Fs = cfg["features"]
@@ -419,6 +422,8 @@ class Engine:
             d_hook[k] = (d_rpre, sBt, a)
             S["re"][k] = None
 
+        cb("reassemble")
+
         def add_hook_grad(k, dx):
             d_rpre, sBt, a = d_hook[k]
             wname = a + "0.project.0.weight"
@@ -461,6 +466,7 @@ class Engine:
                                    G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1)
             del dln1, dx1
             S["blocks"][i] = None
+            cb(f"block{i}")
 
         # ---- embeddings (vit.py:179-193)
         dpos = ops.segsum(dx, Nt, B, Nt * D, D, D)  # [Nt, D] f32, sum over images
@@ -480,4 +486,5 @@ class Engine:
         else:
             tmp = ops.gemm_tn(dx, patches, dbias=G[m + "patch_embed.proj.bias"], dy_remap=(g, Nt, 1), M=B * g)
             gwp.copy_(tmp[:, :K])
+        cb("embed")
         S.clear()

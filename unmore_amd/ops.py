@@ -105,7 +105,7 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     if c_remap is not None:
         d.c_rows_in, d.c_rows_out, d.c_row_off = c_remap
     d.aux_mod = aux_mod
-    L.check(L.lib().umr_gemm_nt(ctypes.byref(d), _stream()), "umr_gemm_nt")
+    L.check(_timed_call(d), "umr_gemm_nt")
     return (out, out2) if c2_mode else out
 
 
@@ -327,3 +327,34 @@ def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_
         assert t.dtype == torch.float32 and t.is_contiguous()
     L.check(L.lib().umr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()),
             "umr_adam_step")
+
+
+# ---------------------------------------------------------------- kernel timing hook (bench.py roofline leg)
+# HIP events recorded on the launch stream around selected umr_gemm_nt launches.
+_timer = {"select": None, "events": []}
+
+
+def set_kernel_timer(select):
+    """select(desc: GemmDesc) -> bool chooses which gemm_nt launches to time; None disables."""
+    _timer["select"] = select
+    _timer["events"] = []
+
+
+def kernel_timer_results_ms():
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) for a, b in _timer["events"]]
+
+
+_raw_gemm_nt_call = None
+
+
+def _timed_call(d):
+    sel = _timer["select"]
+    if sel is not None and sel(d):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        st = L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
+        b.record()
+        _timer["events"].append((a, b))
+        return st
+    return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())

@@ -1,0 +1,102 @@
+"""Native training step for the stage-1 ObjectnessNet (reference loop:
+train_objectness_net.py:181-261): forward, fused 4-term loss, backward, gradient
+all-reduce (data parallel, one process per GPU over RCCL), Adam and the per-iteration
+MultiStepLR schedule -- all on the HIP kernels, no autograd graph, one host sync at most
+(only if the caller reads the loss).
+
+Parameters that receive gradients are re-homed into ONE flat fp32 buffer laid out in
+backward-completion order (heads, refinenets, reassemble, blocks last..first, embeddings)
+so that (a) the gradient buffer is exchanged in a few large contiguous buckets that
+overlap the remaining backward, and (b) Adam is a single kernel launch over the flat
+buffers.  `model.state_dict()` is unaffected (parameters are views)."""
+import torch
+
+from . import ops
+from .parallel import BucketedAllReduce
+
+
+def _stage_of(name, cfg):
+    if name.startswith("center_field_prediction_head") or name.startswith("sdf_prediction_head"):
+        return "heads"
+    if name.startswith("backbone.scratch.refinenet"):
+        return "refine"
+    if name.startswith("backbone.scratch.layer") or name.startswith("backbone.pretrained.act_postprocess"):
+        return "reassemble"
+    m = "backbone.pretrained.model.blocks."
+    if name.startswith(m):
+        return "block" + name[len(m):].split(".")[0]
+    return "embed"
+
+
+class TrainStep:
+    def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, center_field_loss_type="l2", sdf_loss_type="l1",
+                 use_sdf_gradient_loss=True, use_sdf_binary_mask_loss=True, lr_milestones=(), lr_gamma=1.0, group=None):
+        self.net = net
+        self.lr0, self.betas, self.eps = lr, betas, eps
+        self.milestones, self.gamma = tuple(lr_milestones), lr_gamma
+        self.loss_cfg = (center_field_loss_type == "l2", sdf_loss_type == "l2", bool(use_sdf_gradient_loss),
+                         bool(use_sdf_binary_mask_loss))
+        self.iter = 0
+        cfg = net.cfg
+        named = dict(net.named_parameters())
+        dev = next(iter(named.values())).device
+        assert dev.type == "cuda", "TrainStep needs the model on the GPU"
+        nograd = net.nograd_names()
+        order = ["heads", "refine", "reassemble"] + [f"block{i}" for i in range(max(cfg["hooks"]), -1, -1)] + ["embed"]
+        by_stage = {s: [] for s in order}
+        for n, p in named.items():
+            if n in nograd:
+                continue
+            by_stage[_stage_of(n, cfg)].append(n)
+        # flat layout, every view 256-byte aligned
+        offs, bounds, off = {}, [0], 0
+        self.stage_bucket = {}
+        for bi, s in enumerate(order):
+            for n in by_stage[s]:
+                offs[n] = off
+                off += (named[n].numel() + 63) // 64 * 64
+            bounds.append(off)
+            self.stage_bucket[s] = bi
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.G = {}
+        with torch.no_grad():
+            for n, o in offs.items():
+                p = named[n]
+                view = self.flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self.G[n] = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.P = {n: p for n, p in net.named_parameters()}
+        self.comm = BucketedAllReduce(self.flat_g, bounds, group)
+        net._engine().cache.clear()
+
+    def current_lr(self):
+        lr = self.lr0
+        for ms in self.milestones:
+            if self.iter >= ms:
+                lr *= self.gamma
+        return lr
+
+    def step(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
+        """One optimisation step; returns the [total, center, sdf, grad, bce] loss tensor (device, f32)."""
+        eng = self.net._engine()
+        center, sdf, S = eng.forward(self.P, images, save=True)
+        out5, dpc, dps = ops.objectness_loss(center, sdf, gt_center_fields, gt_sdf_maps, gt_saliency_maps, *self.loss_cfg)
+        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=lambda s: self.comm.ready(self.stage_bucket[s]))
+        scale = self.comm.finish()
+        self.iter += 1
+        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.iter, self.current_lr_for_step(), self.betas[0], self.betas[1],
+                      self.eps, scale)
+        eng.cache.clear()  # packed (kernel-layout) weight copies are stale after the in-place update
+        return out5
+
+    def current_lr_for_step(self):
+        # torch's MultiStepLR.step() runs after optimizer.step(): step k (1-based) uses the lr of k-1 completed steps
+        lr = self.lr0
+        for ms in self.milestones:
+            if self.iter - 1 >= ms:
+                lr *= self.gamma
+        return lr

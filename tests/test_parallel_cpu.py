@@ -1,0 +1,59 @@
+"""world_size-2 gloo test (CPU) of the data-parallel gradient exchange used by TrainStep:
+bucketed asynchronous all-reduce of a flat gradient buffer + 1/world scaling."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unmore_amd.parallel import BucketedAllReduce
+    n = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(n, generator=g)
+    local = flat.clone()
+    bounds = [0, 64, 64, 640, 1000]  # includes an empty bucket
+    comm = BucketedAllReduce(flat, bounds)
+    assert comm.enabled and comm.world == world and comm.num_buckets == 4
+    for k in range(comm.num_buckets):  # backward-completion order
+        comm.ready(k)
+    scale = comm.finish()
+    torch.save({"local": local, "reduced": flat.clone(), "scale": scale}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"r{i}.pt")) for i in range(world)]
+    expect = r[0]["local"] + r[1]["local"]
+    for i in range(world):
+        torch.testing.assert_close(r[i]["reduced"], expect)
+        assert r[i]["scale"] == 0.5
+    # averaged gradient == gradient of the mean loss over the global batch
+    torch.testing.assert_close(r[0]["reduced"] * r[0]["scale"], (r[0]["local"] + r[1]["local"]) / 2)
+
+
+def test_single_process_is_a_noop():
+    from unmore_amd.parallel import BucketedAllReduce
+    flat = torch.arange(10.0)
+    comm = BucketedAllReduce(flat, [0, 4, 10])
+    assert not comm.enabled
+    comm.ready(0)
+    comm.ready(1)
+    assert comm.finish() == 1.0
+    assert torch.equal(flat, torch.arange(10.0))

@@ -83,6 +83,65 @@ __device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_log
     }
 }
 
+// 8 consecutive elements <-> two f32x4
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, f32x4& a, f32x4& b) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+    static __device__ __forceinline__ void store(float* p, f32x4 a, f32x4 b) { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, f32x4& a, f32x4& b) {
+        const bf16x8 t = *(const bf16x8*)p;
+        a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        b = f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, f32x4 a, f32x4 b) {
+        bf16x8 t;
+        t[0] = (bf16_t)a[0]; t[1] = (bf16_t)a[1]; t[2] = (bf16_t)a[2]; t[3] = (bf16_t)a[3];
+        t[4] = (bf16_t)b[0]; t[5] = (bf16_t)b[1]; t[6] = (bf16_t)b[2]; t[7] = (bf16_t)b[3];
+        *(bf16x8*)p = t;
+    }
+};
+
+// vector form of epilogue_store: 8 consecutive columns n..n+7 of logical row m_logical (all in range, all
+// row strides multiples of 8 elements)
+template <typename T>
+__device__ __forceinline__ void epilogue_store8(const umr_gemm_desc& p, int m_logical, int n, f32x4 v0, f32x4 v1) {
+    int m = m_logical;
+    if (p.c_rows_in > 0) m = (m_logical / p.c_rows_in) * p.c_rows_out + p.c_row_off + (m_logical % p.c_rows_in);
+    const int m_aux = p.aux_mod > 0 ? (m_logical % p.aux_mod) : m;
+    if (p.flags & UMR_EPI_BIAS) { v0 += *(const f32x4*)(p.bias + n); v1 += *(const f32x4*)(p.bias + n + 4); }
+    if (p.flags & UMR_EPI_ROWBIAS) {
+        const float* rb = p.rowbias + (int64_t)(m_logical / p.rows_per_batch) * p.N + n;
+        v0 += *(const f32x4*)rb; v1 += *(const f32x4*)(rb + 4);
+    }
+    if (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) {
+        f32x4 a0, a1;
+        Vec8<T>::load((const T*)p.aux + (int64_t)m_aux * p.ldaux + n, a0, a1);
+        if (p.flags & UMR_EPI_ADD_AUX) { v0 += a0; v1 += a1; }
+        else if (p.flags & UMR_EPI_MASK_RELU) {
+            for (int j = 0; j < 4; ++j) { v0[j] = a0[j] > 0.f ? v0[j] : 0.f; v1[j] = a1[j] > 0.f ? v1[j] : 0.f; }
+        } else {
+            for (int j = 0; j < 4; ++j) { v0[j] *= dgelu_erf(a0[j]); v1[j] *= dgelu_erf(a1[j]); }
+        }
+    }
+    if (p.flags & UMR_EPI_ADD_AUX2) {
+        f32x4 a0, a1;
+        Vec8<T>::load((const T*)p.aux2 + (int64_t)m * p.ldaux2 + n, a0, a1);
+        v0 += a0; v1 += a1;
+    }
+    if (p.c2_mode == 2) Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
+    if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); } }
+    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); } }
+    else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) { v0[j] = tanhf(v0[j]); v1[j] = tanhf(v1[j]); } }
+    if (p.flags & UMR_EPI_OUT_F32) Vec8<float>::store((float*)p.C + (int64_t)m * p.ldc + n, v0, v1);
+    else Vec8<T>::store((T*)p.C + (int64_t)m * p.ldc + n, v0, v1);
+    if (p.c2_mode == 1) {
+        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
+        Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
+    }
+}
+
 template <typename T, int CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -101,68 +160,100 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const char* zero = (const char*)umr_zero_page;
+    // ---- staging by buffer LDS-DMA (buffer_load_dwordx4 ... lds): address = descriptor base (tile-local,
+    // scalar) + per-lane 32-bit voffset (constant for the whole K loop) + scalar soffset (the K-tile / tap
+    // offset).  Out-of-range lanes make the DMA write ZEROS to LDS (measured: tools/probe/oob_lds.hip), which
+    // gives conv halos, M/N tails and K tails for free: a masked lane's voffset is simply OOB.  Per K-tile the
+    // staging path issues no VALU address arithmetic at all (it was ~4 VALU per MFMA with flat addresses).
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int SZ = (int)sizeof(T);
     const int lrow = lane >> 3, lchk = lane & 7;
-    const char* a_ptr[4];
-    const char* b_ptr[4];
-    bool a_ok[4], b_ok[4];
-    int a_y[4], a_x[4], gch[4];
     const int stride = (CONV == 2) ? 2 : 1;
+    unsigned a_vo[4], a_eff[4], b_vo[4];
+    int a_y[4], a_x[4], gch[4];
+    const char* a_base;
+    {
+        int64_t origin;  // element index of the tile-local origin in A
+        if (CONV == 0) {
+            int ar0 = m0;
+            if (p.a_rows_in > 0) ar0 = (m0 / p.a_rows_in) * p.a_rows_out + p.a_row_off + (m0 % p.a_rows_in);
+            origin = (int64_t)ar0 * p.lda;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (w * 4 + i) * 8 + lrow;
+                gch[i] = lchk ^ (((i & 1) << 2) + (lane >> 4));
+                const int m = m0 + r;
+                int ar = m;
+                if (p.a_rows_in > 0) ar = (m / p.a_rows_in) * p.a_rows_out + p.a_row_off + (m % p.a_rows_in);
+                a_vo[i] = (m < p.M) ? (unsigned)(((int64_t)(ar - ar0) * p.lda) * SZ + gch[i] * 16) : OOB;
+                a_y[i] = a_x[i] = 0;
+            }
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int b0 = m0 / hw, rem0 = m0 - b0 * hw;
+            const int oy0 = rem0 / p.Wo, ox0 = rem0 - oy0 * p.Wo;
+            const int64_t pix0 = ((int64_t)b0 * p.H + oy0 * stride) * p.W + ox0 * stride;
+            origin = (pix0 - (p.W + 1)) * p.Cin;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (w * 4 + i) * 8 + lrow;
+                gch[i] = lchk ^ (((i & 1) << 2) + (lane >> 4));
+                const int m = m0 + r;
+                const int b = m / hw, rem = m - b * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int64_t pix = ((int64_t)b * p.H + oy * stride) * p.W + ox * stride;
+                a_vo[i] = (m < p.M) ? (unsigned)((pix - pix0) * p.Cin * SZ + gch[i] * 16) : OOB;
+                a_y[i] = oy * stride - 1;
+                a_x[i] = ox * stride - 1;
+            }
+        }
+        a_base = (const char*)p.A + origin * SZ;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (w * 4 + i) * 8 + lrow;
-        gch[i] = lchk ^ (((i & 1) << 2) + (lane >> 4));
-        const int m = m0 + r;
-        a_ok[i] = m < p.M;
-        if (CONV == 0) {
-            int ar = m;
-            if (p.a_rows_in > 0) ar = (m / p.a_rows_in) * p.a_rows_out + p.a_row_off + (m % p.a_rows_in);
-            a_ptr[i] = (const char*)p.A + (int64_t)ar * p.lda * (int64_t)sizeof(T);
-            a_y[i] = a_x[i] = 0;
-        } else {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, rem = m - b * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_ptr[i] = (const char*)p.A + (int64_t)b * p.H * p.W * p.Cin * (int64_t)sizeof(T);
-            a_y[i] = oy * stride - 1;
-            a_x[i] = ox * stride - 1;
-        }
-        const int n = n0 + r;
-        b_ok[i] = n < p.N;
-        b_ptr[i] = (const char*)p.B + (int64_t)n * p.ldb * (int64_t)sizeof(T);
+        b_vo[i] = (n0 + r < p.N) ? (unsigned)(((int64_t)r * p.ldb) * SZ + gch[i] * 16) : OOB;
+        a_eff[i] = a_vo[i];
     }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a_base, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (int64_t)n0 * p.ldb * SZ), 0, 0x7FFFFFFF, 0x00020000);
 
     const int ktiles_per_tap = (CONV == 0) ? 0 : (p.Cin + BK - 1) / BK;
     const int nt = (CONV == 0) ? (p.K + BK - 1) / BK : 9 * ktiles_per_tap;
+    const bool k_tail = (CONV == 0) ? (p.K % BK) != 0 : (p.Cin % BK) != 0;
 
+    // sequential staging state (stage() is called for t = 0, 1, 2, ... in order)
+    int st_tap = 0, st_ci = 0;
     auto stage = [&](int t, int buf) {
         char* sa = smem + buf * STAGE_BYTES + w * 4096;
         char* sb = sa + TILE_BYTES;
-        int tap = 0, c0 = t * BK, ky = 0, kx = 0;
-        if (CONV != 0) {
-            tap = t / ktiles_per_tap;
-            c0 = (t - tap * ktiles_per_tap) * BK;
-            ky = tap / 3;
-            kx = tap - ky * 3;
+        unsigned soffA, soffB;
+        int c0;
+        if (CONV == 0) {
+            c0 = t * BK;
+            soffA = soffB = (unsigned)(c0 * SZ);
+        } else {
+            c0 = st_ci * BK;
+            const int ky = st_tap / 3, kx = st_tap - ky * 3;
+            if (st_ci == 0) {  // new tap: which of this lane's rows fall inside the image
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = (unsigned)(a_y[i] + ky) < (unsigned)p.H && (unsigned)(a_x[i] + kx) < (unsigned)p.W;
+                    a_eff[i] = ok ? a_vo[i] : OOB;
+                }
+            }
+            soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
+            soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
+            if (++st_ci == ktiles_per_tap) { st_ci = 0; ++st_tap; }
         }
+        const int klim = (CONV == 0) ? p.K : p.Cin;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int kk = c0 + gch[i] * EPC;
-            const char* srcA;
-            const char* srcB;
-            if (CONV == 0) {
-                const bool okk = kk < p.K;
-                srcA = (a_ok[i] && okk) ? a_ptr[i] + (int64_t)kk * sizeof(T) : zero;
-                srcB = (b_ok[i] && okk) ? b_ptr[i] + (int64_t)kk * sizeof(T) : zero;
-            } else {
-                const bool okc = kk < p.Cin;
-                const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-                const bool oka = a_ok[i] && okc && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                srcA = oka ? a_ptr[i] + ((int64_t)(iy * p.W + ix) * p.Cin + kk) * (int64_t)sizeof(T) : zero;
-                srcB = (b_ok[i] && okc) ? b_ptr[i] + (int64_t)(tap * p.Cin + kk) * sizeof(T) : zero;
-            }
-            glds16(srcA, sa + i * 1024);
-            glds16(srcB, sb + i * 1024);
+            unsigned va = a_eff[i], vb = b_vo[i];
+            if (k_tail && (c0 + gch[i] * EPC >= klim)) { va = OOB; vb = OOB; }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, UMR_LDS_PTR(sa + i * 1024), 16, va, soffA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, UMR_LDS_PTR(sb + i * 1024), 16, vb, soffB, 0, 0);
         }
     };
 
@@ -174,32 +265,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 
     const int wr = w >> 1, wc = w & 1;
     const int frow = lane & 15, fq = lane >> 4;
-    // row byte offsets and swizzle keys of this lane's fragment rows
-    int a_off[4], b_off[4], a_sw[4], b_sw[4];
+    // LDS byte addresses of this lane's fragments (buffer 0), one per (k-step, tile): loop invariant
+    int a_addr[2][4], b_addr[2][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ra = wr * 64 + i * 16 + frow, rb = wc * 64 + i * 16 + frow;
-        a_off[i] = ra * ROWB;
-        a_sw[i] = (ra >> 1) & 7;
-        b_off[i] = TILE_BYTES + rb * ROWB;
-        b_sw[i] = (rb >> 1) & 7;
-    }
-
-    stage(0, 0);
-    for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-        const char* sbuf = smem + (t & 1) * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int q = ks * 4 + fq;
+            a_addr[ks][i] = ra * ROWB + ((q ^ ((ra >> 1) & 7)) << 4);
+            b_addr[ks][i] = TILE_BYTES + rb * ROWB + ((q ^ ((rb >> 1) & 7)) << 4);
+        }
+    }
+
+    auto compute = [&](const char* sbuf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
             if constexpr (sizeof(T) == 2) {
                 bf16x8 af[4], bfr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[i] = *(const bf16x8*)(sbuf + a_off[i] + ((q ^ a_sw[i]) << 4));
-                    bfr[i] = *(const bf16x8*)(sbuf + b_off[i] + ((q ^ b_sw[i]) << 4));
+                    af[i] = *(const bf16x8*)(sbuf + a_addr[ks][i]);
+                    bfr[i] = *(const bf16x8*)(sbuf + b_addr[ks][i]);
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -210,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
                 f32x4 af[4], bfr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    af[i] = *(const f32x4*)(sbuf + a_off[i] + ((q ^ a_sw[i]) << 4));
-                    bfr[i] = *(const f32x4*)(sbuf + b_off[i] + ((q ^ b_sw[i]) << 4));
+                    af[i] = *(const f32x4*)(sbuf + a_addr[ks][i]);
+                    bfr[i] = *(const f32x4*)(sbuf + b_addr[ks][i]);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -222,18 +309,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
                             acc[mt][ntl] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[ntl][j], af[mt][j], acc[mt][ntl], 0, 0, 0);
             }
         }
+    };
+
+    stage(0, 0);
+    for (int t = 0; t < nt; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, 1);
+        compute(smem);
+        if (t + 1 >= nt) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nt) stage(t + 2, 0);
+        compute(smem + STAGE_BYTES);
     }
 
-    // epilogue: lane holds row m = .. + (lane&15), columns n = .. + (lane>>4)*4 + {0..3}
+    // ---- epilogue.  Accumulators (lane: row (lane&15), 4 consecutive columns) are staged through LDS in two
+    // passes of 64 tile rows ([64][132] f32, padded against ds_write_b128 conflicts), then every thread handles
+    // (row, 8 consecutive columns) tasks: bias / aux / C accesses are 16-byte vectors and each 128-column tile row
+    // is written as one contiguous 256-byte (bf16) run -- full HBM lines instead of 32-byte fragments.
+    constexpr int EP_LD = 132;
+    float* stg = (float*)smem;
+    const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.ldc2 & 7) == 0) && ((p.ldaux & 7) == 0) &&
+                        ((p.ldaux2 & 7) == 0);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wr * 64 + mt * 16 + frow;
-        if (m >= p.M) continue;
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
 #pragma unroll
-        for (int ntl = 0; ntl < 4; ++ntl) {
-            const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-            if (n >= p.N) continue;
-            epilogue_store<T>(p, m, n, acc[mt][ntl]);
+        for (int mh = 0; mh < 2; ++mh) {
+            const int mt = pass * 2 + mh;
+            const int lr = wr * 32 + mh * 16 + frow;  // staging row 0..63
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl)
+                *(f32x4*)(stg + lr * EP_LD + wc * 64 + ntl * 16 + fq * 4) = acc[mt][ntl];
+        }
+        __syncthreads();
+        for (int task = tid; task < 64 * 16; task += 256) {
+            const int lr = task >> 4, c8 = (task & 15) * 8;
+            // staging row -> tile row: rows [wr*32, wr*32+32) of this pass are tile rows wr*64 + pass*32 + ..
+            const int trow = (lr >> 5) * 64 + pass * 32 + (lr & 31);
+            const int m = m0 + trow, n = n0 + c8;
+            if (m >= p.M || n >= p.N) continue;
+            const f32x4 v0 = *(const f32x4*)(stg + lr * EP_LD + c8), v1 = *(const f32x4*)(stg + lr * EP_LD + c8 + 4);
+            if (vec_ok) {
+                epilogue_store8<T>(p, m, n, v0, v1);
+            } else {
+                epilogue_store<T>(p, m, n, v0);
+                if (n + 4 < p.N) epilogue_store<T>(p, m, n + 4, v1);
+            }
         }
     }
 }

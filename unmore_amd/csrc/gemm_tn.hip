@@ -66,6 +66,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
         }
     }
     const int stride = (CONV == 2) ? 2 : 1;
+    // conv: pixel coordinates of this lane's 4 staging rows, advanced incrementally by ROWS per stage
+    // (float-reciprocal carries instead of integer divisions: the staging path is VALU-bound otherwise)
+    int cb[4], coy[4], cox[4], tky[4], tkx[4];
+    const float inv_wo = (CONV != 0) ? 1.0f / (float)p.Wo : 0.f, inv_ho = (CONV != 0) ? 1.0f / (float)p.Ho : 0.f;
+    if (CONV != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_begin + (w * 4 + i) * RPI + lrow;
+            const int hw = p.Ho * p.Wo;
+            cb[i] = m / hw;
+            const int rem = m - cb[i] * hw;
+            coy[i] = rem / p.Wo;
+            cox[i] = rem - coy[i] * p.Wo;
+            tky[i] = k_tap[i] / 3;
+            tkx[i] = k_tap[i] - tky[i] * 3 - 1;
+            tky[i] -= 1;
+        }
+    }
+    auto carry = [](int& x, int d, float inv) -> int {  // x < 2^22: q = x / d, x %= d
+        int q = (int)((float)x * inv);
+        int r = x - q * d;
+        if (r >= d) { r -= d; ++q; } else if (r < 0) { r += d; --q; }
+        x = r;
+        return q;
+    };
 
     auto stage = [&](int mbase, int buf) {
         char* sa = smem + buf * STAGE + w * 4096;  // dY tile
@@ -86,14 +111,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
                 if (mok && k_ok[i]) srcB = (const char*)p.X + ((int64_t)mx * p.ldx + k_ci[i]) * (int64_t)sizeof(T);
             } else {
                 if (mok && k_ok[i]) {
-                    const int hw = p.Ho * p.Wo;
-                    const int b = m / hw, rem = m - b * hw;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    const int ky = k_tap[i] / 3, kx = k_tap[i] - ky * 3;
-                    const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+                    const int iy = coy[i] * stride + tky[i], ix = cox[i] * stride + tkx[i];
                     if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                        srcB = (const char*)p.X + ((((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * (int64_t)sizeof(T);
+                        srcB = (const char*)p.X + ((((int64_t)cb[i] * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * (int64_t)sizeof(T);
                 }
+                cox[i] += ROWS;
+                coy[i] += carry(cox[i], p.Wo, inv_wo);
+                cb[i] += carry(coy[i], p.Ho, inv_ho);
             }
             glds16(srcA, sa + i * 1024);
             glds16(srcB, sb + i * 1024);
@@ -227,7 +251,8 @@ TnPlan tn_plan(const umr_gemm_tn_desc* d) {
     pl.tiles_k = (d->K + TN_BK - 1) / TN_BK;
     const int64_t tiles = (int64_t)pl.tiles_n * pl.tiles_k;
     const int rows = d->dtype == UMR_BF16 ? 64 : 32;
-    int64_t want = (1536 + tiles - 1) / tiles;              // ~6 workgroups per CU in flight
+    // 256 CUs x 2 resident workgroups = 512 slots: aim just under 8 full rounds so the last round is full
+    int64_t want = 4096 / tiles;
     const int64_t max_by_rows = ((int64_t)d->M + rows * 8 - 1) / (rows * 8);  // >= 8 stages per split
     if (want > max_by_rows) want = max_by_rows;
     if (want < 1) want = 1;

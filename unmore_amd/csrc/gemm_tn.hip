@@ -42,48 +42,56 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
     const int n0 = tn * TN_BN, k0 = tk * TN_BK;
     const int m_begin = split * rows_per_split;
     const int m_end = min(p.M, m_begin + rows_per_split);
-    const char* zero = (const char*)umr_zero_page;
     const bool do_bias = (p.dbias != nullptr) && (tk == 0);
 
-    // ---- staging roles: per stage each wave issues 4 glds per operand; instruction i of
-    // wave w covers rows (w*4+i)*RPI + lane/CPR, chunk position lane%CPR.
+    // ---- staging by buffer LDS-DMA (see gemm_nt.hip): per stage each wave issues 4 loads per operand;
+    // instruction i of wave w covers rows (w*4+i)*RPI + lane/CPR, chunk position lane%CPR.  Descriptor bases are
+    // advanced per stage with scalar arithmetic; per-lane voffsets are loop constants; row tails fall out of the
+    // descriptor's num_records and conv halos / column tails use an out-of-range voffset (LDS gets zeros).
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int SZ = (int)sizeof(T);
     const int lrow = lane / CPR, lchk = lane % CPR;
-    int gch[4];
-    bool n_ok[4], k_ok[4];
-    int k_tap[4], k_ci[4];
+    const int stride = (CONV == 2) ? 2 : 1;
+    int rr[4], gch[4], k_tap[4], k_ci[4], tky[4], tkx[4];
+    unsigned y_vo[4], x_vo[4];
+    bool k_ok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (w * 4 + i) * RPI + lrow;
+        rr[i] = r;
         gch[i] = (sizeof(T) == 2) ? (lchk ^ tn_swz(r)) : lchk;
-        n_ok[i] = (n0 + gch[i] * EPC) < p.N;
+        const bool n_ok = (n0 + gch[i] * EPC) < p.N;
+        y_vo[i] = n_ok ? (unsigned)(((int64_t)r * p.lddy) * SZ + gch[i] * 16) : OOB;
         const int kc = k0 + gch[i] * EPC;
         k_ok[i] = kc < p.K;
         k_tap[i] = 0;
         k_ci[i] = kc;
+        tky[i] = tkx[i] = 0;
         if (CONV != 0 && k_ok[i]) {
             k_tap[i] = kc / p.Cin;
             k_ci[i] = kc - k_tap[i] * p.Cin;
-        }
-    }
-    const int stride = (CONV == 2) ? 2 : 1;
-    // conv: pixel coordinates of this lane's 4 staging rows, advanced incrementally by ROWS per stage
-    // (float-reciprocal carries instead of integer divisions: the staging path is VALU-bound otherwise)
-    int cb[4], coy[4], cox[4], tky[4], tkx[4];
-    const float inv_wo = (CONV != 0) ? 1.0f / (float)p.Wo : 0.f, inv_ho = (CONV != 0) ? 1.0f / (float)p.Ho : 0.f;
-    if (CONV != 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_begin + (w * 4 + i) * RPI + lrow;
-            const int hw = p.Ho * p.Wo;
-            cb[i] = m / hw;
-            const int rem = m - cb[i] * hw;
-            coy[i] = rem / p.Wo;
-            cox[i] = rem - coy[i] * p.Wo;
             tky[i] = k_tap[i] / 3;
             tkx[i] = k_tap[i] - tky[i] * 3 - 1;
             tky[i] -= 1;
         }
+        if (CONV == 0) x_vo[i] = k_ok[i] ? (unsigned)(((int64_t)r * p.ldx) * SZ + gch[i] * 16) : OOB;
+        else x_vo[i] = k_ok[i] ? (unsigned)(((int64_t)(r + (tky[i] + 1) * p.W + (tkx[i] + 1)) * p.Cin + k_ci[i]) * SZ) : OOB;
     }
+    // fast conv path: stride 1 and every ROWS-row stage lies inside one image row (Wo % ROWS == 0)
+    const bool conv_fast = (CONV == 1) && (p.Wo % ROWS == 0);
+    const bool remap = (p.dy_rows_in > 0) || (CONV == 0 && p.x_rows_in > 0);
+    // scalar pixel position of the stage's first row (conv)
+    int sb = 0, soy = 0, sox = 0;
+    if (CONV != 0) {
+        const int hw = p.Ho * p.Wo;
+        sb = m_begin / hw;
+        const int rem = m_begin - sb * hw;
+        soy = rem / p.Wo;
+        sox = rem - soy * p.Wo;
+    }
+    // general conv path: per-lane pixel coordinates advanced incrementally (float-reciprocal carries)
+    int cb[4], coy[4], cox[4];
+    const float inv_wo = (CONV != 0) ? 1.0f / (float)p.Wo : 0.f, inv_ho = (CONV != 0) ? 1.0f / (float)p.Ho : 0.f;
     auto carry = [](int& x, int d, float inv) -> int {  // x < 2^22: q = x / d, x %= d
         int q = (int)((float)x * inv);
         int r = x - q * d;
@@ -91,36 +99,83 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
         x = r;
         return q;
     };
+    if (CONV != 0 && !conv_fast) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cb[i] = sb; coy[i] = soy; cox[i] = sox + rr[i];
+            coy[i] += carry(cox[i], p.Wo, inv_wo);
+            cb[i] += carry(coy[i], p.Ho, inv_ho);
+        }
+    }
 
     auto stage = [&](int mbase, int buf) {
         char* sa = smem + buf * STAGE + w * 4096;  // dY tile
-        char* sb = sa + TILE;                      // X tile
+        char* sb_ = sa + TILE;                     // X tile
+        const int rows_left = min(m_end - mbase, ROWS);
+        unsigned vy[4], vx[4];
+        const char* ybase;
+        const char* xbase;
+        unsigned yrec = 0x7FFFFFFFu, xrec = 0x7FFFFFFFu;
+        if (!remap) {
+            ybase = (const char*)p.dY + ((int64_t)mbase * p.lddy + n0) * SZ;
+            yrec = (unsigned)(rows_left * p.lddy * SZ);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (w * 4 + i) * RPI + lrow;
-            const int m = mbase + r;
-            const bool mok = m < m_end;
-            int my = m, mx = m;
-            if (p.dy_rows_in > 0) my = (m / p.dy_rows_in) * p.dy_rows_out + p.dy_row_off + (m % p.dy_rows_in);
-            if (CONV == 0 && p.x_rows_in > 0) mx = (m / p.x_rows_in) * p.x_rows_out + p.x_row_off + (m % p.x_rows_in);
-            const char* srcA = (mok && n_ok[i])
-                                   ? (const char*)p.dY + ((int64_t)my * p.lddy + n0 + gch[i] * EPC) * (int64_t)sizeof(T)
-                                   : zero;
-            const char* srcB = zero;
-            if (CONV == 0) {
-                if (mok && k_ok[i]) srcB = (const char*)p.X + ((int64_t)mx * p.ldx + k_ci[i]) * (int64_t)sizeof(T);
+            for (int i = 0; i < 4; ++i) vy[i] = y_vo[i];
+        } else {
+            ybase = (const char*)p.dY + (int64_t)n0 * SZ;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mbase + rr[i];
+                int my = m;
+                if (p.dy_rows_in > 0) my = (m / p.dy_rows_in) * p.dy_rows_out + p.dy_row_off + (m % p.dy_rows_in);
+                vy[i] = (m < m_end && y_vo[i] != OOB) ? (unsigned)(((int64_t)my * p.lddy) * SZ + gch[i] * 16) : OOB;
+            }
+        }
+        if (CONV == 0) {
+            if (!remap) {
+                xbase = (const char*)p.X + ((int64_t)mbase * p.ldx + k0) * SZ;
+                xrec = (unsigned)(rows_left * p.ldx * SZ);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) vx[i] = x_vo[i];
             } else {
-                if (mok && k_ok[i]) {
-                    const int iy = coy[i] * stride + tky[i], ix = cox[i] * stride + tkx[i];
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                        srcB = (const char*)p.X + ((((int64_t)cb[i] * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * (int64_t)sizeof(T);
+                xbase = (const char*)p.X + (int64_t)k0 * SZ;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mbase + rr[i];
+                    int mx = m;
+                    if (p.x_rows_in > 0) mx = (m / p.x_rows_in) * p.x_rows_out + p.x_row_off + (m % p.x_rows_in);
+                    vx[i] = (m < m_end && k_ok[i]) ? (unsigned)(((int64_t)mx * p.ldx) * SZ + gch[i] * 16) : OOB;
                 }
+            }
+        } else if (conv_fast) {
+            // all ROWS rows of this stage: image sb, output row soy, columns sox .. sox+ROWS-1
+            xbase = (const char*)p.X + ((((int64_t)sb * p.H + soy) * p.W + sox) - (p.W + 1)) * p.Cin * SZ;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = (unsigned)(soy + tky[i]) < (unsigned)p.H && (unsigned)(sox + rr[i] + tkx[i]) < (unsigned)p.W &&
+                                rr[i] < rows_left;
+                vx[i] = ok ? x_vo[i] : OOB;
+            }
+            sox += ROWS;
+            if (sox >= p.Wo) { sox = 0; if (++soy >= p.Ho) { soy = 0; ++sb; } }
+        } else {
+            xbase = (const char*)p.X;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = coy[i] * stride + tky[i], ix = cox[i] * stride + tkx[i];
+                const bool ok = k_ok[i] && rr[i] < rows_left && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                vx[i] = ok ? (unsigned)(((((int64_t)cb[i] * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * SZ) : OOB;
                 cox[i] += ROWS;
                 coy[i] += carry(cox[i], p.Wo, inv_wo);
                 cb[i] += carry(coy[i], p.Ho, inv_ho);
             }
-            glds16(srcA, sa + i * 1024);
-            glds16(srcB, sb + i * 1024);
+        }
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, yrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xrec, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(sa + i * 1024), 16, vy[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(sb_ + i * 1024), 16, vx[i], 0, 0, 0);
         }
     };
 
@@ -287,6 +342,20 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
         UMR_CHECK_ARG((int64_t)d->nb * d->Ho * d->Wo == d->M, "gemm_tn: conv M != nb*Ho*Wo");
         const int s = d->conv == 2 ? 2 : 1;
         UMR_CHECK_ARG(d->Ho == (d->H - 1) / s + 1 && d->Wo == (d->W - 1) / s + 1, "gemm_tn: conv output size");
+    }
+    {   // paths that address with absolute 32-bit offsets from the tensor base
+        const int rows = d->dtype == UMR_BF16 ? 64 : 32;
+        const int64_t sz = d->dtype == UMR_BF16 ? 2 : 4;
+        const bool remap = d->dy_rows_in > 0 || (d->conv == 0 && d->x_rows_in > 0);
+        const bool conv_general = d->conv != 0 && !(d->conv == 1 && d->Wo % rows == 0);
+        if (conv_general && (int64_t)d->nb * d->H * d->W * d->Cin * sz >= (1ll << 31))
+            return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_tn: conv input >= 2 GiB needs Wo % rows-per-stage == 0 and stride 1");
+        if (remap) {
+            const int64_t ymax = d->dy_rows_in > 0 ? ((int64_t)d->M / d->dy_rows_in + 1) * d->dy_rows_out : d->M;
+            const int64_t xmax = d->x_rows_in > 0 ? ((int64_t)d->M / d->x_rows_in + 1) * d->x_rows_out : d->M;
+            if (ymax * d->lddy * sz >= (1ll << 31) || (d->conv == 0 && xmax * d->ldx * sz >= (1ll << 31)))
+                return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_tn: row-remapped operands must be < 2 GiB");
+        }
     }
     const TnPlan pl = tn_plan(d);
     UMR_CHECK_ARG(d->workspace_bytes >= pl.ws, "gemm_tn: workspace too small");

@@ -12,6 +12,8 @@
 // Implicit conv: the A row of output pixel m for tap (ky,kx) is the input pixel row
 // (iy,ix) = (oy*s+ky-1, ox*s+kx-1); out-of-image rows, K tails and M/N tails read a zero page.
 #include "umr_common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -24,123 +26,6 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;  // double buffered: 64 KiB -> 2 work
 template <typename T> struct Tr;
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };
-
-template <typename T>
-__device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_logical, int n, f32x4 v) {
-    // v = 4 consecutive columns n..n+3 of logical row m_logical; C-shaped operands use the remapped row m
-    int m = m_logical;
-    if (p.c_rows_in > 0) m = (m_logical / p.c_rows_in) * p.c_rows_out + p.c_row_off + (m_logical % p.c_rows_in);
-    const int m_aux = p.aux_mod > 0 ? (m_logical % p.aux_mod) : m;
-    const int nv = p.N - n;  // >0 guaranteed by caller
-    const bool full = nv >= 4 && ((p.N & 3) == 0);
-    if (p.flags & UMR_EPI_BIAS) {
-        if (full) { f32x4 b = *(const f32x4*)(p.bias + n); v += b; }
-        else { for (int j = 0; j < 4; ++j) if (j < nv) v[j] += p.bias[n + j]; }
-    }
-    if (p.flags & UMR_EPI_ROWBIAS) {
-        const float* rb = p.rowbias + (int64_t)(m_logical / p.rows_per_batch) * p.N + n;
-        if (full) { f32x4 b = *(const f32x4*)rb; v += b; }
-        else { for (int j = 0; j < 4; ++j) if (j < nv) v[j] += rb[j]; }
-    }
-    if (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) {
-        const T* ap = (const T*)p.aux + (int64_t)m_aux * p.ldaux + n;
-        f32x4 a;
-        if (full && ((p.ldaux & 3) == 0)) a = Vec4<T>::load(ap);
-        else { for (int j = 0; j < 4; ++j) a[j] = (j < nv) ? to_f32<T>(ap[j]) : 0.f; }
-        if (p.flags & UMR_EPI_ADD_AUX) v += a;
-        else if (p.flags & UMR_EPI_MASK_RELU) { for (int j = 0; j < 4; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f; }
-        else { for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(a[j]); }
-    }
-    if (p.flags & UMR_EPI_ADD_AUX2) {
-        const T* ap = (const T*)p.aux2 + (int64_t)m * p.ldaux2 + n;
-        f32x4 a;
-        if (full && ((p.ldaux2 & 3) == 0)) a = Vec4<T>::load(ap);
-        else { for (int j = 0; j < 4; ++j) a[j] = (j < nv) ? to_f32<T>(ap[j]) : 0.f; }
-        v += a;
-    }
-    if (p.c2_mode == 2) {
-        T* cp = (T*)p.C2 + (int64_t)m * p.ldc2 + n;
-        if (full && ((p.ldc2 & 3) == 0)) Vec4<T>::store(cp, v);
-        else { for (int j = 0; j < 4; ++j) if (j < nv) cp[j] = from_f32<T>(v[j]); }
-    }
-    if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f); }
-    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
-    else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) v[j] = tanhf(v[j]); }
-    if (p.flags & UMR_EPI_OUT_F32) {
-        float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-        if (full && ((p.ldc & 3) == 0)) *(f32x4*)cp = v;
-        else { for (int j = 0; j < 4; ++j) if (j < nv) cp[j] = v[j]; }
-    } else {
-        T* cp = (T*)p.C + (int64_t)m * p.ldc + n;
-        if (full && ((p.ldc & 3) == 0)) Vec4<T>::store(cp, v);
-        else { for (int j = 0; j < 4; ++j) if (j < nv) cp[j] = from_f32<T>(v[j]); }
-    }
-    if (p.c2_mode == 1) {
-        T* cp = (T*)p.C2 + (int64_t)m * p.ldc2 + n;
-        f32x4 r = {fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
-        if (full && ((p.ldc2 & 3) == 0)) Vec4<T>::store(cp, r);
-        else { for (int j = 0; j < 4; ++j) if (j < nv) cp[j] = from_f32<T>(r[j]); }
-    }
-}
-
-// 8 consecutive elements <-> two f32x4
-template <typename T> struct Vec8;
-template <> struct Vec8<float> {
-    static __device__ __forceinline__ void load(const float* p, f32x4& a, f32x4& b) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
-    static __device__ __forceinline__ void store(float* p, f32x4 a, f32x4 b) { *(f32x4*)p = a; *(f32x4*)(p + 4) = b; }
-};
-template <> struct Vec8<bf16_t> {
-    static __device__ __forceinline__ void load(const bf16_t* p, f32x4& a, f32x4& b) {
-        const bf16x8 t = *(const bf16x8*)p;
-        a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-        b = f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
-    }
-    static __device__ __forceinline__ void store(bf16_t* p, f32x4 a, f32x4 b) {
-        bf16x8 t;
-        t[0] = (bf16_t)a[0]; t[1] = (bf16_t)a[1]; t[2] = (bf16_t)a[2]; t[3] = (bf16_t)a[3];
-        t[4] = (bf16_t)b[0]; t[5] = (bf16_t)b[1]; t[6] = (bf16_t)b[2]; t[7] = (bf16_t)b[3];
-        *(bf16x8*)p = t;
-    }
-};
-
-// vector form of epilogue_store: 8 consecutive columns n..n+7 of logical row m_logical (all in range, all
-// row strides multiples of 8 elements)
-template <typename T>
-__device__ __forceinline__ void epilogue_store8(const umr_gemm_desc& p, int m_logical, int n, f32x4 v0, f32x4 v1) {
-    int m = m_logical;
-    if (p.c_rows_in > 0) m = (m_logical / p.c_rows_in) * p.c_rows_out + p.c_row_off + (m_logical % p.c_rows_in);
-    const int m_aux = p.aux_mod > 0 ? (m_logical % p.aux_mod) : m;
-    if (p.flags & UMR_EPI_BIAS) { v0 += *(const f32x4*)(p.bias + n); v1 += *(const f32x4*)(p.bias + n + 4); }
-    if (p.flags & UMR_EPI_ROWBIAS) {
-        const float* rb = p.rowbias + (int64_t)(m_logical / p.rows_per_batch) * p.N + n;
-        v0 += *(const f32x4*)rb; v1 += *(const f32x4*)(rb + 4);
-    }
-    if (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) {
-        f32x4 a0, a1;
-        Vec8<T>::load((const T*)p.aux + (int64_t)m_aux * p.ldaux + n, a0, a1);
-        if (p.flags & UMR_EPI_ADD_AUX) { v0 += a0; v1 += a1; }
-        else if (p.flags & UMR_EPI_MASK_RELU) {
-            for (int j = 0; j < 4; ++j) { v0[j] = a0[j] > 0.f ? v0[j] : 0.f; v1[j] = a1[j] > 0.f ? v1[j] : 0.f; }
-        } else {
-            for (int j = 0; j < 4; ++j) { v0[j] *= dgelu_erf(a0[j]); v1[j] *= dgelu_erf(a1[j]); }
-        }
-    }
-    if (p.flags & UMR_EPI_ADD_AUX2) {
-        f32x4 a0, a1;
-        Vec8<T>::load((const T*)p.aux2 + (int64_t)m * p.ldaux2 + n, a0, a1);
-        v0 += a0; v1 += a1;
-    }
-    if (p.c2_mode == 2) Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
-    if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); } }
-    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); } }
-    else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) { v0[j] = tanhf(v0[j]); v1[j] = tanhf(v1[j]); } }
-    if (p.flags & UMR_EPI_OUT_F32) Vec8<float>::store((float*)p.C + (int64_t)m * p.ldc + n, v0, v1);
-    else Vec8<T>::store((T*)p.C + (int64_t)m * p.ldc + n, v0, v1);
-    if (p.c2_mode == 1) {
-        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
-        Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
-    }
-}
 
 template <typename T, int CONV>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n) {
@@ -363,6 +248,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 
 }  // namespace
 
+int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
+
+static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("UMR_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     UMR_CHECK_ARG(d != nullptr, "gemm_nt: null descriptor");
     UMR_CHECK_ARG(d->A && d->B && d->C, "gemm_nt: null operand");
@@ -387,6 +283,13 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     UMR_CHECK_ARG(grid < (1ll << 31), "gemm_nt: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == UMR_BF16) {
+        const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
+        const int ov = tile_override();
+        const bool kfit = d->conv == 0 ? (d->K % 64 == 0) : (d->Cin % 64 == 0);  // the 256 kernel has no K-tail path
+        const bool big = kfit && d->N >= 192 && t256 >= 192;  // enough 256x256 tiles to occupy most CUs
+        if (kfit && (ov == 256 || (ov == 0 && big))) return umr_launch_gemm_nt256(d, s);
+    }
     dim3 g((unsigned)grid), b(256);
 #define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_nt_kernel<T, CV>), g, b, LDS_BYTES, s, *d, tiles_n)
     if (d->dtype == UMR_BF16) {

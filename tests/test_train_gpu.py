@@ -1,0 +1,116 @@
+"""Native TrainStep (fwd + fused loss + bwd + Adam, flat parameter buffer) against the oracle's
+autograd + Adam over several steps, and the extension configs' forward against the oracle."""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import objectness_oracle as orc
+from unmore_amd import synth
+from unmore_amd.hashrng import hash_init, uniform01
+
+pytestmark = pytest.mark.gpu
+ARGS = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+
+
+def _net(backbone, tag, dtype=torch.float32, args=ARGS):
+    from unmore_amd.objectness_net import ObjectnessNet
+    net = ObjectnessNet("cuda:0", 64, backbone, args)
+    sd = {k: torch.from_numpy(hash_init(k, tuple(v.shape), tag)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0")
+    net.set_compute_dtype(dtype)
+    return net, sd
+
+
+def test_trainstep_three_steps_match_oracle_fp32():
+    from unmore_amd.trainer import TrainStep
+    B, H, W = 2, 64, 96
+    net, sd = _net("dpt_tiny", "tiny")
+    img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(B, H, W, seed=3))
+    step = TrainStep(net, lr=1e-3, lr_milestones=(2,), lr_gamma=0.1)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v_ = {k: torch.zeros_like(v) for k, v in sd.items()}
+    lrs = [1e-3, 1e-3, 1e-4]  # MultiStepLR(milestones=[2], gamma=0.1), stepped per iteration
+    for it in range(3):
+        out5 = step.step(img.cuda(), cf.cuda(), sdf.cuda(), sal.cuda())
+        for t in sdo.values():
+            t.grad = None
+        loss_o, terms = orc.loss_terms(orc.forward(sdo, img, orc.CONFIGS["dpt_tiny"]), cf, sdf, sal)
+        loss_o.backward()
+        with torch.no_grad():
+            for k, t in sdo.items():
+                if t.grad is not None:
+                    orc.adam_update(t, t.grad, m[k], v_[k], it + 1, lr=lrs[it])
+        # losses track each other step after step (the trajectories only diverge through fp32 noise)
+        assert abs(out5[0].item() - loss_o.item()) < 2e-3 * max(1.0, abs(loss_o.item())), (it, out5[0].item(), loss_o.item())
+        for i, t in enumerate(terms):
+            assert abs(out5[1 + i].item() - t.item()) < 2e-3 * max(1.0, abs(t.item()))
+    assert step.iter == 3
+    # state_dict still has the reference schema and holds the updated weights
+    new_sd = net.state_dict()
+    assert list(new_sd.keys()) == list(sd.keys())
+    moved = sum(int((new_sd[k].cpu() != sd[k]).any()) for k in sd)
+    assert moved >= len(sd) - len(net.nograd_names())
+    for k in net.nograd_names():
+        assert torch.equal(new_sd[k].cpu(), sd[k])  # never updated, as in the reference
+
+
+def test_autograd_path_with_torch_optimizer_matches_trainstep():
+    """The drop-in path (loss.backward() + torch.optim.Adam, as train_objectness_net.py does) and the
+    native TrainStep produce the same weights after one step."""
+    from unmore_amd.loss import objectness_loss
+    from unmore_amd.trainer import TrainStep
+    B, H, W = 2, 64, 64
+    img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=4))
+    net_a, _ = _net("dpt_tiny", "tiny")
+    net_b, _ = _net("dpt_tiny", "tiny")
+    opt = torch.optim.Adam(net_a.parameters(), 1e-4)
+    opt.zero_grad()
+    objectness_loss(net_a(images=img), cf, sdf, sal).backward()
+    opt.step()
+    TrainStep(net_b, lr=1e-4).step(img, cf, sdf, sal)
+    for (n, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        torch.testing.assert_close(pa, pb, atol=2e-6, rtol=1e-5, msg=n)
+    # and the second forward of net_a sees the updated weights (packed-weight cache invalidation)
+    with torch.no_grad():
+        o1 = net_a(images=img)["sdf_maps"]
+        o2 = net_b(images=img)["sdf_maps"]
+    torch.testing.assert_close(o1, o2, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("backbone,H,W", [("dpt_small", 64, 96), ("dpt_large14", 70, 98)])
+def test_extension_configs_match_oracle_fp32(backbone, H, W):
+    """BASELINE.json extension configs: ViT-S/16 and the patch-14 wiring with odd grids
+    (fusion blocks upsample to the skip's size, final upsample to the input size)."""
+    net, sd = _net(backbone, backbone)
+    net.eval()
+    x = torch.from_numpy(uniform01(f"img:{backbone}", (1, 3, H, W)))
+    with torch.no_grad():
+        out = net(images=x.cuda())
+        ref = orc.forward(sd, x, orc.CONFIGS[backbone])
+    for k in ("center_fields", "sdf_maps"):
+        assert out[k].shape == ref[k].shape
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-4, rtol=0)
+
+
+def test_inference_crops_128_bf16_and_fp32_peaks():
+    """cfg5-style call: [<=50,3,128,128] crops under no_grad (object_reasoning.py:324-326); fp32 peak indices of the
+    anti-centre score map are identical to the oracle's on the same inputs (ties reported, not hidden)."""
+    net, sd = _net("dpt_tiny", "tiny")
+    net.eval()
+    B = 6
+    x = torch.from_numpy(uniform01("img:crops", (B, 3, 128, 128)))
+    with torch.no_grad():
+        out = net.get_prediction(x.cuda())
+        ref = orc.forward(sd, x, orc.CONFIGS["dpt_tiny"])
+    s_g, m_g, a_g = orc.peak_pick(out["sdf_maps"][:, 0].cpu(), out["center_fields"].cpu())
+    s_r, m_r, a_r = orc.peak_pick(ref["sdf_maps"][:, 0], ref["center_fields"])
+    for b in range(B):
+        if a_g[b] != a_r[b]:
+            # a flipped threshold / near-tie would show here: require the two candidates to be a genuine tie
+            gap = abs(s_r[b].flatten()[a_g[b]] - s_r[b].flatten()[a_r[b]]).item()
+            assert gap < 1e-6, f"image {b}: argmax {int(a_g[b])} vs {int(a_r[b])}, score gap {gap}"
+    torch.testing.assert_close(m_g, m_r, atol=1e-4, rtol=0)

@@ -287,7 +287,7 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
         const int ov = tile_override();
         const bool kfit = d->conv == 0 ? (d->K % 64 == 0) : (d->Cin % 64 == 0);  // the 256 kernel has no K-tail path
-        const bool big = kfit && d->N >= 192 && t256 >= 192;  // enough 256x256 tiles to occupy most CUs
+        const bool big = kfit && d->N >= 192 && t256 >= 2048;  // >= 8 full rounds of one 256x256 tile per CU (no tail, overheads amortised)
         if (kfit && (ov == 256 || (ov == 0 && big))) return umr_launch_gemm_nt256(d, s);
     }
     dim3 g((unsigned)grid), b(256);

@@ -26,6 +26,8 @@
 // phase's DMA issue and ds_reads.
 #include "umr_common.h"
 #include "gemm_epilogue.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -134,48 +136,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
     // (K % 64 == 0, resp. Cin % 64 == 0, is guaranteed by the dispatcher: no K-tail masking here)
 
     // staging cursor: groups are issued in the order A0,B0,B1,A1 of tile 0, then of tile 1, ...
-    int st_tile = 0, st_group = 0, st_tap = 0, st_ci = 0;
+    int st_tile = 0, st_tap = 0, st_ci = 0;
     unsigned soffA = 0, soffB = 0;
-    int st_c0 = 0;
-    auto stage_next = [&]() {
-        if (st_group == 0) {  // first group of a new tile: K offsets (and the halo mask when the tap changes)
-            if (CONV == 0) {
-                st_c0 = st_tile * BK2;
-                soffA = soffB = (unsigned)(st_c0 * SZ);
-            } else {
-                st_c0 = st_ci * BK2;
-                const int ky = st_tap / 3, kx = st_tap - ky * 3;
-                if (st_ci == 0) {
+    // called when group 0 (A0) of a new tile is about to be issued: K offsets, and the halo mask on a tap change
+    auto stage_prep = [&]() {
+        if (CONV == 0) {
+            soffA = soffB = (unsigned)(st_tile * BK2 * SZ);
+        } else {
+            const int c0 = st_ci * BK2;
+            const int ky = st_tap / 3, kx = st_tap - ky * 3;
+            if (st_ci == 0) {
 #pragma unroll
-                    for (int gi = 0; gi < 2; ++gi)
+                for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            a_eff[gi][i] = ((a_tapmask[gi][i] >> st_tap) & 1u) ? vo[gi == 0 ? 0 : 3][i] : OOB;
-                        }
-                }
-                soffA = (unsigned)(((ky * p.W + kx) * p.Cin + st_c0) * SZ);
-                soffB = (unsigned)((st_tap * p.Cin + st_c0) * SZ);
-                if (++st_ci == ktiles_per_tap) { st_ci = 0; ++st_tap; }
+                    for (int i = 0; i < 2; ++i)
+                        a_eff[gi][i] = ((a_tapmask[gi][i] >> st_tap) & 1u) ? vo[gi == 0 ? 0 : 3][i] : OOB;
             }
+            soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
+            soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
+            if (++st_ci == ktiles_per_tap) { st_ci = 0; ++st_tap; }
         }
-        const bool live = st_tile < nt;
-        char* dst = smem + (st_tile & 1) * BUF2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned v;
-            int row;
-            bool isA;
-            // st_group is wave-uniform; keep the four cases explicit so every index is a compile-time constant
-            if (st_group == 0) { v = a_eff[0][i]; row = lds_row[0][i]; isA = true; }
-            else if (st_group == 1) { v = vo[1][i]; row = lds_row[1][i]; isA = false; }
-            else if (st_group == 2) { v = vo[2][i]; row = lds_row[2][i]; isA = false; }
-            else { v = a_eff[1][i]; row = lds_row[3][i]; isA = true; }
-            if (!live) v = OOB;
-            if (isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, UMR_LDS_PTR(dst + row * ROWB2), 16, v, soffA, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, UMR_LDS_PTR(dst + TILE2 + row * ROWB2), 16, v, soffB, 0, 0);
-        }
-        if (++st_group == 4) { st_group = 0; ++st_tile; }
     };
+    // one LDS-DMA instruction (i = 0/1) of group G of the cursor's tile; G = 3 completes the tile
+    auto stage_issue = [&](auto gtag, auto itag) {
+        constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
+        unsigned v = (G == 0) ? a_eff[0][I] : (G == 3) ? a_eff[1][I] : vo[G][I];
+        if (st_tile >= nt) v = OOB;  // past the end: zero fill into a dead region, keeps the DMA count uniform
+        char* dst = smem + (st_tile & 1) * BUF2;
+        if (G == 0 || G == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, UMR_LDS_PTR(dst + lds_row[G][I] * ROWB2), 16, v, soffA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, UMR_LDS_PTR(dst + TILE2 + lds_row[G][I] * ROWB2), 16, v, soffB, 0, 0);
+        if (G == 3 && I == 1) ++st_tile;
+    };
+#define STAGE_DMA(G, I) stage_issue(std::integral_constant<int, G>{}, std::integral_constant<int, I>{})
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -200,15 +192,40 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
 
     bf16x8 fa[2][4], fb0[2][2], fb1[2][2];  // [ks][tile]: A of the current m-half, B(nh0), B(nh1)
 
+    // One phase = ds_reads, counted wait + barrier, then a 16-MFMA quadrant with this phase's two LDS-DMA
+    // instructions placed INSIDE the MFMA cluster (after 4 and after 10 MFMAs): the ~100-cycle DMA issue then
+    // hides behind matrix work that is already queued instead of stalling both waves of a SIMD at once.
+    // At the wait, the groups issued in earlier phases number "all but this phase's", so vmcnt(6) leaves the
+    // three youngest groups in flight -- the same lead as issuing before the wait with vmcnt(8).
 #define PHASE_SYNC()                                               \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
     __builtin_amdgcn_s_barrier();                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
     __builtin_amdgcn_sched_barrier(0);
+#define MFMA(ACC, BF, AF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF, AF, ACC, 0, 0, 0)
+    // quadrant (M0 = first m-tile of the acc block, N0 = first n-tile), B fragments FB, staging group G
+#define QUADRANT(M0, N0, FB, G)                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(G, 0);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 2][N0 + 0], FB[0][0], fa[0][2]); MFMA(acc[M0 + 2][N0 + 1], FB[0][1], fa[0][2]);   \
+    MFMA(acc[M0 + 3][N0 + 0], FB[0][0], fa[0][3]); MFMA(acc[M0 + 3][N0 + 1], FB[0][1], fa[0][3]);   \
+    MFMA(acc[M0 + 0][N0 + 0], FB[1][0], fa[1][0]); MFMA(acc[M0 + 0][N0 + 1], FB[1][1], fa[1][0]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(G, 1);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
+    MFMA(acc[M0 + 2][N0 + 0], FB[1][0], fa[1][2]); MFMA(acc[M0 + 2][N0 + 1], FB[1][1], fa[1][2]);   \
+    MFMA(acc[M0 + 3][N0 + 0], FB[1][0], fa[1][3]); MFMA(acc[M0 + 3][N0 + 1], FB[1][1], fa[1][3]);   \
+    __builtin_amdgcn_s_setprio(0);
 
+    // With 6 groups pre-issued, phase p of tile t issues group (6 + 4t + p) % 4 of tile (6 + 4t + p) / 4:
+    //   Q0 -> B1(t+1), Q1 -> A1(t+1), Q2 -> A0(t+2), Q3 -> B0(t+2)   (the table in the header)
     auto tile_body = [&](const char* sbuf) {
-        // ---- phase 0: Q0
-        stage_next();
+        // ---- phase 0: Q0 = (mh0, nh0)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -217,74 +234,43 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
         }
         PHASE_SYNC();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[mt][nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ks][nl], fa[ks][mt], acc[mt][nl], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 1: Q1
-        stage_next();
+        QUADRANT(0, 0, fb0, 2)
+        // ---- phase 1: Q1 = (mh0, nh1)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
         PHASE_SYNC();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[mt][2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ks][nl], fa[ks][mt], acc[mt][2 + nl], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 2: Q2
-        stage_next();
+        QUADRANT(0, 2, fb1, 3)
+        // ---- phase 2: Q2 = (mh1, nh1)
+        stage_prep();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
         PHASE_SYNC();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[4 + mt][2 + nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[ks][nl], fa[ks][mt], acc[4 + mt][2 + nl], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 3: Q3
-        stage_next();
+        QUADRANT(4, 2, fb1, 0)
+        // ---- phase 3: Q3 = (mh1, nh0)
         PHASE_SYNC();
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nl = 0; nl < 2; ++nl)
-                    acc[4 + mt][nl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[ks][nl], fa[ks][mt], acc[4 + mt][nl], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        QUADRANT(4, 0, fb0, 1)
     };
 
-    // prologue: the six groups that the steady-state schedule has already issued when tile 0 starts
-    // (A0,B0,B1,A1 of tile 0 and A0,B0 of tile 1), then make A0(0),B0(0) visible.
-#pragma unroll 1
-    for (int i = 0; i < 6; ++i) stage_next();
+    // prologue: the six groups the steady-state schedule has already issued when tile 0 starts
+    // (A0,B0,B1,A1 of tile 0; A0,B0 of tile 1), then make A0(0), B0(0) visible.
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // NOTE on the staging order inside a tile: phase 0 issues B1 of the next-but-one... the cursor simply
-    // continues the global sequence A0,B0,B1,A1,A0,... ; with 6 groups pre-issued, phase p of tile t issues
-    // group (6 + 4t + p): (t,0)->B1(t+1), (t,1)->A1(t+1), (t,2)->A0(t+2), (t,3)->B0(t+2)  == the table above.
 #pragma unroll 1
     for (int t = 0; t < nt; ++t) tile_body(smem + (t & 1) * BUF2);
+#undef QUADRANT
+#undef MFMA
 #undef PHASE_SYNC
+#undef STAGE_DMA
 #undef A_FRAG
 #undef B_FRAG
 
@@ -329,16 +315,16 @@ int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     dim3 g((unsigned)grid), b(512);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        attr_set = true;
-    }
-    if (d->conv == 0) hipLaunchKernelGGL(gemm_nt256_kernel<0>, g, b, LDS2, s, *d, tiles_n);
-    else if (d->conv == 1) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g, b, LDS2, s, *d, tiles_n);
-    else hipLaunchKernelGGL(gemm_nt256_kernel<2>, g, b, LDS2, s, *d, tiles_n);
+#define L256(CV)                                                                                                       \
+    do {                                                                                                               \
+        static bool set_ = false;                                                                                      \
+        if (!set_) { hipFuncSetAttribute((const void*)gemm_nt256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2); set_ = true; } \
+        hipLaunchKernelGGL((gemm_nt256_kernel<CV>), g, b, LDS2, s, *d, tiles_n);                                        \
+    } while (0)
+    if (d->conv == 0) L256(0);
+    else if (d->conv == 1) L256(1);
+    else L256(2);
+#undef L256
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

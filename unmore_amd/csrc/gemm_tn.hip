@@ -14,6 +14,7 @@
 // dbias rides along on workgroups with k-tile 0: one extra MFMA against an all-ones
 // fragment per n-tile and k-step.
 #include "umr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -298,10 +299,33 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restri
     }
 }
 
-struct TnPlan { int tiles_n, tiles_k, splits, rows_per_split; int64_t ws; };
+struct TnPlan { int tiles_n, tiles_k, splits, rows_per_split; int64_t ws; bool big; };
+
+}  // namespace
+bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force);                                                  // gemm_tn256.hip
+void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split);
+int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s);
+namespace {
+
+static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("UMR_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 
 TnPlan tn_plan(const umr_gemm_tn_desc* d) {
     TnPlan pl;
+    pl.big = tn_tile_override() != 128 && umr_tn256_eligible(d, tn_tile_override() == 256);
+    if (pl.big) {
+        pl.tiles_n = (d->N + 255) / 256;
+        pl.tiles_k = (d->K + 255) / 256;
+        umr_tn256_plan(d, &pl.splits, &pl.rows_per_split);
+        pl.ws = ((int64_t)pl.splits * d->N * d->K + (int64_t)pl.splits * d->N) * 4;
+        return pl;
+    }
     pl.tiles_n = (d->N + TN_BN - 1) / TN_BN;
     pl.tiles_k = (d->K + TN_BK - 1) / TN_BK;
     const int64_t tiles = (int64_t)pl.tiles_n * pl.tiles_k;
@@ -362,6 +386,10 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)d->workspace;
     float* bslab = slab + (int64_t)pl.splits * d->N * d->K;
+    if (pl.big) {
+        const int st = umr_launch_gemm_tn256(d, pl.splits, pl.rows_per_split, slab, bslab, s);
+        if (st != UMR_OK) return st;
+    } else {
     dim3 g((unsigned)(pl.tiles_n * pl.tiles_k), (unsigned)pl.splits), b(256);
 #define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_tn_kernel<T, CV>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
     if (d->dtype == UMR_BF16) {
@@ -371,6 +399,7 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     }
 #undef LAUNCH
     UMR_LAUNCH_CHECK();
+    }
     const int64_t total = (int64_t)d->N * d->K;
     int rb = (int)((total + 255) / 256);
     if (rb > 4096) rb = 4096;

@@ -1,0 +1,318 @@
+// 256x256-tile weight-gradient GEMM ("TN") for bf16: the throughput path of umr_gemm_tn.
+//   dW[N,K] (f32 slabs) = sum_m dY[m,N]^T . X[m,K]        (+ dbias[N])
+// Same software pipeline as gemm_nt256.hip (4 phases per 64-row stage, one 16-MFMA 64x32 quadrant each, LDS-DMA
+// groups issued two stages ahead inside the MFMA clusters, counted vmcnt, one raw barrier per phase), with the
+// TN specifics of gemm_tn.hip: operands are staged as they lie in memory ([rows m][columns]) and transposed on
+// the LDS->register path by ds_read_b64_tr_b16.
+//
+// Geometry: 8 waves as 2 (n) x 4 (k); a wave owns 128 n x 64 k = 8 x 4 MFMA tiles.  A stage is 64 rows of m.
+// LDS per stage: four 16-KiB sub-tiles [64 rows][128 columns] (256-B rows, chunk XOR as gemm_tn.hip):
+//     Y0 / Y1 : dY columns of n-half 0 / 1 of both wave rows   (column c' = wn*64 + n_local)
+//     X0 / X1 : X  columns of k-half 0 / 1 of the four wave columns (c' = wk*32 + k_local)
+// which are exactly the read sets of the quadrants Q0=(nh0,kh0) Q1=(nh0,kh1) Q2=(nh1,kh1) Q3=(nh1,kh0), so the
+// staging table of gemm_nt256.hip applies verbatim with A -> Y and B -> X.
+// Descriptor bases move with the stage (scalar arithmetic); per-lane voffsets are loop constants; the conv fast
+// path (stride 1, Wo % 64 == 0: a stage lies inside one image row) masks halo lanes once per stage.
+// Row tails of the split fall out of num_records (plain) and cannot occur on the conv fast path.
+// dbias: workgroups of k-tile 0 add up their dY fragments on the VALU (one f32 per n-tile and lane).
+#include "umr_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int TSUB = 64 * 256;       // 16 KiB sub-tile
+constexpr int TBUF = 4 * TSUB;       // 64 KiB per stage: Y0, X0, X1, Y1
+constexpr int TLDS = 2 * TBUF;       // 128 KiB
+
+__device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+// sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
+template <int CONV>
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int rows_per_split, float* slab,
+                                                            float* bslab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SZ = 2;
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    const int n0 = tn * 256, k0 = tk * 256;
+    const int m_begin = split * rows_per_split;
+    const int m_end = min(p.M, m_begin + rows_per_split);
+    const int nst = (m_end - m_begin + 63) / 64;
+    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+
+    // ---- staging roles: instruction i (0/1) of wave w covers sub-tile rows (w*2+i)*4 + lane/16, chunk position lane%16
+    unsigned vo[4][2];      // per-lane voffsets (or OOB) of the four groups, relative to the stage's descriptor bases
+    unsigned x_eff[2][2];   // conv: X groups after the per-stage halo mask
+    int x_r[2][2], x_t[2][2];  // conv: row within the stage, packed tap offsets (tky+1) | (tkx+1) << 2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (w * 2 + i) * 4 + (lane >> 4);
+        const int gch = (lane & 15) ^ tn_swz2(r);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // Y_h: chunk gch -> stripe (wave row) gch>>3, 8-column chunk gch&7
+            const int ncol = n0 + (gch >> 3) * 128 + h * 64 + (gch & 7) * 8;
+            vo[h == 0 ? 0 : 3][i] = (ncol < p.N) ? (unsigned)(((int64_t)r * p.lddy + (ncol - n0)) * SZ) : OOB;
+            // X_h: stripe (wave column) gch>>2, chunk gch&3
+            const int kcol = k0 + (gch >> 2) * 64 + h * 32 + (gch & 3) * 8;
+            unsigned v = OOB;
+            x_r[h][i] = r;
+            x_t[h][i] = 0;
+            if (kcol < p.K) {
+                if (CONV == 0) {
+                    v = (unsigned)(((int64_t)r * p.ldx + (kcol - k0)) * SZ);
+                } else {
+                    const int tap = kcol / p.Cin, ci = kcol - tap * p.Cin;
+                    const int ky = tap / 3, kx = tap - ky * 3;  // offsets ky-1, kx-1 relative to the output pixel
+                    x_t[h][i] = ky | (kx << 2);
+                    v = (unsigned)(((int64_t)(r + ky * p.W + kx) * p.Cin + ci) * SZ);
+                }
+            }
+            vo[1 + h][i] = v;
+            x_eff[h][i] = v;
+        }
+    }
+
+    // ---- stage cursor (groups are issued Y0,X0,X1,Y1 of stage 0, then of stage 1, ...)
+    int st_tile = 0;
+    int sb = 0, soy = 0, sox = 0;  // conv: pixel position of the cursor stage's first row
+    if (CONV != 0) {
+        const int hw = p.Ho * p.Wo;
+        sb = m_begin / hw;
+        const int rem = m_begin - sb * hw;
+        soy = rem / p.Wo;
+        sox = rem - soy * p.Wo;
+    }
+    __amdgpu_buffer_rsrc_t rsY, rsX;
+    auto stage_prep = [&]() {
+        const int mbase = m_begin + st_tile * 64;
+        int rows_left = m_end - mbase;
+        rows_left = rows_left < 0 ? 0 : (rows_left > 64 ? 64 : rows_left);
+        const char* yb = (const char*)p.dY + ((int64_t)mbase * p.lddy + n0) * SZ;
+        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)(rows_left * p.lddy * SZ), 0x00020000);
+        if (CONV == 0) {
+            const char* xb = (const char*)p.X + ((int64_t)mbase * p.ldx + k0) * SZ;
+            rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(rows_left * p.ldx * SZ), 0x00020000);
+        } else {
+            const char* xb = (const char*)p.X + ((((int64_t)sb * p.H + soy) * p.W + sox) - (p.W + 1)) * p.Cin * SZ;
+            rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, rows_left > 0 ? 0x7FFFFFFFu : 0u, 0x00020000);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int ky = x_t[h][i] & 3, kx = x_t[h][i] >> 2;
+                    const bool ok = (unsigned)(soy + ky - 1) < (unsigned)p.H && (unsigned)(sox + x_r[h][i] + kx - 1) < (unsigned)p.W;
+                    x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
+                }
+            sox += 64;
+            if (sox >= p.Wo) { sox = 0; if (++soy >= p.Ho) { soy = 0; ++sb; } }
+        }
+    };
+    auto stage_issue = [&](auto gtag, auto itag) {
+        constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
+        char* dst = smem + (st_tile & 1) * TBUF + G * TSUB + (w * 2 + I) * 1024;
+        if (G == 0 || G == 3) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], 0, 0, 0);
+        } else {
+            const unsigned v = (CONV == 0) ? vo[G][I] : x_eff[G - 1][I];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(dst), 16, v, 0, 0, 0);
+        }
+        if (G == 3 && I == 1) ++st_tile;
+    };
+#define STAGE_DMA(G, I) stage_issue(std::integral_constant<int, G>{}, std::integral_constant<int, I>{})
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bsum[i] = 0.f;
+
+    const int wn = w >> 2, wk = w & 3;
+    const int g = lane >> 4, li = lane & 15;
+    const int q = li >> 2, pp = li & 3;
+    // transposed-read addresses.  Block row r = ks*32 + g*8 + half*4 + q; swizzle key = (q<<2) | ((2g+half)&3); the
+    // 16-column tile t of a wave starts at chunk cbase + 2t.  One base per (tile, half); ks adds 32 rows (+8192 B).
+    int y_ad[4][2], x_ad[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int r = g * 8 + half * 4 + q;
+        const int sw = tn_swz2(r);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = wn * 8 + 2 * t + (pp >> 1);
+            y_ad[t][half] = r * 256 + ((c ^ sw) << 4) + ((pp & 1) << 3);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int c = wk * 4 + 2 * t + (pp >> 1);
+            x_ad[t][half] = r * 256 + ((c ^ sw) << 4) + ((pp & 1) << 3);
+        }
+    }
+    // (ks*32 rows keep the swizzle key: (32>>2)&3 == 0 and 32&3 == 0)
+#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
+    auto read_frag = [&](const char* sub, int ad0, int ad1, int ks) -> bf16x8 {
+        const bf16x4 v0 = TR_READ(sub + ad0 + ks * 8192), v1 = TR_READ(sub + ad1 + ks * 8192);
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; }
+        return f;
+    };
+
+    bf16x8 fy[2][4], fx0[2][2], fx1[2][2];  // [ks][tile]: dY of the current n-half, X(kh0), X(kh1)
+
+#define PHASE_SYNC()                                               \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
+    __builtin_amdgcn_s_barrier();                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);
+    // D[i = k_local][j = n_local] = sum_m X[m,k] dY[m,n]: first operand = X fragment, second = dY fragment
+#define MFMA(ACC, XF, YF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XF, YF, ACC, 0, 0, 0)
+#define QUADRANT(N0, K0, FX, G)                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    MFMA(acc[N0 + 0][K0 + 0], FX[0][0], fy[0][0]); MFMA(acc[N0 + 0][K0 + 1], FX[0][1], fy[0][0]);   \
+    MFMA(acc[N0 + 1][K0 + 0], FX[0][0], fy[0][1]); MFMA(acc[N0 + 1][K0 + 1], FX[0][1], fy[0][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(G, 0);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[N0 + 2][K0 + 0], FX[0][0], fy[0][2]); MFMA(acc[N0 + 2][K0 + 1], FX[0][1], fy[0][2]);   \
+    MFMA(acc[N0 + 3][K0 + 0], FX[0][0], fy[0][3]); MFMA(acc[N0 + 3][K0 + 1], FX[0][1], fy[0][3]);   \
+    MFMA(acc[N0 + 0][K0 + 0], FX[1][0], fy[1][0]); MFMA(acc[N0 + 0][K0 + 1], FX[1][1], fy[1][0]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(G, 1);                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[N0 + 1][K0 + 0], FX[1][0], fy[1][1]); MFMA(acc[N0 + 1][K0 + 1], FX[1][1], fy[1][1]);   \
+    MFMA(acc[N0 + 2][K0 + 0], FX[1][0], fy[1][2]); MFMA(acc[N0 + 2][K0 + 1], FX[1][1], fy[1][2]);   \
+    MFMA(acc[N0 + 3][K0 + 0], FX[1][0], fy[1][3]); MFMA(acc[N0 + 3][K0 + 1], FX[1][1], fy[1][3]);   \
+    __builtin_amdgcn_s_setprio(0);
+#define BIAS_ACC(N0)                                                                                \
+    if (do_bias && wk == 0) {                                                                       \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
+            float s_ = 0.f;                                                                         \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) s_ += (float)fy[ks][t][e];            \
+            bsum[N0 + t] += s_;                                                                     \
+        }                                                                                           \
+    }
+
+    auto stage_body = [&](const char* sbuf) {
+        // ---- phase 0: Q0 = (nh0, kh0)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fx0[ks][t] = read_frag(sbuf + 1 * TSUB, x_ad[t][0], x_ad[t][1], ks);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fy[ks][t] = read_frag(sbuf + 0 * TSUB, y_ad[t][0], y_ad[t][1], ks);
+        }
+        PHASE_SYNC();
+        BIAS_ACC(0)
+        QUADRANT(0, 0, fx0, 2)
+        // ---- phase 1: Q1 = (nh0, kh1)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) fx1[ks][t] = read_frag(sbuf + 2 * TSUB, x_ad[t][0], x_ad[t][1], ks);
+        PHASE_SYNC();
+        QUADRANT(0, 2, fx1, 3)
+        // ---- phase 2: Q2 = (nh1, kh1)
+        stage_prep();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) fy[ks][t] = read_frag(sbuf + 3 * TSUB, y_ad[t][0], y_ad[t][1], ks);
+        PHASE_SYNC();
+        BIAS_ACC(4)
+        QUADRANT(4, 2, fx1, 0)
+        // ---- phase 3: Q3 = (nh1, kh0)
+        PHASE_SYNC();
+        QUADRANT(4, 0, fx0, 1)
+    };
+
+    // prologue: Y0,X0,X1,Y1 of stage 0 and Y0,X0 of stage 1
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#pragma unroll 1
+    for (int t = 0; t < nst; ++t) stage_body(smem + (t & 1) * TBUF);
+#undef BIAS_ACC
+#undef QUADRANT
+#undef MFMA
+#undef PHASE_SYNC
+#undef STAGE_DMA
+#undef TR_READ
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- results: lane holds n = li, k = 4*g + reg of each tile
+    float* out = slab + (int64_t)split * p.N * p.K;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const int n = n0 + wn * 128 + nt * 16 + li;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + g * 4;
+            if (k >= p.K) continue;
+            float* o = out + (int64_t)n * p.K + k;
+            if (k + 3 < p.K && (p.K & 3) == 0) *(f32x4*)o = acc[nt][kt];
+            else { for (int e = 0; e < 4; ++e) if (k + e < p.K) o[e] = acc[nt][kt][e]; }
+        }
+        if (do_bias && wk == 0) {
+            float s_ = bsum[nt];
+            s_ += __shfl_xor(s_, 16, 64);
+            s_ += __shfl_xor(s_, 32, 64);
+            if (g == 0) bslab[(int64_t)split * p.N + n] = s_;
+        }
+    }
+}
+
+}  // namespace
+
+// plan shared with gemm_tn.hip through these two helpers
+bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force) {
+    if (d->dtype != UMR_BF16) return false;
+    if (d->dy_rows_in > 0 || d->x_rows_in > 0) return false;
+    if (d->conv == 2) return false;
+    if (d->conv == 1 && (d->Wo % 64) != 0) return false;
+    if (force) return true;  // structurally supported (tails are masked); the rest is a performance heuristic
+    if (d->N < 192 || d->K < 192) return false;
+    const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);
+    // enough rows that >= ~1000 workgroups of >= 16 stages exist
+    return (int64_t)d->M >= 1024 * 64 * 16 / (tiles < 1 ? 1 : tiles) && d->M >= 64 * 64;
+}
+
+void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split) {
+    const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);
+    int64_t want = 1024 / tiles;  // ~4 rounds of one workgroup per CU
+    if (want < 1) want = 1;
+    const int64_t max_by_rows = ((int64_t)d->M + 64 * 16 - 1) / (64 * 16);
+    if (want > max_by_rows) want = max_by_rows;
+    int64_t rps = ((int64_t)d->M + want - 1) / want;
+    rps = (rps + 63) / 64 * 64;
+    *rows_per_split = (int)rps;
+    *splits = (int)(((int64_t)d->M + rps - 1) / rps);
+}
+
+int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s) {
+    const int tiles_n = (d->N + 255) / 256, tiles_k = (d->K + 255) / 256;
+    dim3 g((unsigned)(tiles_n * tiles_k), (unsigned)splits), b(512);
+#define LT(CV)                                                                                                         \
+    do {                                                                                                               \
+        static bool set_ = false;                                                                                      \
+        if (!set_) { hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS); set_ = true; } \
+        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, rows_per_split, slab, bslab);            \
+    } while (0)
+    if (d->conv == 0) LT(0); else LT(1);
+#undef LT
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -28,14 +28,22 @@ __device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2
 
 // sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
 template <int CONV>
-__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int rows_per_split, float* slab,
-                                                            float* bslab) {
+__global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int ntiles, int rows_per_split,
+                                                            float* slab, float* bslab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
     constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x, split = blockIdx.y;
+    // 1-D grid, XCD-aware bijective remap: the workgroups that share an XCD (id % 8) take a contiguous run of
+    // (split, tile) pairs, so the tiles of one split -- which all stream the same dY / X rows -- share one L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q_ = nwg >> 3, r_ = nwg & 7;
+        const int base = (xcd < r_) ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+        bid = base + (bid >> 3);
+    }
+    const int split = bid / ntiles, tile = bid - split * ntiles;
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * 256, k0 = tk * 256;
     const int m_begin = split * rows_per_split;
@@ -304,12 +312,12 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
 
 int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s) {
     const int tiles_n = (d->N + 255) / 256, tiles_k = (d->K + 255) / 256;
-    dim3 g((unsigned)(tiles_n * tiles_k), (unsigned)splits), b(512);
+    dim3 g((unsigned)(tiles_n * tiles_k * splits)), b(512);
 #define LT(CV)                                                                                                         \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
         if (!set_) { hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS); set_ = true; } \
-        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, rows_per_split, slab, bslab);            \
+        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab);            \
     } while (0)
     if (d->conv == 0) LT(0); else LT(1);
 #undef LT

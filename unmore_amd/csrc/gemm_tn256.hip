@@ -17,6 +17,7 @@
 // dbias: workgroups of k-tile 0 add up their dY fragments on the VALU (one f32 per n-tile and lane).
 #include "umr_common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -29,7 +30,7 @@ __device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2
 // sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
 template <int CONV>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int ntiles, int rows_per_split,
-                                                            float* slab, float* bslab) {
+                                                            float* slab, float* bslab, int mapmode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
     constexpr unsigned OOB = 0x80000000u;
@@ -62,10 +63,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // Y_h: chunk gch -> stripe (wave row) gch>>3, 8-column chunk gch&7
-            const int ncol = n0 + (gch >> 3) * 128 + h * 64 + (gch & 7) * 8;
+            const int ncol = (mapmode & 2) ? n0 + h * 128 + gch * 8 : n0 + (gch >> 3) * 128 + h * 64 + (gch & 7) * 8;
             vo[h == 0 ? 0 : 3][i] = (ncol < p.N) ? (unsigned)(((int64_t)r * p.lddy + (ncol - n0)) * SZ) : OOB;
             // X_h: stripe (wave column) gch>>2, chunk gch&3
-            const int kcol = k0 + (gch >> 2) * 64 + h * 32 + (gch & 3) * 8;
+            const int kcol = (mapmode & 1) ? k0 + h * 128 + gch * 8 : k0 + (gch >> 2) * 64 + h * 32 + (gch & 3) * 8;
             unsigned v = OOB;
             x_r[h][i] = r;
             x_t[h][i] = 0;
@@ -264,11 +265,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     float* out = slab + (int64_t)split * p.N * p.K;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-        const int n = n0 + wn * 128 + nt * 16 + li;
+        const int n = (mapmode & 2) ? n0 + (nt >> 2) * 128 + wn * 64 + (nt & 3) * 16 + li : n0 + wn * 128 + nt * 16 + li;
         if (n >= p.N) continue;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const int k = k0 + wk * 64 + kt * 16 + g * 4;
+            const int k = (mapmode & 1) ? k0 + (kt >> 1) * 128 + wk * 32 + (kt & 1) * 16 + g * 4 : k0 + wk * 64 + kt * 16 + g * 4;
             if (k >= p.K) continue;
             float* o = out + (int64_t)n * p.K + k;
             if (k + 3 < p.K && (p.K & 3) == 0) *(f32x4*)o = acc[nt][kt];
@@ -313,11 +314,13 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
 int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s) {
     const int tiles_n = (d->N + 255) / 256, tiles_k = (d->K + 255) / 256;
     dim3 g((unsigned)(tiles_n * tiles_k * splits)), b(512);
+    static int mapmode = -1;
+    if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 2; }
 #define LT(CV)                                                                                                         \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
         if (!set_) { hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS); set_ = true; } \
-        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab);            \
+        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);            \
     } while (0)
     if (d->conv == 0) LT(0); else LT(1);
 #undef LT

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         } else {
             c0 = st_ci * BK;
             const int ky = st_tap / 3, kx = st_tap - ky * 3;
-            if (st_ci == 0) {  // new tap: which of this lane's rows fall inside the image
+            {   // the tap changes every K-tile (channel-chunk-major order): rows of this lane inside the image
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ok = (unsigned)(a_y[i] + ky) < (unsigned)p.H && (unsigned)(a_x[i] + kx) < (unsigned)p.W;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
             }
             soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
             soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
-            if (++st_ci == ktiles_per_tap) { st_ci = 0; ++st_tap; }
+            if (++st_tap == 9) { st_tap = 0; ++st_ci; }
         }
         const int klim = (CONV == 0) ? p.K : p.Cin;
 #pragma unroll

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
         } else {
             const int c0 = st_ci * BK2;
             const int ky = st_tap / 3, kx = st_tap - ky * 3;
-            if (st_ci == 0) {
+            {   // the tap changes every K-tile (channel-chunk-major order)
 #pragma unroll
                 for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
             }
             soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
             soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
-            if (++st_ci == ktiles_per_tap) { st_ci = 0; ++st_tap; }
+            if (++st_tap == 9) { st_tap = 0; ++st_ci; }
         }
     };
     // one LDS-DMA instruction (i = 0/1) of group G of the cursor's tile; G = 3 completes the tile

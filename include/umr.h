@@ -149,6 +149,20 @@ int umr_objectness_loss(const float* pred_center, const float* pred_sdf, const f
 int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   int step, float grad_scale, umr_stream_t stream);
 
+/* ---- object-reasoning glue around the net ("next" rows f1/f2) -----------------------
+ * crop_resize: proposal crops [x1,y1,x2,y2) of a [3,H,W] f32 image -> [N,3,S,S], bilinear, no antialias
+ *   (object_reasoning.py:311-323,398-410: torchvision Resize on tensors == F.interpolate(align_corners=False)).
+ * center_peaks: union mask (sigmoid(sdf)>0.5 | ||center||>0.5), `erode_rounds` x (k x k) erosion, float64 5x5
+ *   anti-centre correlation / 24, zero `border`, per-map max and FIRST flat argmax
+ *   (object_reasoning.py:360-377,528-550; utils/misc.py:10-20).  filter50 = the 2x5x5 float64 taps (device).
+ *   score_out may be NULL.  Maps up to H*W = 76,800 pixels.
+ * boundary_deltas: [delta_x1, delta_y1, delta_x2, delta_y2] per map (object_reasoning.py:139-174). */
+int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* out, int N, int H, int W, int S, umr_stream_t stream);
+int umr_center_peaks(const float* sdf_maps, const float* center_fields, const double* filter50, double* score_out,
+                     double* max_values, int64_t* argmax, int B, int H, int W, int border, int erode_kernel, int erode_rounds,
+                     umr_stream_t stream);
+int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -423,3 +423,33 @@ def peak_pick(sdf_maps, center_fields, border=10):
     B = score.shape[0]
     flat = score.reshape(B, -1)
     return score, flat.amax(dim=1), flat.argmax(dim=1)
+
+
+def crop_resize(image, boxes, size=128):
+    """object_reasoning.py:311-323: per box floor/ceil, crop, torchvision tensor Resize((size,size), BILINEAR)
+    (torchvision 0.14: no antialias == F.interpolate(mode='bilinear', align_corners=False))."""
+    outs = []
+    for box in boxes:
+        x1, y1, x2, y2 = [float(v) for v in box]
+        x1, y1, x2, y2 = int(math.floor(x1)), int(math.floor(y1)), int(math.ceil(x2)), int(math.ceil(y2))
+        crop = image[:, y1:y2, x1:x2]
+        outs.append(F.interpolate(crop[None], size=(size, size), mode="bilinear", align_corners=False)[0])
+    return torch.stack(outs, 0)
+
+
+def update_bbox_with_boundary_fields(sdf_maps):
+    """object_reasoning.py:139-174 (image_gradients restated as above)."""
+    dy, dx = image_gradients(sdf_maps.unsqueeze(1))
+    g = torch.cat((dy, dx), dim=1)[:, :, 0:-1, 0:-1]
+    s = sdf_maps[:, 0:-1, 0:-1]
+    gn = torch.norm(g, dim=1)
+    fg = torch.sigmoid(s)
+    bg = 1 - fg
+    avg_fg = (fg * gn).sum(-1).sum(-1) / (fg.sum(-1).sum(-1) + 1e-8)
+    avg_bg = (bg * gn).sum(-1).sum(-1) / (bg.sum(-1).sum(-1) + 1e-8)
+    step_fg = 1 / (avg_fg + 1e-10)
+    step_bg = 1 / (avg_bg + 1e-10)
+    step = step_fg[:, None, None] * fg + step_bg[:, None, None] * bg
+    mv = step * s
+    return (-torch.amax(mv[:, :, 0], dim=1), -torch.amax(mv[:, 0, :], dim=1), torch.amax(mv[:, :, -1], dim=1),
+            torch.amax(mv[:, -1, :], dim=1))

@@ -1,0 +1,94 @@
+"""f1/f2 rows: crop+resize, centre peak picking (bit-exact integer results) and boundary deltas vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import objectness_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(B, H, W, seed):
+    """smooth, object-like fields so the masks have structure (random noise would erode to nothing)."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    sdf = torch.zeros(B, H, W)
+    cen = torch.zeros(B, 2, H, W)
+    for b in range(B):
+        for _ in range(2):
+            cy, cx = (0.25 + 0.5 * torch.rand(2, generator=g)) * torch.tensor([H, W])
+            r = (0.15 + 0.2 * torch.rand(1, generator=g)) * min(H, W)
+            d = torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+            sdf[b] = torch.maximum(sdf[b], torch.tanh((r - d) / 8))
+            inside = d < r
+            n = d + 1e-6
+            sign = -1.0 if b % 2 == 0 else 1.0  # converging fields give positive anti-centre peaks, diverging ones none
+            cen[b, 0] = torch.where(inside, sign * (yy - cy) / n, cen[b, 0])
+            cen[b, 1] = torch.where(inside, sign * (xx - cx) / n, cen[b, 1])
+        sdf[b] = sdf[b] * 2 - 0.3
+    sdf += 0.05 * torch.randn(B, H, W, generator=g)
+    cen += 0.05 * torch.randn(B, 2, H, W, generator=g)
+    return sdf, cen
+
+
+@pytest.mark.parametrize("B,H,W", [(5, 128, 128), (3, 96, 160)])
+def test_center_peaks_bit_exact(B, H, W):
+    from unmore_amd import reasoning
+    sdf, cen = _fields(B, H, W, 0)
+    score_r, max_r, arg_r = orc.peak_pick(sdf, cen)
+    mx, am, sc = reasoning.center_peaks(sdf.cuda(), cen.cuda(), return_scores=True)
+    mx, am, sc = mx.cpu(), am.cpu(), sc.cpu()
+    # the integer side (masks, erosion, border) is exact: identical support of the score map
+    assert torch.equal(sc != 0, score_r != 0)
+    torch.testing.assert_close(sc, score_r, atol=1e-12, rtol=0)
+    assert (max_r > 0).any(), "fixture has no peak: test would be vacuous"
+    for b in range(B):
+        if am[b] != arg_r[b]:  # only a genuine float64 tie may differ; report it
+            gap = abs(score_r[b].flatten()[am[b]] - score_r[b].flatten()[arg_r[b]]).item()
+            assert gap < 1e-13, f"map {b}: argmax {int(am[b])} vs {int(arg_r[b])} gap {gap}"
+    assert torch.equal(am, arg_r)
+    torch.testing.assert_close(mx, max_r, atol=1e-12, rtol=0)
+
+
+def test_boundary_deltas():
+    from unmore_amd import reasoning
+    sdf, _ = _fields(6, 128, 128, 1)
+    ref = orc.update_bbox_with_boundary_fields(sdf)
+    out = reasoning.update_bbox_with_boundary_fields(sdf.cuda())
+    for a, b in zip(out, ref):
+        torch.testing.assert_close(a.cpu(), b, atol=1e-4, rtol=1e-4)
+
+
+def test_crop_resize_matches_torchvision_semantics():
+    from unmore_amd import reasoning
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(3, 480, 640, generator=g)
+    boxes = torch.tensor([[0.0, 0.0, 640.0, 480.0], [10.3, 20.7, 200.2, 150.9], [300.0, 100.0, 340.5, 460.0], [600.2, 400.1, 640.0, 480.0],
+                          [5.0, 5.0, 9.0, 8.0]])
+    ref = orc.crop_resize(img, boxes, 128)
+    out, on_edge = reasoning.crop_resize(img.cuda(), boxes, 128)
+    torch.testing.assert_close(out.cpu(), ref, atol=2e-6, rtol=0)
+    assert on_edge[0].tolist() == [True, True, True, True] and on_edge[1].tolist() == [False] * 4
+    assert on_edge[3].tolist() == [False, False, True, True]
+
+
+def test_pipeline_crops_to_peaks_fp32():
+    """crop -> net (fp32) -> peaks on device equals the same chain with the oracle's post-processing."""
+    from argparse import Namespace
+    from unmore_amd import reasoning
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.objectness_net import ObjectnessNet
+    net = ObjectnessNet("cuda:0", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    sd = {k: torch.from_numpy(hash_init(k, tuple(v.shape), "tiny")) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to("cuda:0").eval()
+    g = torch.Generator().manual_seed(3)
+    img = torch.rand(3, 240, 320, generator=g).cuda()
+    boxes = torch.tensor([[0, 0, 320, 240], [40, 30, 200, 180], [100, 60, 300, 220.0]])
+    crops, _ = reasoning.crop_resize(img, boxes, 128)
+    with torch.no_grad():
+        out = net.get_prediction(crops)
+    mx, am = reasoning.center_peaks(out["sdf_maps"].squeeze(1), out["center_fields"])
+    s_r, m_r, a_r = orc.peak_pick(out["sdf_maps"].squeeze(1).cpu(), out["center_fields"].cpu())
+    assert torch.equal(am.cpu(), a_r)
+    torch.testing.assert_close(mx.cpu(), m_r, atol=1e-12, rtol=0)

@@ -74,6 +74,9 @@ _SIGS = {
     "umr_loss_workspace": [],
     "umr_objectness_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "umr_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "umr_crop_resize_bilinear": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],
     "umr_version": [],
     "umr_last_error_string": [],
 }

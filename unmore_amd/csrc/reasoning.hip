@@ -1,0 +1,209 @@
+// Field post-processing around the ObjectnessNet calls of unMORE's object reasoning ("next" rows f1/f2 of
+// SURVEY.md section 8f): proposal crop + bilinear resize, centre-field peak picking, boundary-field box deltas.
+// Reference: object_reasoning.py:301-337,398-410 (crop/resize), :360-377,525-557 + utils/misc.py:10-20 (peaks),
+// :139-174 (update_bbox_with_boundary_fields).  HBM/latency-bound integer / small-stencil work: one workgroup per
+// crop or per field map, LDS for the masks, fixed-order reductions (bitwise reproducible).
+#include "umr_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- crop + resize (torchvision tensor Resize, bilinear,
+// no antialias == F.interpolate(mode="bilinear", align_corners=False))
+__global__ void crop_resize_kernel(const float* __restrict__ img, const int32_t* __restrict__ boxes, float* __restrict__ out, int N,
+                                   int H, int W, int S) {
+    const int64_t total = (int64_t)N * 3 * S * S;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % S);
+        int64_t r = idx / S;
+        const int oy = (int)(r % S); r /= S;
+        const int c = (int)(r % 3);
+        const int n = (int)(r / 3);
+        const int x1 = boxes[n * 4 + 0], y1 = boxes[n * 4 + 1], x2 = boxes[n * 4 + 2], y2 = boxes[n * 4 + 3];
+        const int hc = y2 - y1, wc = x2 - x1;
+        float v = 0.f;
+        if (hc > 0 && wc > 0) {
+            const float sh = (float)hc / (float)S, sw = (float)wc / (float)S;
+            const float sy = fmaxf(sh * ((float)oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(sw * ((float)ox + 0.5f) - 0.5f, 0.f);
+            int iy = (int)sy, ix = (int)sx;
+            if (iy > hc - 1) iy = hc - 1;
+            if (ix > wc - 1) ix = wc - 1;
+            const int dy = iy < hc - 1 ? 1 : 0, dx = ix < wc - 1 ? 1 : 0;
+            const float ly1 = fminf(fmaxf(sy - (float)iy, 0.f), 1.f), lx1 = fminf(fmaxf(sx - (float)ix, 0.f), 1.f);
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            const float* p = img + ((int64_t)c * H + (y1 + iy)) * W + (x1 + ix);
+            const float v00 = p[0], v01 = p[dx], v10 = p[(int64_t)dy * W], v11 = p[(int64_t)dy * W + dx];
+            v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        }
+        out[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------- centre peaks
+// one workgroup per map; masks live in LDS as bytes (two planes for the erosion rounds)
+struct PeakCfg { int H, W, border, erode_k, erode_rounds; };
+
+__global__ __launch_bounds__(256) void center_peaks_kernel(const float* __restrict__ sdf, const float* __restrict__ center,
+                                                           const double* __restrict__ filt /* [2][5][5] */, double* __restrict__ score_out,
+                                                           double* __restrict__ maxval, int64_t* __restrict__ argmax, PeakCfg cfg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ double red_v[256];
+    __shared__ int red_i[256];
+    const int H = cfg.H, W = cfg.W, HW = H * W;
+    unsigned char* m0 = lds;
+    unsigned char* m1 = lds + HW;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sdf + (int64_t)b * HW;
+    const float* c0 = center + (int64_t)b * 2 * HW;
+    const float* c1 = c0 + HW;
+    // union of (sigmoid(sdf) > 0.5) and (||center|| > 0.5)  (object_reasoning.py:528-531)
+    for (int i = tid; i < HW; i += 256) {
+        const float sg = 1.0f / (1.0f + expf(-s[i]));
+        const float nr = sqrtf(c0[i] * c0[i] + c1[i] * c1[i]);
+        m0[i] = (sg > 0.5f || nr > 0.5f) ? 1 : 0;
+    }
+    __syncthreads();
+    // erosion: k x k all-ones box, keep where the (zero padded) sum == k*k  (utils/misc.py:10-20) -- separable AND
+    const int rad = (cfg.erode_k - 1) / 2;
+    for (int round = 0; round < cfg.erode_rounds; ++round) {
+        for (int i = tid; i < HW; i += 256) {  // horizontal
+            const int y = i / W, x = i - y * W;
+            unsigned char ok = 1;
+            for (int d = -rad; d <= rad; ++d) {
+                const int xx = x + d;
+                ok &= (xx >= 0 && xx < W) ? m0[y * W + xx] : 0;
+            }
+            m1[i] = ok;
+        }
+        __syncthreads();
+        for (int i = tid; i < HW; i += 256) {  // vertical
+            const int y = i / W, x = i - y * W;
+            unsigned char ok = 1;
+            for (int d = -rad; d <= rad; ++d) {
+                const int yy = y + d;
+                ok &= (yy >= 0 && yy < H) ? m1[yy * W + x] : 0;
+            }
+            m0[i] = ok;
+        }
+        __syncthreads();
+    }
+    // anti-centre score: float64 5x5 correlation with normalize((2-i, 2-j)), /24  (object_reasoning.py:360-377)
+    double best = -1.0e300;
+    int besti = 0;
+    bool any = false;
+    for (int i = tid; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        double acc = 0.0;
+        if (m0[i] && y >= cfg.border && y < H - cfg.border && x >= cfg.border && x < W - cfg.border) {
+            for (int ch = 0; ch < 2; ++ch) {
+                const float* cp = ch == 0 ? c0 : c1;
+                for (int fi = 0; fi < 5; ++fi) {
+                    const int yy = y + fi - 2;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int fj = 0; fj < 5; ++fj) {
+                        const int xx = x + fj - 2;
+                        if (xx < 0 || xx >= W) continue;
+                        acc += (double)cp[yy * W + xx] * filt[(ch * 5 + fi) * 5 + fj];
+                    }
+                }
+            }
+            acc = acc / 24.0;
+        }
+        if (score_out) score_out[(int64_t)b * HW + i] = acc;
+        if (!any || acc > best) { best = acc; besti = i; any = true; }  // i increases: first maximum wins inside a thread
+    }
+    red_v[tid] = any ? best : -1.0e300;
+    red_i[tid] = any ? besti : 0x7FFFFFFF;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double v2 = red_v[tid + off];
+            const int i2 = red_i[tid + off];
+            if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { maxval[b] = red_v[0]; argmax[b] = red_i[0]; }
+}
+
+// ---------------------------------------------------------------- boundary-field box deltas (object_reasoning.py:139-174)
+__global__ __launch_bounds__(256) void boundary_deltas_kernel(const float* __restrict__ sdf, float* __restrict__ deltas, int H, int W) {
+    __shared__ float red[4][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sdf + (int64_t)b * H * W;
+    const int h1 = H - 1, w1 = W - 1;
+    float s_fg = 0.f, s_bg = 0.f, n_fg = 0.f, n_bg = 0.f;
+    for (int i = tid; i < h1 * w1; i += 256) {
+        const int y = i / w1, x = i - y * w1;
+        const float v = s[y * W + x];
+        const float dy = s[(y + 1) * W + x] - v, dx = s[y * W + x + 1] - v;
+        const float nr = sqrtf(dy * dy + dx * dx);
+        const float fg = 1.0f / (1.0f + expf(-v)), bg = 1.0f - fg;
+        s_fg += fg * nr; s_bg += bg * nr; n_fg += fg; n_bg += bg;
+    }
+    red[0][tid] = s_fg; red[1][tid] = s_bg; red[2][tid] = n_fg; red[3][tid] = n_bg;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + off];
+        __syncthreads();
+    }
+    const float avg_fg = red[0][0] / (red[2][0] + 1e-8f), avg_bg = red[1][0] / (red[3][0] + 1e-8f);
+    const float step_fg = 1.0f / (avg_fg + 1e-10f), step_bg = 1.0f / (avg_bg + 1e-10f);
+    __syncthreads();
+    auto movement = [&](int y, int x) {
+        const float v = s[y * W + x];
+        const float fg = 1.0f / (1.0f + expf(-v));
+        return (step_fg * fg + step_bg * (1.0f - fg)) * v;
+    };
+    float mx1 = -INFINITY, my1 = -INFINITY, mx2 = -INFINITY, my2 = -INFINITY;
+    for (int y = tid; y < h1; y += 256) { mx1 = fmaxf(mx1, movement(y, 0)); mx2 = fmaxf(mx2, movement(y, w1 - 1)); }
+    for (int x = tid; x < w1; x += 256) { my1 = fmaxf(my1, movement(0, x)); my2 = fmaxf(my2, movement(h1 - 1, x)); }
+    red[0][tid] = mx1; red[1][tid] = my1; red[2][tid] = mx2; red[3][tid] = my2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) for (int k = 0; k < 4; ++k) red[k][tid] = fmaxf(red[k][tid], red[k][tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        deltas[b * 4 + 0] = -red[0][0];
+        deltas[b * 4 + 1] = -red[1][0];
+        deltas[b * 4 + 2] = red[2][0];
+        deltas[b * 4 + 3] = red[3][0];
+    }
+}
+
+}  // namespace
+
+extern "C" int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* out, int N, int H, int W, int S,
+                                        umr_stream_t stream) {
+    UMR_CHECK_ARG(image && boxes && out && N > 0 && H > 0 && W > 0 && S > 0, "crop_resize: bad arguments");
+    const int64_t total = (int64_t)N * 3 * S * S;
+    int64_t g = (total + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(crop_resize_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, image, boxes, out, N, H, W, S);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_center_peaks(const float* sdf_maps, const float* center_fields, const double* filter50, double* score_out,
+                                double* max_values, int64_t* argmax, int B, int H, int W, int border, int erode_kernel,
+                                int erode_rounds, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && center_fields && filter50 && max_values && argmax, "center_peaks: null pointer");
+    UMR_CHECK_ARG(B > 0 && H > 0 && W > 0 && border >= 0 && erode_kernel >= 1 && (erode_kernel & 1) && erode_rounds >= 0,
+                  "center_peaks: bad arguments");
+    if ((int64_t)H * W * 2 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "center_peaks: map larger than the LDS mask planes (H*W <= 76800)");
+    PeakCfg cfg{H, W, border, erode_kernel, erode_rounds};
+    const size_t lds = (size_t)H * W * 2;
+    static bool set_ = false;
+    if (!set_) { hipFuncSetAttribute((const void*)center_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set_ = true; }
+    hipLaunchKernelGGL(center_peaks_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sdf_maps, center_fields, filter50, score_out,
+                       max_values, argmax, cfg);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && deltas && B > 0 && H > 1 && W > 1, "boundary_deltas: bad arguments");
+    hipLaunchKernelGGL(boundary_deltas_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sdf_maps, deltas, H, W);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -1,0 +1,74 @@
+"""Device-side glue of unMORE's object reasoning around the ObjectnessNet calls:
+proposal crop + resize, centre-field peak picking, boundary-field box deltas.  Each function replaces a Python /
+PyTorch block of the reference's `Object_Discovery` (object_reasoning.py) with one kernel launch."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .ops import _p, _stream, _need_gpu
+
+
+def crop_resize(image, boxes, size=128):
+    """object_reasoning.py:311-323 -- for every box: floor/ceil the corners, crop `image[:, y1:y2, x1:x2]`, resize to
+    (size, size) with bilinear interpolation (torchvision tensor Resize, no antialias).  image: [3,H,W] f32 on the GPU,
+    boxes: [N,4] (x1,y1,x2,y2) any float/int tensor.  Returns ([N,3,size,size] f32, on_edge_flags [N,4] bool)."""
+    _need_gpu(image)
+    assert image.dim() == 3 and image.shape[0] == 3 and image.dtype == torch.float32
+    image = image.contiguous()
+    H, W = image.shape[1], image.shape[2]
+    b = boxes.detach().to("cpu", torch.float64)
+    ib = torch.stack([torch.floor(b[:, 0]), torch.floor(b[:, 1]), torch.ceil(b[:, 2]), torch.ceil(b[:, 3])], 1).to(torch.int32)
+    # python slicing semantics of image[:, y1:y2, x1:x2]: negative starts would wrap; the reference clips boxes beforehand
+    ib[:, 0].clamp_(0, W); ib[:, 2].clamp_(0, W); ib[:, 1].clamp_(0, H); ib[:, 3].clamp_(0, H)
+    on_edge = torch.stack([ib[:, 0] == 0, ib[:, 1] == 0, ib[:, 2] == W, ib[:, 3] == H], 1)
+    N = ib.shape[0]
+    out = torch.empty((N, 3, size, size), dtype=torch.float32, device=image.device)
+    ibd = ib.to(image.device)
+    L.check(L.lib().umr_crop_resize_bilinear(_p(image), _p(ibd), _p(out), N, H, W, size, _stream()), "umr_crop_resize_bilinear")
+    return out, on_edge
+
+
+_filter_cache = {}
+
+
+def _anti_center_filter(device):
+    """normalize((2-i, 2-j)) per tap in float32 (F.normalize), promoted to float64 (object_reasoning.py:368-373)."""
+    f = _filter_cache.get(device)
+    if f is None:
+        g = np.zeros((2, 5, 5), np.float32)
+        for i in range(5):
+            for j in range(5):
+                v = np.array([2 - i, 2 - j], np.float32)
+                n = np.float32(np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1])))
+                g[:, i, j] = v / max(n, np.float32(1e-12))
+        f = torch.from_numpy(g.astype(np.float64)).to(device)
+        _filter_cache[device] = f
+    return f
+
+
+def center_peaks(sdf_maps, center_fields, border=10, erode_kernel=9, erode_rounds=3, return_scores=False):
+    """object_reasoning.py:528-550.  sdf_maps [B,H,W], center_fields [B,2,H,W] (f32, GPU).
+    Returns (max score [B] f64, flat argmax [B] int64[, score maps [B,H,W] f64])."""
+    _need_gpu(sdf_maps, center_fields)
+    sdf = sdf_maps.contiguous().float()
+    cen = center_fields.contiguous().float()
+    B, H, W = sdf.shape
+    mx = torch.empty(B, dtype=torch.float64, device=sdf.device)
+    am = torch.empty(B, dtype=torch.int64, device=sdf.device)
+    sc = torch.empty((B, H, W), dtype=torch.float64, device=sdf.device) if return_scores else None
+    L.check(L.lib().umr_center_peaks(_p(sdf), _p(cen), _p(_anti_center_filter(sdf.device)), _p(sc), _p(mx), _p(am), B, H, W, border,
+                                     erode_kernel, erode_rounds, _stream()), "umr_center_peaks")
+    return (mx, am, sc) if return_scores else (mx, am)
+
+
+def update_bbox_with_boundary_fields(sdf_maps):
+    """object_reasoning.py:139-174: (delta_x1, delta_y1, delta_x2, delta_y2), each [B]."""
+    _need_gpu(sdf_maps)
+    sdf = sdf_maps.contiguous().float()
+    B, H, W = sdf.shape
+    d = torch.empty((B, 4), dtype=torch.float32, device=sdf.device)
+    L.check(L.lib().umr_boundary_deltas(_p(sdf), _p(d), B, H, W, _stream()), "umr_boundary_deltas")
+    return d[:, 0], d[:, 1], d[:, 2], d[:, 3]

@@ -114,3 +114,32 @@ def test_inference_crops_128_bf16_and_fp32_peaks():
             gap = abs(s_r[b].flatten()[a_g[b]] - s_r[b].flatten()[a_r[b]]).item()
             assert gap < 1e-6, f"image {b}: argmax {int(a_g[b])} vs {int(a_r[b])}, score gap {gap}"
     torch.testing.assert_close(m_g, m_r, atol=1e-4, rtol=0)
+
+
+def test_batch_filter_matches_reference_semantics():
+    """train_objectness_net.py:190-207: images whose saliency is all background or all foreground are dropped."""
+    from unmore_amd.trainer import filter_batch
+    B, H, W = 5, 32, 32
+    img = torch.rand(B, 3, H, W).cuda()
+    cf = torch.rand(B, 2, H, W).cuda()
+    sdf = torch.rand(B, 1, H, W).cuda()
+    sal = torch.zeros(B, 1, H, W).cuda()
+    sal[1, :, 4:9, 4:9] = 1          # mixed -> kept
+    sal[2] = 1                       # all foreground -> dropped
+    sal[4, :, :, :16] = 1            # mixed -> kept
+    i2, c2, s2, m2 = filter_batch(img, cf, sdf, sal)
+    assert i2.shape[0] == 2 and torch.equal(i2, img[[1, 4]]) and torch.equal(m2, sal[[1, 4]])
+    assert torch.equal(c2, cf[[1, 4]]) and torch.equal(s2, sdf[[1, 4]])
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 32, 32), (3, 32, 64), (1, 160, 96)])
+def test_small_and_ragged_shapes_fp32(B, H, W):
+    """smallest grid the reference wiring allows (2x2 patches: the stride-2 conv sees a 2x2 map), B=1, H != W."""
+    net, sd = _net("dpt_tiny", "tiny")
+    net.eval()
+    x = torch.from_numpy(uniform01(f"img:ragged{H}x{W}", (B, 3, H, W)))
+    with torch.no_grad():
+        out = net(images=x.cuda())
+        ref = orc.forward(sd, x, orc.CONFIGS["dpt_tiny"])
+    for k in ("center_fields", "sdf_maps"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-4, rtol=0)

@@ -28,6 +28,15 @@ def _stage_of(name, cfg):
     return "embed"
 
 
+def filter_batch(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
+    """The reference's per-step batch filter (train_objectness_net.py:190-207): drop images whose pseudo-mask is all
+    background or all foreground, so every remaining image has both.  Host-side boolean indexing (tensor plumbing,
+    one device sync for the data-dependent batch size), exactly as the reference does it."""
+    s = gt_saliency_maps.reshape(gt_saliency_maps.shape[0], -1)
+    keep = (s.sum(1) > 0) & ((1 - s).sum(1) != 0)
+    return images[keep], gt_center_fields[keep], gt_sdf_maps[keep], gt_saliency_maps[keep]
+
+
 class TrainStep:
     def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, center_field_loss_type="l2", sdf_loss_type="l1",
                  use_sdf_gradient_loss=True, use_sdf_binary_mask_loss=True, lr_milestones=(), lr_gamma=1.0, group=None):

@@ -160,16 +160,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
             sox += ROWS;
             if (sox >= p.Wo) { sox = 0; if (++soy >= p.Ho) { soy = 0; ++sb; } }
         } else {
-            xbase = (const char*)p.X;
+            // general path: per-lane coordinates, addressed relative to the stage's first input pixel (minus one
+            // halo row + column) so that the 32-bit voffset stays small for tensors of any size
+            const int64_t pix_base = ((int64_t)sb * p.H + soy * stride) * p.W + sox * stride - (p.W + 1);
+            xbase = (const char*)p.X + pix_base * p.Cin * SZ;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int iy = coy[i] * stride + tky[i], ix = cox[i] * stride + tkx[i];
                 const bool ok = k_ok[i] && rr[i] < rows_left && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                vx[i] = ok ? (unsigned)(((((int64_t)cb[i] * p.H + iy) * p.W + ix) * p.Cin + k_ci[i]) * SZ) : OOB;
+                const int64_t pix = ((int64_t)cb[i] * p.H + iy) * p.W + ix;
+                vx[i] = ok ? (unsigned)(((pix - pix_base) * p.Cin + k_ci[i]) * SZ) : OOB;
                 cox[i] += ROWS;
                 coy[i] += carry(cox[i], p.Wo, inv_wo);
                 cb[i] += carry(coy[i], p.Ho, inv_ho);
             }
+            sox += ROWS;
+            while (sox >= p.Wo) { sox -= p.Wo; ++soy; }
+            while (soy >= p.Ho) { soy -= p.Ho; ++sb; }
         }
         const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, yrec, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xrec, 0x00020000);
@@ -372,8 +379,7 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
         const int64_t sz = d->dtype == UMR_BF16 ? 2 : 4;
         const bool remap = d->dy_rows_in > 0 || (d->conv == 0 && d->x_rows_in > 0);
         const bool conv_general = d->conv != 0 && !(d->conv == 1 && d->Wo % rows == 0);
-        if (conv_general && (int64_t)d->nb * d->H * d->W * d->Cin * sz >= (1ll << 31))
-            return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_tn: conv input >= 2 GiB needs Wo % rows-per-stage == 0 and stride 1");
+        (void)conv_general;  // both conv paths address relative to a per-stage base: no size limit
         if (remap) {
             const int64_t ymax = d->dy_rows_in > 0 ? ((int64_t)d->M / d->dy_rows_in + 1) * d->dy_rows_out : d->M;
             const int64_t xmax = d->x_rows_in > 0 ? ((int64_t)d->M / d->x_rows_in + 1) * d->x_rows_out : d->M;

@@ -163,6 +163,24 @@ int umr_center_peaks(const float* sdf_maps, const float* center_fields, const do
                      umr_stream_t stream);
 int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream);
 
+/* ---- collapsed linear head (opt-in; SURVEY.md section 7 "the sdf head has no nonlinearity before tanh") ------
+ * A head whose four convolutions have no activation between them (objectness_net.py:119-142) equals ONE 3x3 conv
+ * C -> 1 plus a border-dependent bias: out(p) = act( sum_{taps t inside the image at p} (kw[t].x(p+t) + tapbias10[t])
+ * + tapbias10[9] ).  x is NHWC [B,H,W,C=256]; out / dout / yout are [B,1,H,W] f32; kw is [9][C] f32.
+ * bwd_data: dx (+)= sum_t kw[t] * g(p-t), g = dout*act'(yout).  bwd_weight: out = [G(9*C) | n(9) | D(1)] with
+ * G[t] = sum_p g(p) x(p+t), n[t] = sum_{p: p+t inside} g(p), D = sum_p g(p): all the factored weights' gradients
+ * follow from these by small matrix products (umr_small_gemm_f32).  act: UMR_ACT_NONE / UMR_ACT_TANH (4 = sine, fwd only). */
+int umr_linear_head_fwd(const void* x, const float* kw, const float* tapbias10, float* out, int B, int H, int W, int C, int act,
+                        int dtype, umr_stream_t stream);
+int umr_linear_head_bwd_data(const float* dout, const float* yout, const float* kw, void* dx, int B, int H, int W, int C, int act,
+                             int accumulate, int dtype, umr_stream_t stream);
+int64_t umr_linear_head_bwd_weight_workspace(int64_t M, int C);
+int umr_linear_head_bwd_weight(const void* x, const float* dout, const float* yout, float* out, void* workspace,
+                               int64_t workspace_bytes, int B, int H, int W, int C, int act, int dtype, umr_stream_t stream);
+/* C[i*sc_m + j*sc_n] (=|+=) sum_k A[i*sa_m + k*sa_k] * B[k*sb_k + j*sb_n]  (tiny f32 products, arbitrary strides) */
+int umr_small_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sa_m, int64_t sa_k, int64_t sb_k,
+                       int64_t sb_n, int64_t sc_m, int64_t sc_n, int accumulate, umr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,49 @@ def test_small_and_ragged_shapes_fp32(B, H, W):
         ref = orc.forward(sd, x, orc.CONFIGS["dpt_tiny"])
     for k in ("center_fields", "sdf_maps"):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64)])
+def test_collapsed_sdf_head_equals_factored(dtype, H, W):
+    """Opt-in algebraic form of the linear boundary-distance head: same outputs and the same gradients for EVERY
+    factored weight (fp32: vs the fp64 oracle at the bar of the factored path; bf16: vs the factored bf16 path)."""
+    from unmore_amd.loss import objectness_loss
+    B = 2
+    img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(B, H, W, seed=5))
+    nets = {}
+    for mode in ("factored", "collapsed"):
+        net, sd = _net("dpt_tiny", "tiny", dtype)
+        net.set_sdf_head_mode(mode)
+        net.train()
+        out = net(images=img.cuda())
+        loss = objectness_loss(out, cf.cuda(), sdf.cuda(), sal.cuda())
+        loss.backward()
+        nets[mode] = (net, out, loss.item())
+    o_f, o_c = nets["factored"][1], nets["collapsed"][1]
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert (o_f["sdf_maps"] - o_c["sdf_maps"]).abs().max().item() < tol
+    assert torch.equal(o_f["center_fields"], o_c["center_fields"])
+    if dtype == torch.float32:
+        # both paths against each other, parameter by parameter (a comparison with the fp64 oracle would also measure
+        # ReLU masks that fp32 and fp64 decide differently -- identical for the two paths, unrelated to the algebra)
+        assert abs(nets["collapsed"][2] - nets["factored"][2]) < 1e-5
+        gf = dict((n, p.grad) for n, p in nets["factored"][0].named_parameters())
+        for n, p in nets["collapsed"][0].named_parameters():
+            if gf[n] is None:
+                assert p.grad is None
+                continue
+            err = (p.grad - gf[n]).abs().max().item() / (gf[n].abs().max().item() + 1e-12)
+            assert err < 2e-4, (n, err)
+        # and the head's own gradients against the fp64 oracle
+        sdo = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+        lo, _ = orc.loss_terms(orc.forward(sdo, img.double(), orc.CONFIGS["dpt_tiny"]), cf.double(), sdf.double(), sal.double())
+        lo.backward()
+        for n, p in nets["collapsed"][0].named_parameters():
+            if n.startswith("sdf_prediction_head"):
+                ref = sdo[n].grad
+                err = (p.grad.cpu().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+                assert err < 5e-4, (n, err)
+    else:
+        a = torch.cat([p.grad.flatten() for _, p in nets["factored"][0].named_parameters() if p.grad is not None])
+        b = torch.cat([p.grad.flatten() for _, p in nets["collapsed"][0].named_parameters() if p.grad is not None])
+        assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99

@@ -77,6 +77,11 @@ _SIGS = {
     "umr_crop_resize_bilinear": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "umr_linear_head_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_linear_head_bwd_data": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_linear_head_bwd_weight_workspace": [_i64, _i32],
+    "umr_linear_head_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "umr_version": [],
     "umr_last_error_string": [],
 }
@@ -101,7 +106,8 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.umr_last_error_string.restype = ctypes.c_char_p
         _set_argtypes(_lib)
-        for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace"):
+        for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
+                   "umr_linear_head_bwd_weight_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

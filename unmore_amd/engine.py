@@ -95,11 +95,77 @@ def _rep_bias(b, reps):
 
 
 class Engine:
-    def __init__(self, cfg, head_layouts, compute_dtype=torch.float32):
+    def __init__(self, cfg, head_layouts, compute_dtype=torch.float32, collapse_linear_heads=False):
         self.cfg = cfg
         self.center_layout, self.sdf_layout = head_layouts
         self.dt = compute_dtype
         self.cache = PackCache()
+        # opt-in algebraic fast path for heads without non-linearities between their convs:
+        # default False = compute the four convolutions as the reference does
+        self.collapse_linear_heads = collapse_linear_heads
+
+    # ------------------------------------------------------------------ collapsed linear head (opt-in)
+    def _linear_head_forward(self, P, name, idx, feat, act):
+        """W4 W3 (W2 * (W1 x + b1) + b2) + b3) + b4 as one 3x3 conv 256 -> 1 (csrc/linear_head.hip).  All weight
+        algebra is f32 on the master weights (element strides of the PyTorch layouts, no packing):
+          u = W4 W3 [512];  Vc[ci][t] = sum_co u[co] W2[co,ci,t];  Kw[t][c] = sum_ci Vc[ci][t] W1[ci][c];
+          s[t] = sum_ci Vc[ci][t] b1[ci];  c0 = u.b2 + W4.b3 + b4."""
+        dev = feat.device
+        W1, b1 = self._f32(P, f"{name}.{idx[0]}.weight"), self._f32(P, f"{name}.{idx[0]}.bias")
+        W2, b2 = self._f32(P, f"{name}.{idx[1]}.weight"), self._f32(P, f"{name}.{idx[1]}.bias")
+        W3, b3 = self._f32(P, f"{name}.{idx[2]}.weight"), self._f32(P, f"{name}.{idx[2]}.bias")
+        W4, b4 = self._f32(P, f"{name}.{idx[3]}.weight"), self._f32(P, f"{name}.{idx[3]}.bias")
+        C, C1, C3 = W1.shape[1], W1.shape[0], W3.shape[0]  # 256, 512, 1024
+        assert W4.shape[0] == 1 and W2.shape == (C1, C1, 3, 3) and all(t.is_contiguous() for t in (W1, W2, W3, W4))
+        f = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        u, Vc, Kw, tb = f(C1), f(C1 * 9), f(9 * C), f(10)
+        ops.small_gemm(W4, W3, u, 1, C1, C3, (0, 1), (C1, 1), (0, 1))
+        ops.small_gemm(u, W2, Vc, 1, C1 * 9, C1, (0, 1), (C1 * 9, 1), (0, 1))
+        ops.small_gemm(Vc, W1, Kw, 9, C, C1, (1, 9), (C, 1), (C, 1))
+        ops.small_gemm(Vc, b1, tb, 9, 1, C1, (1, 9), (1, 0), (1, 0))
+        ops.cast(b4, torch.float32, out=tb[9:10])
+        ops.small_gemm(u, b2, tb[9:10], 1, 1, C1, (0, 1), (1, 0), (0, 0), accumulate=True)
+        ops.small_gemm(W4, b3, tb[9:10], 1, 1, C3, (0, 1), (1, 0), (0, 0), accumulate=True)
+        out = ops.linear_head_fwd(feat, Kw, tb, act)
+        return out, dict(collapsed=True, u=u, Vc=Vc, Kw=Kw, act=act)
+
+    def _linear_head_backward(self, P, name, idx, feat, hs, dout, dfeat, G):
+        """Gradients of every factored parameter from the three pixel reductions R = [G | n | D] (csrc/linear_head.hip)."""
+        W1, b1 = self._f32(P, f"{name}.{idx[0]}.weight"), self._f32(P, f"{name}.{idx[0]}.bias")
+        W2, b2 = self._f32(P, f"{name}.{idx[1]}.weight"), self._f32(P, f"{name}.{idx[1]}.bias")
+        W3, b3 = self._f32(P, f"{name}.{idx[2]}.weight"), self._f32(P, f"{name}.{idx[2]}.bias")
+        W4 = self._f32(P, f"{name}.{idx[3]}.weight")
+        C, C1, C3 = W1.shape[1], W1.shape[0], W3.shape[0]
+        dev = feat.device
+        act, u, Vc, Kw = hs["act"], hs["u"], hs["Vc"], hs["Kw"]
+        dout = dout.contiguous()
+        R = ops.linear_head_bwd_weight(feat, dout, hs["out"], act)
+        Gm, n, D = R[:9 * C], R[9 * C:9 * C + 9], R[9 * C + 9:]
+        # data gradient (accumulates into the centre head's dfeat when there is one)
+        if dfeat is None:
+            dfeat = torch.empty_like(feat)
+            ops.linear_head_bwd_data(dout, hs["out"], Kw, dfeat, act, False)
+        else:
+            ops.linear_head_bwd_data(dout, hs["out"], Kw, dfeat.view(feat.shape), act, True)
+        g = lambda k: (G[f"{name}.{idx[k]}.weight"], G[f"{name}.{idx[k]}.bias"])
+        (gW1, gb1), (gW2, gb2), (gW3, gb3), (gW4, gb4) = g(0), g(1), g(2), g(3)
+        gvc = torch.empty(C1 * 9, dtype=torch.float32, device=dev)
+        gu = torch.empty(C1, dtype=torch.float32, device=dev)
+        # gv[ci][t] = sum_c W1[ci][c] G[t][c] + n[t] b1[ci]
+        ops.small_gemm(W1, Gm, gvc, C1, 9, C, (C, 1), (1, C), (9, 1))
+        ops.small_gemm(b1, n, gvc, C1, 9, 1, (1, 0), (0, 1), (9, 1), accumulate=True)
+        ops.small_gemm(Vc, Gm, gW1, C1, C, 9, (9, 1), (C, 1), (C, 1))           # dW1 = Vc G
+        ops.small_gemm(Vc, n, gb1, C1, 1, 9, (9, 1), (1, 0), (1, 0))            # db1 = Vc n
+        ops.small_gemm(u, gvc, gW2, C1, C1 * 9, 1, (1, 0), (0, 1), (C1 * 9, 1))  # dW2[co,ci,t] = u[co] gv[ci][t]
+        ops.small_gemm(W2, gvc, gu, C1, 1, C1 * 9, (C1 * 9, 1), (1, 0), (1, 0))  # gu = W2 gv (+ D b2)
+        ops.small_gemm(b2, D, gu, C1, 1, 1, (1, 0), (0, 0), (1, 0), accumulate=True)
+        ops.small_gemm(u, D, gb2, C1, 1, 1, (1, 0), (0, 0), (1, 0))             # db2 = D u
+        ops.small_gemm(gu, W3, gW4, 1, C3, C1, (0, 1), (1, C1), (0, 1))         # dW4 = gu W3^T (+ D b3)
+        ops.small_gemm(D, b3, gW4, 1, C3, 1, (0, 0), (0, 1), (0, 1), accumulate=True)
+        ops.small_gemm(W4, gu, gW3, C3, C1, 1, (1, 0), (0, 1), (C1, 1))         # dW3 = W4^T gu
+        ops.small_gemm(W4, D, gb3, C3, 1, 1, (1, 0), (0, 0), (1, 0))            # db3 = D W4^T
+        ops.cast(D, torch.float32, out=gb4.view(1))                              # db4 = D
+        return dfeat
 
     # ------------------------------------------------------------------ helpers
     def _w(self, P, name, kind):
@@ -272,6 +338,13 @@ class Engine:
         heads_saved = []
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
+            if self.collapse_linear_heads and not lay["relu"]:
+                out, cs = self._linear_head_forward(P, name, idx, feat, _ACT[lay["final"]])
+                outs.append(out)
+                if save:
+                    cs["out"] = out
+                    heads_saved.append(cs)
+                continue
             act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
             h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
             h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
@@ -313,6 +386,9 @@ class Engine:
                                                ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
             idx = lay["conv_idx"]
+            if hs.get("collapsed"):
+                dfeat = self._linear_head_backward(P, name, idx, feat, hs, dout, dfeat, G)
+                continue
             relu = lay["relu"]
             w4 = self._f32(P, f"{name}.{idx[3]}.weight")
             dh3 = ops.head_out_bwd(hs["h3"], w4.reshape(w4.shape[0], -1), dout.contiguous(), hs["out"], _ACT[lay["final"]], relu,

@@ -358,3 +358,39 @@ def _timed_call(d):
         _timer["events"].append((a, b))
         return st
     return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
+
+
+# ---------------------------------------------------------------- collapsed linear head (opt-in)
+def small_gemm(A, B, C, M, N, K, sa, sb, sc, accumulate=False):
+    """C[i*sc[0] + j*sc[1]] (=|+=) sum_k A[i*sa[0] + k*sa[1]] * B[k*sb[0] + j*sb[1]]; f32 device tensors, element strides."""
+    _need_gpu(A, B, C)
+    assert A.dtype == B.dtype == C.dtype == torch.float32
+    L.check(L.lib().umr_small_gemm_f32(_p(A), _p(B), _p(C), M, N, K, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(accumulate), _stream()),
+            "umr_small_gemm_f32")
+    return C
+
+
+def linear_head_fwd(x, kw, tapbias10, act):
+    """x NHWC [B,H,W,256] -> [B,1,H,W] f32."""
+    _need_gpu(x)
+    B, H, W, C = x.shape
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+    L.check(L.lib().umr_linear_head_fwd(_p(x), _p(kw), _p(tapbias10), _p(out), B, H, W, C, act, _DT[x.dtype], _stream()), "umr_linear_head_fwd")
+    return out
+
+
+def linear_head_bwd_data(dout, yout, kw, dx, act, accumulate):
+    B, H, W, C = dx.shape
+    L.check(L.lib().umr_linear_head_bwd_data(_p(dout), _p(yout), _p(kw), _p(dx), B, H, W, C, act, int(accumulate), _DT[dx.dtype], _stream()),
+            "umr_linear_head_bwd_data")
+    return dx
+
+
+def linear_head_bwd_weight(x, dout, yout, act):
+    """-> f32 [9*C + 10] = [G (9,C) | n (9) | D (1)]"""
+    B, H, W, C = x.shape
+    out = torch.empty(9 * C + 10, dtype=torch.float32, device=x.device)
+    ws = _workspace(L.lib().umr_linear_head_bwd_weight_workspace(B * H * W, C), x.device)
+    L.check(L.lib().umr_linear_head_bwd_weight(_p(x), _p(dout), _p(yout), _p(out), _p(ws), ws.numel(), B, H, W, C, act, _DT[x.dtype],
+                                               _stream()), "umr_linear_head_bwd_weight")
+    return out

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--backbone", default="dpt_base")
     ap.add_argument("--check", type=int, default=100, help="crops whose peaks are checked against the CPU oracle")
+    ap.add_argument("--sdf-head", default="factored", choices=["factored", "collapsed"], help="opt-in algebraic sdf head (DESIGN.md section 7)")
     a = ap.parse_args()
     from argparse import Namespace
     from unmore_amd import reasoning
@@ -52,6 +53,7 @@ def main():
     for p in net.parameters():
         p.requires_grad = False
     net.set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    net.set_sdf_head_mode(a.sdf_head)
     H, W = 480, 640
     props = torch.from_numpy(anchors(H, W))
     assert props.shape[0] == 1225, props.shape
@@ -81,7 +83,7 @@ def main():
     dt = time.perf_counter() - t0
     ncrops = a.images * props.shape[0]
     res = {"metric": "object-reasoning sweep: crop+resize, ObjectnessNet maps, centre peaks, boundary deltas",
-           "backbone": a.backbone, "dtype": a.dtype, "images": a.images, "image_size": [W, H], "proposals_per_image": 1225,
+           "backbone": a.backbone, "dtype": a.dtype, "sdf_head": a.sdf_head, "images": a.images, "image_size": [W, H], "proposals_per_image": 1225,
            "crops_per_sec": ncrops / dt, "images_per_sec": a.images / dt, "est_minutes_for_5000_images": 5000 / (a.images / dt) / 60}
     # parity of the integer outputs: device peaks vs the CPU oracle on the same maps
     from oracle import objectness_oracle as orc

@@ -1,0 +1,93 @@
+"""Condense rocprofv3 output directories into the JSON summary kept under profiles/.
+
+  python tools/pmc_summary.py --stats DIR --fetch DIR --write DIR --out profiles/rNN_pmc_traffic.json
+
+DIR are rocprofv3 `-d` directories: --stats from `--kernel-trace --stats`, --fetch from a `--pmc FETCH_SIZE`
+pass and --write from a separate `--pmc WRITE_SIZE` pass (the two counters do not fit one pass,
+MI355X_MICROARCH.md "HBM" / counter table).  Per (kernel, grid) it reports launches, average duration and the
+average HBM-side bytes per launch: FETCH_SIZE is in KB and is DOUBLED (gfx950 counts 128-B requests as 64 B for
+16-B-per-lane streaming reads, which is how every hot kernel here loads); WRITE_SIZE is in KB, uncorrected.
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+
+def _find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits
+
+
+def short(name):
+    for tag in ("gemm_nt256p_kernel<0, 0>", "gemm_nt256p_kernel<0, 1>", "gemm_nt256p_kernel<1, 0>", "gemm_nt256p_kernel<1, 1>", "gemm_nt256_kernel<1>", "gemm_nt256_kernel<0>", "gemm_nt256_kernel<2>", "gemm_tn256_kernel<1>", "gemm_tn256_kernel<0>"):
+        if tag in name:
+            return tag
+    for tag in ("gemm_nt_kernel", "gemm_tn_kernel", "head_out_bwd", "head_out_fwd", "tn_reduce", "attn_bwd_dkv", "attn_bwd_dq",
+                "attn_fwd", "bilinear_bwd", "bilinear_fwd", "ln_bwd_kernel", "ln_bwd_reduce", "ln_fwd", "adam_kernel",
+                "linear_head", "permute4", "segsum", "cast_kernel", "pixel_shuffle", "zero_stuff2", "patchify", "loss"):
+        if tag in name:
+            return tag
+    return name[:60]
+
+
+def durations(d):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in _find(d, "kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+            k = (short(r["Kernel_Name"]), grid)
+            acc[k][0] += 1
+            acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+    return acc
+
+
+def counters(d, name):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in _find(d, "counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != name:
+                continue
+            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats", required=True)
+    ap.add_argument("--fetch", required=True)
+    ap.add_argument("--write", required=True)
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--command", default="")
+    a = ap.parse_args()
+    dur = durations(a.stats)
+    fe = counters(a.fetch, "FETCH_SIZE")
+    wr = counters(a.write, "WRITE_SIZE")
+    rows = []
+    for k, (n, ms) in dur.items():
+        row = {"kernel": k[0], "grid_threads": k[1], "launches": n, "avg_ms": ms / n, "total_ms": ms}
+        if k in fe and fe[k][0]:
+            row["fetch_bytes_per_launch"] = 2.0 * 1024.0 * fe[k][1] / fe[k][0]
+        if k in wr and wr[k][0]:
+            row["write_bytes_per_launch"] = 1024.0 * wr[k][1] / wr[k][0]
+        if "fetch_bytes_per_launch" in row and "write_bytes_per_launch" in row:
+            row["hbm_bytes_per_launch"] = row["fetch_bytes_per_launch"] + row["write_bytes_per_launch"]
+        rows.append(row)
+    rows.sort(key=lambda r: -r["total_ms"])
+    out = {"command": a.command,
+           "corrections": "FETCH_SIZE[KB] x 1024 x 2 (gfx950 half-count of 16-B/lane streaming reads); WRITE_SIZE[KB] x 1024",
+           "kernels": rows[:40]}
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    for r in rows[:12]:
+        print(json.dumps(r))
+
+
+if __name__ == "__main__":
+    main()

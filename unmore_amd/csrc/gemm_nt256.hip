@@ -310,8 +310,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
 
 }  // namespace
 
+int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip (persistent form)
+
 // launched from umr_gemm_nt (gemm_nt.hip) for bf16 problems large enough to fill the chip with 256x256 tiles
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
+    {   // the persistent kernel covers plain GEMMs without A-row remap and stride-1 convs; UMR_NT256_PERSIST=0 disables it
+        static int persist = -1;
+        if (persist < 0) { const char* e = getenv("UMR_NT256_PERSIST"); persist = e ? atoi(e) : 1; }
+        if (persist && ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1)) return umr_launch_gemm_nt256p(d, s);
+    }
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     dim3 g((unsigned)grid), b(512);

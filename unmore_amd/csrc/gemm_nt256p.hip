@@ -1,0 +1,408 @@
+// Persistent form of the 256x256-tile bf16 NT GEMM / implicit 3x3 conv (see gemm_nt256.hip for the tile
+// geometry, the four-phase K-tile and the staging-group schedule, which are unchanged here).
+//
+// Why: the one-tile-per-workgroup kernel measures  T(tile) = 12 us + 1.56 us x K-tiles  (tools/kbench4.py): with one
+// 512-thread workgroup per CU nothing overlaps a tile's first-load latency, its epilogue and the launch of the next
+// workgroup, so the 1x1 head GEMMs (4..16 K-tiles) spend about half their time outside the MFMA loop and run at
+// the SUM of their HBM time and their MFMA time instead of the max.
+//
+// Here one workgroup per CU walks a strided sequence of output tiles and treats their K-tiles as ONE stream: the
+// staging cursor (two K-tiles ahead of the MFMAs) rolls over from the last K-tile of output tile i into the
+// first K-tiles of output tile i+1, so those loads are in flight during -- and have landed by the end of -- the
+// epilogue of tile i.  The epilogue therefore cannot borrow the staging buffers: it goes through a separate
+// 32-KiB LDS region (8 passes of 32 rows x 256 columns, XOR-swizzled 16-B chunks), and its global stores drain
+// behind the next tile's first phases.
+//
+// Addressing is arranged so that a tile switch costs scalar work only: per-lane voffsets are tile-independent
+// (rows relative to the tile origin) and row/column validity comes from the buffer descriptor's num_records
+// (out-of-range rows read as zeros); only the conv halo masks are recomputed per tile.
+#include "umr_common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int BM2 = 256, BN2 = 256, BK2 = 64;
+constexpr int ROWB2 = 128;
+constexpr int TILE2 = 256 * ROWB2;   // 32 KiB per operand
+constexpr int BUF2 = 2 * TILE2;      // 64 KiB per K-tile
+constexpr int STG_OFF = 2 * BUF2;    // epilogue staging behind the two K-tile buffers
+constexpr int STG_BYTES = 32 * 256 * 4;
+constexpr int LDS2P = STG_OFF + STG_BYTES;  // 160 KiB
+
+typedef bf16_t T2;
+
+template <int CONV, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SZ = 2;
+    constexpr unsigned OOB = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // tile sequence of this workgroup: virtual ids pw, pw + G, pw + 2G, ...; workgroups of one XCD (blockIdx % 8)
+    // own a contiguous run of G/8 ids per round, so neighbouring tiles share that XCD's L2
+    const int G = gridDim.x;
+    const int pw = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (pw >= total_tiles) return;
+    const int n_my = (total_tiles - pw + G - 1) / G;
+
+    const int lrow = lane >> 3, lchk = lane & 7;
+    const int hw = (CONV != 0) ? p.Ho * p.Wo : 1;
+    // ---- per-lane staging constants (tile independent).  Group-local row lr = (w*2+i)*8 + lane/8.
+    unsigned vo[4][2];         // [group A0,B0,B1,A1][i]
+    int trow_a[2][2];          // tile row of A group gi, instruction i (for the conv halo masks)
+    unsigned a_tapmask[2][2];  // conv: bit t set <=> tap t of this row lies inside the image (0 for rows >= M)
+    unsigned a_eff[2][2];
+    int lds_row[4][2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = (w * 2 + i) * 8 + lrow;
+            {   // A group gi = m-half
+                const int trow = (lr >> 6) * 128 + gi * 64 + (lr & 63);
+                const int g = gi == 0 ? 0 : 3;
+                lds_row[g][i] = (((w * 2 + i) * 8) >> 6) * 128 + gi * 64 + (((w * 2 + i) * 8) & 63);
+                const int gch = lchk ^ ((trow >> 1) & 7);
+                trow_a[gi][i] = trow;
+                vo[g][i] = (CONV == 0) ? (unsigned)(((int64_t)trow * p.lda) * SZ + gch * 16)
+                                       : (unsigned)((int64_t)trow * p.Cin * SZ + gch * 16);
+                a_eff[gi][i] = vo[g][i];
+                a_tapmask[gi][i] = 0x1FFu;
+            }
+            {   // B group gi = n-half
+                const int trow = (lr >> 5) * 64 + gi * 32 + (lr & 31);
+                const int g = 1 + gi;
+                lds_row[g][i] = (((w * 2 + i) * 8) >> 5) * 64 + gi * 32 + (((w * 2 + i) * 8) & 31);
+                const int gch = lchk ^ ((trow >> 1) & 7);
+                vo[g][i] = (unsigned)(((int64_t)trow * p.ldb) * SZ + gch * 16);
+            }
+        }
+    }
+
+    const int ktiles_per_tap = (CONV == 0) ? 0 : p.Cin / BK2;
+    const int nt = (CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap;   // K % 64 == 0 guaranteed by the dispatcher
+
+    // ---- staging side state
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    int s_it = 0;                     // tile iteration the cursor is in
+    int st_tile = 0, st_tap = 0, st_ci = 0, st_par = 0;
+    unsigned soffA = 0, soffB = 0;
+    auto clamp31 = [](int64_t v) -> int { return v > 0x7FFFFFFFll ? 0x7FFFFFFF : (v < 0 ? 0 : (int)v); };
+    auto stage_setup = [&](int it) {
+        const bool live = it < n_my;
+        const int v = live ? it * G + pw : 0;
+        const int tm = v / tiles_n, tn = v - tm * tiles_n;
+        const int m0 = tm * BM2, n0 = tn * BN2;
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (int64_t)n0 * p.ldb * SZ), 0,
+                                                live ? clamp31((int64_t)(p.N - n0) * p.ldb * SZ) : 0, 0x00020000);
+        if (CONV == 0) {
+            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (int64_t)m0 * p.lda * SZ), 0,
+                                                    live ? clamp31((int64_t)(p.M - m0) * p.lda * SZ) : 0, 0x00020000);
+        } else {
+            // stride-1 'same' conv: input pixel index == output row index; origin = tap (-1,-1) of tile row 0
+            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + ((int64_t)m0 - (p.W + 1)) * p.Cin * SZ), 0,
+                                                    live ? 0x7FFFFFFF : 0, 0x00020000);
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + trow_a[gi][i];
+                    const int rem = m % hw;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    unsigned mask = 0;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) {
+                        const int iy = oy - 1 + tap / 3, ix = ox - 1 + tap % 3;
+                        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << tap;
+                    }
+                    a_tapmask[gi][i] = (live && m < p.M) ? mask : 0u;
+                }
+        }
+    };
+    // called when group 0 (A0) of a new K-tile is about to be issued
+    auto stage_prep = [&]() {
+        if (st_tile == nt) {   // roll over into the next output tile of this workgroup
+            st_tile = 0; st_tap = 0; st_ci = 0;
+            ++s_it;
+            stage_setup(s_it);
+        }
+        if (CONV == 0) {
+            soffA = soffB = (unsigned)(st_tile * BK2 * SZ);
+        } else {
+            const int c0 = st_ci * BK2;
+            const int ky = st_tap / 3, kx = st_tap - ky * 3;
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    a_eff[gi][i] = ((a_tapmask[gi][i] >> st_tap) & 1u) ? vo[gi == 0 ? 0 : 3][i] : OOB;
+            soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
+            soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
+            if (++st_tap == 9) { st_tap = 0; ++st_ci; }
+        }
+    };
+    auto stage_issue = [&](auto gtag, auto itag) {
+        constexpr int Gp = decltype(gtag)::value, I = decltype(itag)::value;
+        const unsigned v = (Gp == 0) ? a_eff[0][I] : (Gp == 3) ? a_eff[1][I] : vo[Gp][I];
+        char* dst = smem + st_par * BUF2;
+        if (Gp == 0 || Gp == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, UMR_LDS_PTR(dst + lds_row[Gp][I] * ROWB2), 16, v, soffA, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, UMR_LDS_PTR(dst + TILE2 + lds_row[Gp][I] * ROWB2), 16, v, soffB, 0, 0);
+        if (Gp == 3 && I == 1) { ++st_tile; st_par ^= 1; }
+    };
+#define STAGE_DMA(Gp, I) stage_issue(std::integral_constant<int, Gp>{}, std::integral_constant<int, I>{})
+
+    f32x4 acc[8][4];
+    const int wr = w >> 2, wc = w & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_ad[2], b_ad[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int q = ks * 4 + fq;
+        const int sw = (frow >> 1) & 7;
+        a_ad[ks] = (wr * 128 + frow) * ROWB2 + ((q ^ sw) << 4);
+        b_ad[ks] = TILE2 + (wc * 64 + frow) * ROWB2 + ((q ^ sw) << 4);
+    }
+#define A_FRAG(ks, i) (*(const bf16x8*)(sbuf + a_ad[ks] + (i) * 16 * ROWB2))
+#define B_FRAG(ks, i) (*(const bf16x8*)(sbuf + b_ad[ks] + (i) * 16 * ROWB2))
+
+    bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
+
+#define PHASE_SYNC()                                               \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
+    __builtin_amdgcn_s_barrier();                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);
+#define MFMA(ACC, BF, AF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF, AF, ACC, 0, 0, 0)
+#define QUADRANT(M0, N0, FB, Gp)                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                  \
+    MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(Gp, 0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 2][N0 + 0], FB[0][0], fa[0][2]); MFMA(acc[M0 + 2][N0 + 1], FB[0][1], fa[0][2]);   \
+    MFMA(acc[M0 + 3][N0 + 0], FB[0][0], fa[0][3]); MFMA(acc[M0 + 3][N0 + 1], FB[0][1], fa[0][3]);   \
+    MFMA(acc[M0 + 0][N0 + 0], FB[1][0], fa[1][0]); MFMA(acc[M0 + 0][N0 + 1], FB[1][1], fa[1][0]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(Gp, 1);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
+    MFMA(acc[M0 + 2][N0 + 0], FB[1][0], fa[1][2]); MFMA(acc[M0 + 2][N0 + 1], FB[1][1], fa[1][2]);   \
+    MFMA(acc[M0 + 3][N0 + 0], FB[1][0], fa[1][3]); MFMA(acc[M0 + 3][N0 + 1], FB[1][1], fa[1][3]);   \
+    __builtin_amdgcn_s_setprio(0);
+
+    auto tile_body = [&](const char* sbuf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb0[ks][i] = B_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
+        }
+        PHASE_SYNC();
+        QUADRANT(0, 0, fb0, 2)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
+        PHASE_SYNC();
+        QUADRANT(0, 2, fb1, 3)
+        stage_prep();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
+        PHASE_SYNC();
+        QUADRANT(4, 2, fb1, 0)
+        PHASE_SYNC();
+        QUADRANT(4, 0, fb0, 1)
+    };
+
+    // prologue: the six groups the steady-state schedule has already issued when the first K-tile starts
+    stage_setup(0);
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
+    stage_prep();
+    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    float* stg = (float*)(smem + STG_OFF);
+    // one epilogue pass writes the 32 rows {wr*128 + mt*16 + 0..15} x 256 columns of the tile into the staging region
+    auto stage_rows = [&](auto mtag) {
+        constexpr int MT = decltype(mtag)::value;
+        const int lr = wr * 16 + frow;
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) {
+            const int ch = (wc * 16 + ntl * 4 + fq) ^ frow;
+            *(f32x4*)(stg + lr * 256 + ch * 4) = acc[MT][ntl];
+        }
+    };
+    int c_par = 0;
+#pragma unroll 1
+    for (int it = 0; it < n_my; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            tile_body(smem + c_par * BUF2);
+            c_par ^= 1;
+        }
+        // ---- epilogue of output tile `it`; the next tile's first K-tiles are already in flight
+        const int v = it * G + pw;
+        const int tm = v / tiles_n, tn = v - tm * tiles_n;
+        const int m0 = tm * BM2, n0 = tn * BN2;
+        if (EPI == 0) {
+            // bias / aux add / ReLU mask / ReLU, bf16 out, all strides 16-B aligned (checked by the launcher).
+            // All global LOADS (bias, aux) are issued before the first store: vmcnt retires in order, so a load issued
+            // after a store would wait for that store's write acknowledgement -- once per pass.
+            const int n_thr = n0 + (tid & 31) * 8;
+            const bool n_ok = n_thr < p.N;
+            f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 ax[16];
+            if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n_thr); bias1 = *(const f32x4*)(p.bias + n_thr + 4); }
+            // aux rows are fetched two passes ahead of their use (24 VGPRs live): a load issued before the stores of
+            // pass k only has to wait for stores of passes < k, which have long been acknowledged when pass k+2 reads it
+            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
+            auto load_aux = [&](auto mtag) {
+                constexpr int MT = decltype(mtag)::value;
+                if (MT < 8 && use_aux) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int lr = (tid >> 5) + j * 16;
+                        const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
+                        if (m < p.M && n_ok) ax[(MT & 7) * 2 + j] = *(const bf16x8*)((const T2*)p.aux + (int64_t)m * p.ldaux + n_thr);
+                    }
+                }
+            };
+            load_aux(std::integral_constant<int, 0>{});
+            load_aux(std::integral_constant<int, 1>{});
+            auto pass = [&](auto mtag) {
+                constexpr int MT = decltype(mtag)::value;
+                if (MT > 0) __syncthreads();
+                stage_rows(mtag);
+                load_aux(std::integral_constant<int, MT + 2>{});
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int lr = (tid >> 5) + j * 16, cg = tid & 31;
+                    const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
+                    if (m >= p.M || !n_ok) continue;
+                    const int sw = lr & 15;
+                    f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
+                    f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
+                    v0 += bias0; v1 += bias1;
+                    if (use_aux) {
+                        const bf16x8 a = ax[MT * 2 + j];
+                        if (p.flags & UMR_EPI_ADD_AUX) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] += (float)a[e]; v1[e] += (float)a[4 + e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] = (float)a[e] > 0.f ? v0[e] : 0.f; v1[e] = (float)a[4 + e] > 0.f ? v1[e] : 0.f; }
+                        }
+                    }
+                    if (p.act == UMR_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    }
+                    Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
+                }
+            };
+            pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
+            pass(std::integral_constant<int, 2>{}); pass(std::integral_constant<int, 3>{});
+            pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
+            pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
+        } else {
+            // generic epilogue (every flag / activation / remap of include/umr.h): ONE copy of the store code in a
+            // runtime loop over the passes -- unrolled it is ~100 KiB of instructions and runs out of the I-cache
+            const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.ldc2 & 7) == 0) && ((p.ldaux & 7) == 0) &&
+                                ((p.ldaux2 & 7) == 0);
+#pragma unroll 1
+            for (int mt = 0; mt < 8; ++mt) {
+                if (mt > 0) __syncthreads();
+                switch (mt) {
+                    case 0: stage_rows(std::integral_constant<int, 0>{}); break;
+                    case 1: stage_rows(std::integral_constant<int, 1>{}); break;
+                    case 2: stage_rows(std::integral_constant<int, 2>{}); break;
+                    case 3: stage_rows(std::integral_constant<int, 3>{}); break;
+                    case 4: stage_rows(std::integral_constant<int, 4>{}); break;
+                    case 5: stage_rows(std::integral_constant<int, 5>{}); break;
+                    case 6: stage_rows(std::integral_constant<int, 6>{}); break;
+                    default: stage_rows(std::integral_constant<int, 7>{}); break;
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int j = 0; j < 2; ++j) {
+                    const int lr = (tid >> 5) + j * 16, cg = tid & 31;
+                    const int m = m0 + (lr >> 4) * 128 + mt * 16 + (lr & 15), n = n0 + cg * 8;
+                    if (m >= p.M || n >= p.N) continue;
+                    const int sw = lr & 15;
+                    const f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
+                    const f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
+                    if (vec_ok) {
+                        epilogue_store8<T2>(p, m, n, v0, v1);
+                    } else {
+                        epilogue_store<T2>(p, m, n, v0);
+                        if (n + 4 < p.N) epilogue_store<T2>(p, m, n + 4, v1);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // the trailing (zero-fill) LDS-DMA groups must land before the LDS allocation is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef QUADRANT
+#undef MFMA
+#undef PHASE_SYNC
+#undef STAGE_DMA
+#undef A_FRAG
+#undef B_FRAG
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n = prop.multiProcessorCount;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+// eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
+int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
+    const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
+    const int64_t total = (int64_t)tiles_m * tiles_n;
+    int grid = num_cus();
+    if (total < grid) grid = (int)total;
+    dim3 g((unsigned)grid), b(512);
+    // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
+    const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
+    const bool fast_ep = vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
+                         !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
+                         (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+#define L256P(CV, EP)                                                                                                  \
+    do {                                                                                                               \
+        static bool set_ = false;                                                                                      \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); set_ = true; } \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP>), g, b, LDS2P, s, *d, tiles_n, (int)total);                      \
+    } while (0)
+    if (d->conv == 0) { if (fast_ep) L256P(0, 0); else L256P(0, 1); }
+    else { if (fast_ep) L256P(1, 0); else L256P(1, 1); }
+#undef L256P
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}

@@ -14,6 +14,7 @@
 // dbias rides along on workgroups with k-tile 0: one extra MFMA against an all-ones
 // fragment per n-tile and k-step.
 #include "umr_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -209,9 +210,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
         if constexpr (sizeof(T) == 2) {
             // lane 4q+pp of a 16-lane group addresses row q, columns 4pp..4pp+3 of the block
             const int q = li >> 2, pp = li & 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[4], fb[4];
+            // The transposed reads are inline asm (see gemm_tn256.hip): through the builtin the compiler orders them
+            // behind the LDS-DMA of the NEXT stage issued just above (s_waitcnt vmcnt(0)), which serialises the
+            // prefetch.  All 32 reads of the stage are issued, then consumed in two halves under counted lgkmcnt.
+            const unsigned lbase = (unsigned)(uintptr_t)UMR_LDS_PTR(sA);
+            u32x2 ra[2][4][2], rb[2][4][2];
+            auto issue_reads = [&](auto kstag) {
+                constexpr int ks = decltype(kstag)::value;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int r = ks * 32 + g * 8 + half * 4 + q;
@@ -220,16 +225,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
                     for (int i = 0; i < 4; ++i) {
                         const int ca = (wn * 64 + i * 16) / 8 + (pp >> 1);
                         const int cb = (wk * 64 + i * 16) / 8 + (pp >> 1);
-                        const char* pa = sA + r * ROWB + ((ca ^ sw) << 4) + ((pp & 1) << 3);
-                        const char* pb = sB + r * ROWB + ((cb ^ sw) << 4) + ((pp & 1) << 3);
-                        bf16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pa);
-                        bf16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)pb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            fa[i][half * 4 + e] = va[e];
-                            fb[i][half * 4 + e] = vb[e];
-                        }
+                        const unsigned pa = lbase + r * ROWB + ((ca ^ sw) << 4) + ((pp & 1) << 3);
+                        const unsigned pb = lbase + TILE + r * ROWB + ((cb ^ sw) << 4) + ((pp & 1) << 3);
+                        u32x2 ta, tb;
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ta) : "v"(pa));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tb) : "v"(pb));
+                        ra[ks][i][half] = ta;
+                        rb[ks][i][half] = tb;
                     }
+                }
+            };
+            auto mfmas = [&](auto kstag) {
+                constexpr int ks = decltype(kstag)::value;
+                bf16x8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32x4 ua = {ra[ks][i][0][0], ra[ks][i][0][1], ra[ks][i][1][0], ra[ks][i][1][1]};
+                    const u32x4 ub = {rb[ks][i][0][0], rb[ks][i][0][1], rb[ks][i][1][0], rb[ks][i][1][1]};
+                    fa[i] = __builtin_bit_cast(bf16x8, ua);
+                    fb[i] = __builtin_bit_cast(bf16x8, ub);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
@@ -244,7 +258,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
                     for (int nt = 0; nt < 4; ++nt)
                         accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[nt], accb[nt], 0, 0, 0);
                 }
-            }
+            };
+            // reads(ks0); wait; reads(ks1) fly behind MFMAs(ks0); wait; MFMAs(ks1)   (lgkmcnt is a 4-bit counter)
+            issue_reads(std::integral_constant<int, 0>{});
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            issue_reads(std::integral_constant<int, 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(std::integral_constant<int, 1>{});
         } else {
 #pragma unroll
             for (int ks = 0; ks < ROWS / 4; ++ks) {

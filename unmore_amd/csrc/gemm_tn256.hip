@@ -95,19 +95,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         soy = rem / p.Wo;
         sox = rem - soy * p.Wo;
     }
-    __amdgpu_buffer_rsrc_t rsY, rsX;
+    // descriptor bases / extents of the cursor stage.  They are kept as scalars and the descriptors are rebuilt at
+    // each issue from values forced into SGPRs: carried across the loop as 128-bit descriptors the compiler parks
+    // them in VGPRs and wraps every LDS-DMA in a readfirstlane waterfall loop.
+    const char* yb_s = nullptr;
+    const char* xb_s = nullptr;
+    unsigned ynrec_s = 0, xnrec_s = 0;
+    auto uni_ptr = [](const char* q_) -> const char* {
+        const uint64_t u = (uint64_t)q_;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (const char*)(((uint64_t)hi << 32) | lo);
+    };
     auto stage_prep = [&]() {
         const int mbase = m_begin + st_tile * 64;
         int rows_left = m_end - mbase;
         rows_left = rows_left < 0 ? 0 : (rows_left > 64 ? 64 : rows_left);
         const char* yb = (const char*)p.dY + ((int64_t)mbase * p.lddy + n0) * SZ;
-        rsY = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)(rows_left * p.lddy * SZ), 0x00020000);
+        yb_s = yb; ynrec_s = (unsigned)(rows_left * p.lddy * SZ);
         if (CONV == 0) {
             const char* xb = (const char*)p.X + ((int64_t)mbase * p.ldx + k0) * SZ;
-            rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)(rows_left * p.ldx * SZ), 0x00020000);
+            xb_s = xb; xnrec_s = (unsigned)(rows_left * p.ldx * SZ);
         } else {
             const char* xb = (const char*)p.X + ((((int64_t)sb * p.H + soy) * p.W + sox) - (p.W + 1)) * p.Cin * SZ;
-            rsX = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, rows_left > 0 ? 0x7FFFFFFFu : 0u, 0x00020000);
+            xb_s = xb; xnrec_s = rows_left > 0 ? 0x7FFFFFFFu : 0u;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -124,9 +134,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
         char* dst = smem + (st_tile & 1) * TBUF + G * TSUB + (w * 2 + I) * 1024;
         if (G == 0 || G == 3) {
+            const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)uni_ptr(yb_s), 0, __builtin_amdgcn_readfirstlane(ynrec_s), 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], 0, 0, 0);
         } else {
             const unsigned v = (CONV == 0) ? vo[G][I] : x_eff[G - 1][I];
+            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)uni_ptr(xb_s), 0, __builtin_amdgcn_readfirstlane(xnrec_s), 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(dst), 16, v, 0, 0, 0);
         }
         if (G == 3 && I == 1) ++st_tile;
@@ -164,14 +176,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         }
     }
     // (ks*32 rows keep the swizzle key: (32>>2)&3 == 0 and 32&3 == 0)
-#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(ptr))
-    auto read_frag = [&](const char* sub, int ad0, int ad1, int ks) -> bf16x8 {
-        const bf16x4 v0 = TR_READ(sub + ad0 + ks * 8192), v1 = TR_READ(sub + ad1 + ks * 8192);
-        bf16x8 f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { f[e] = v0[e]; f[4 + e] = v1[e]; }
-        return f;
+    // Transposed reads are issued as inline asm: through the builtin the compiler cannot tell them from the in-flight
+    // LDS-DMA writes and puts `s_waitcnt vmcnt(0)` in front of every group of reads, which drains the two-stage
+    // prefetch each phase.  Ordering is explicit instead: the reads of a phase are issued before PHASE_SYNC, whose
+    // counted vmcnt + barrier published the data one phase earlier and whose lgkmcnt(0) precedes their first use.
+    const unsigned lds0 = (unsigned)(uintptr_t)UMR_LDS_PTR(smem);
+    unsigned par_off = lds0;  // LDS address of the current stage buffer
+    auto read_frag = [&](auto offtag, int ad0, int ad1) -> bf16x8 {
+        constexpr int OFF = decltype(offtag)::value;
+        u32x2 v0, v1;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v0) : "v"(par_off + (unsigned)ad0), "n"(OFF));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v1) : "v"(par_off + (unsigned)ad1), "n"(OFF));
+        const u32x4 f = {v0[0], v0[1], v1[0], v1[1]};
+        return __builtin_bit_cast(bf16x8, f);
     };
+#define RF(SUBI, KS, AD) read_frag(std::integral_constant<int, (SUBI) * TSUB + (KS) * 8192>{}, AD[0], AD[1])
 
     bf16x8 fy[2][4], fx0[2][2], fx1[2][2];  // [ks][tile]: dY of the current n-half, X(kh0), X(kh1)
 
@@ -209,31 +228,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         }                                                                                           \
     }
 
-    auto stage_body = [&](const char* sbuf) {
+    auto stage_body = [&]() {
         // ---- phase 0: Q0 = (nh0, kh0)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int t = 0; t < 2; ++t) { fx0[0][t] = RF(1, 0, x_ad[t]); fx0[1][t] = RF(1, 1, x_ad[t]); }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) fx0[ks][t] = read_frag(sbuf + 1 * TSUB, x_ad[t][0], x_ad[t][1], ks);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fy[ks][t] = read_frag(sbuf + 0 * TSUB, y_ad[t][0], y_ad[t][1], ks);
-        }
+        for (int t = 0; t < 4; ++t) { fy[0][t] = RF(0, 0, y_ad[t]); fy[1][t] = RF(0, 1, y_ad[t]); }
         PHASE_SYNC();
         BIAS_ACC(0)
         QUADRANT(0, 0, fx0, 2)
         // ---- phase 1: Q1 = (nh0, kh1)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) fx1[ks][t] = read_frag(sbuf + 2 * TSUB, x_ad[t][0], x_ad[t][1], ks);
+        for (int t = 0; t < 2; ++t) { fx1[0][t] = RF(2, 0, x_ad[t]); fx1[1][t] = RF(2, 1, x_ad[t]); }
         PHASE_SYNC();
         QUADRANT(0, 2, fx1, 3)
         // ---- phase 2: Q2 = (nh1, kh1)
         stage_prep();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) fy[ks][t] = read_frag(sbuf + 3 * TSUB, y_ad[t][0], y_ad[t][1], ks);
+        for (int t = 0; t < 4; ++t) { fy[0][t] = RF(3, 0, y_ad[t]); fy[1][t] = RF(3, 1, y_ad[t]); }
         PHASE_SYNC();
         BIAS_ACC(4)
         QUADRANT(4, 2, fx1, 0)
@@ -252,13 +264,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     __builtin_amdgcn_s_barrier();
 
 #pragma unroll 1
-    for (int t = 0; t < nst; ++t) stage_body(smem + (t & 1) * TBUF);
+    for (int t = 0; t < nst; ++t) {
+        par_off = lds0 + (unsigned)((t & 1) * TBUF);
+        stage_body();
+    }
 #undef BIAS_ACC
 #undef QUADRANT
 #undef MFMA
 #undef PHASE_SYNC
 #undef STAGE_DMA
-#undef TR_READ
+#undef RF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- results: lane holds n = li, k = 4*g + reg of each tile

@@ -10,6 +10,8 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define UMR_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define UMR_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))

@@ -12,6 +12,7 @@
 // Implicit conv: the A row of output pixel m for tap (ky,kx) is the input pixel row
 // (iy,ix) = (oy*s+ky-1, ox*s+kx-1); out-of-image rows, K tails and M/N tails read a zero page.
 #include "umr_common.h"
+#include <type_traits>
 #include "gemm_epilogue.h"
 #include <stdlib.h>
 
@@ -27,7 +28,23 @@ template <typename T> struct Tr;
 template <> struct Tr<bf16_t> { static constexpr int EPC = 8, BK = 64; };
 template <> struct Tr<float> { static constexpr int EPC = 4, BK = 32; };
 
-template <typename T, int CONV>
+
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    typedef bf16x8 type;
+    static __device__ __forceinline__ type load(const bf16_t* q) { return *(const bf16x8*)q; }
+    static __device__ __forceinline__ void cvt(type t, f32x4& a, f32x4& b) {
+        a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        b = f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+    }
+};
+template <> struct Raw8<float> {
+    struct type { f32x4 a, b; };
+    static __device__ __forceinline__ type load(const float* q) { type t; t.a = *(const f32x4*)q; t.b = *(const f32x4*)(q + 4); return t; }
+    static __device__ __forceinline__ void cvt(type t, f32x4& a, f32x4& b) { a = t.a; b = t.b; }
+};
+
+template <typename T, int CONV, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Tr<T>::EPC, BK = Tr<T>::BK;
@@ -213,34 +230,112 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     // passes of 64 tile rows ([64][132] f32, padded against ds_write_b128 conflicts), then every thread handles
     // (row, 8 consecutive columns) tasks: bias / aux / C accesses are 16-byte vectors and each 128-column tile row
     // is written as one contiguous 256-byte (bf16) run -- full HBM lines instead of 32-byte fragments.
+    // Two instantiations keep the instruction footprint small (the fully inlined generic epilogue is ~50 KiB and
+    // runs out of the I-cache):
+    //   EPI 0  bias / aux add / ReLU mask / aux2 add / ReLU / C2 copies with 16-B aligned strides: unrolled, every
+    //          global LOAD issued before the first store (vmcnt retires in order -- a load behind a store waits for
+    //          the store's acknowledgement);
+    //   EPI 1  everything else (GELU / dGELU / tanh, row bias, f32 output, row remaps, odd strides): one copy of
+    //          the generic store code in runtime loops.
     constexpr int EP_LD = 132;
     float* stg = (float*)smem;
-    const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.ldc2 & 7) == 0) && ((p.ldaux & 7) == 0) &&
-                        ((p.ldaux2 & 7) == 0);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
+    auto stage_pass = [&](auto ptag) {
+        constexpr int PASS = decltype(ptag)::value;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
-            const int mt = pass * 2 + mh;
             const int lr = wr * 32 + mh * 16 + frow;  // staging row 0..63
 #pragma unroll
             for (int ntl = 0; ntl < 4; ++ntl)
-                *(f32x4*)(stg + lr * EP_LD + wc * 64 + ntl * 16 + fq * 4) = acc[mt][ntl];
+                *(f32x4*)(stg + lr * EP_LD + wc * 64 + ntl * 16 + fq * 4) = acc[PASS * 2 + mh][ntl];
         }
-        __syncthreads();
-        for (int task = tid; task < 64 * 16; task += 256) {
-            const int lr = task >> 4, c8 = (task & 15) * 8;
-            // staging row -> tile row: rows [wr*32, wr*32+32) of this pass are tile rows wr*64 + pass*32 + ..
-            const int trow = (lr >> 5) * 64 + pass * 32 + (lr & 31);
-            const int m = m0 + trow, n = n0 + c8;
-            if (m >= p.M || n >= p.N) continue;
-            const f32x4 v0 = *(const f32x4*)(stg + lr * EP_LD + c8), v1 = *(const f32x4*)(stg + lr * EP_LD + c8 + 4);
-            if (vec_ok) {
-                epilogue_store8<T>(p, m, n, v0, v1);
-            } else {
-                epilogue_store<T>(p, m, n, v0);
-                if (n + 4 < p.N) epilogue_store<T>(p, m, n + 4, v1);
+    };
+    if constexpr (EPI == 0) {
+        const int c8 = (tid & 15) * 8, n = n0 + c8;
+        const bool n_ok = n < p.N;
+        const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
+        const bool use_aux2 = (p.flags & UMR_EPI_ADD_AUX2) != 0;
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+        if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n); bias1 = *(const f32x4*)(p.bias + n + 4); }
+        typename Raw8<T>::type ra[8], rb2[8];
+        auto row_of = [&](int pass, int k) { const int lr = (tid >> 4) + k * 16; return m0 + (lr >> 5) * 64 + pass * 32 + (lr & 31); };
+        auto prefetch = [&](auto ptag) {
+            constexpr int PASS = decltype(ptag)::value;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int m = row_of(PASS, k);
+                if (m < p.M && n_ok) {
+                    if (use_aux) ra[PASS * 4 + k] = Raw8<T>::load((const T*)p.aux + (int64_t)m * p.ldaux + n);
+                    if (use_aux2) rb2[PASS * 4 + k] = Raw8<T>::load((const T*)p.aux2 + (int64_t)m * p.ldaux2 + n);
+                }
+            }
+        };
+        auto pass = [&](auto ptag) {
+            constexpr int PASS = decltype(ptag)::value;
+            __syncthreads();
+            stage_pass(ptag);
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int lr = (tid >> 4) + k * 16;
+                const int m = row_of(PASS, k);
+                if (m >= p.M || !n_ok) continue;
+                f32x4 v0 = *(const f32x4*)(stg + lr * EP_LD + c8), v1 = *(const f32x4*)(stg + lr * EP_LD + c8 + 4);
+                v0 += bias0; v1 += bias1;
+                if (use_aux) {
+                    f32x4 a0, a1;
+                    Raw8<T>::cvt(ra[PASS * 4 + k], a0, a1);
+                    if (p.flags & UMR_EPI_ADD_AUX) { v0 += a0; v1 += a1; }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = a0[e] > 0.f ? v0[e] : 0.f; v1[e] = a1[e] > 0.f ? v1[e] : 0.f; }
+                    }
+                }
+                if (use_aux2) {
+                    f32x4 a0, a1;
+                    Raw8<T>::cvt(rb2[PASS * 4 + k], a0, a1);
+                    v0 += a0; v1 += a1;
+                }
+                if (p.c2_mode == 2) Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
+                if (p.act == UMR_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                }
+                Vec8<T>::store((T*)p.C + (int64_t)m * p.ldc + n, v0, v1);
+                if (p.c2_mode == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                    Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
+                }
+            }
+        };
+        prefetch(std::integral_constant<int, 0>{});
+        if constexpr (sizeof(T) == 2) prefetch(std::integral_constant<int, 1>{});   // 16-bit: both passes fit in registers
+        pass(std::integral_constant<int, 0>{});
+        if constexpr (sizeof(T) != 2) prefetch(std::integral_constant<int, 1>{});
+        pass(std::integral_constant<int, 1>{});
+    } else {
+        const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.ldc2 & 7) == 0) && ((p.ldaux & 7) == 0) &&
+                            ((p.ldaux2 & 7) == 0);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+            if (pass == 0) stage_pass(std::integral_constant<int, 0>{});
+            else stage_pass(std::integral_constant<int, 1>{});
+            __syncthreads();
+#pragma unroll 1
+            for (int task = tid; task < 64 * 16; task += 256) {
+                const int lr = task >> 4, c8 = (task & 15) * 8;
+                // staging row -> tile row: rows [wr*32, wr*32+32) of this pass are tile rows wr*64 + pass*32 + ..
+                const int trow = (lr >> 5) * 64 + pass * 32 + (lr & 31);
+                const int m = m0 + trow, n = n0 + c8;
+                if (m >= p.M || n >= p.N) continue;
+                const f32x4 v0 = *(const f32x4*)(stg + lr * EP_LD + c8), v1 = *(const f32x4*)(stg + lr * EP_LD + c8 + 4);
+                if (vec_ok) {
+                    epilogue_store8<T>(p, m, n, v0, v1);
+                } else {
+                    epilogue_store<T>(p, m, n, v0);
+                    if (n + 4 < p.N) epilogue_store<T>(p, m, n + 4, v1);
+                }
             }
         }
     }
@@ -291,7 +386,16 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         if (kfit && (ov == 256 || (ov == 0 && big))) return umr_launch_gemm_nt256(d, s);
     }
     dim3 g((unsigned)grid), b(256);
-#define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_nt_kernel<T, CV>), g, b, LDS_BYTES, s, *d, tiles_n)
+    const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&
+                         (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) || (d->ldaux & 7) == 0) &&
+                         (!(d->flags & UMR_EPI_ADD_AUX2) || (d->ldaux2 & 7) == 0) && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
+                         !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
+                         (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+#define LAUNCH(T, CV)                                                                                   \
+    do {                                                                                                \
+        if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 0>), g, b, LDS_BYTES, s, *d, tiles_n);   \
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 1>), g, b, LDS_BYTES, s, *d, tiles_n);           \
+    } while (0)
     if (d->dtype == UMR_BF16) {
         if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
     } else {

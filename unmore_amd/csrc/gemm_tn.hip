@@ -312,21 +312,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
     }
 }
 
+// Fixed-order sum of the split slabs (deterministic).  VEC = 4: four consecutive k per thread as 16-byte accesses
+// (K, lddw multiples of 4); the split loop keeps four independent loads in flight.
+template <int VEC>
 __global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int64_t lddw, int N, int K,
                                  int splits, int accumulate, const float* __restrict__ bslab, float* __restrict__ dbias) {
     const int64_t total = (int64_t)N * K;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += slab[(int64_t)sp * total + i];
+    const int64_t nvec = total / VEC;
+    for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = iv * VEC;
         const int n = (int)(i / K), k = (int)(i - (int64_t)n * K);
         float* o = dW + (int64_t)n * lddw + k;
-        *o = accumulate ? (*o + s) : s;
+        if (VEC == 4) {
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+            const float* q = slab + i;
+            int sp = 0;
+            for (; sp + 4 <= splits; sp += 4) {
+                s0 += *(const f32x4*)(q + (int64_t)(sp + 0) * total);
+                s1 += *(const f32x4*)(q + (int64_t)(sp + 1) * total);
+                s2 += *(const f32x4*)(q + (int64_t)(sp + 2) * total);
+                s3 += *(const f32x4*)(q + (int64_t)(sp + 3) * total);
+            }
+            for (; sp < splits; ++sp) s0 += *(const f32x4*)(q + (int64_t)sp * total);
+            f32x4 r = (s0 + s1) + (s2 + s3);
+            if (accumulate) r += *(const f32x4*)o;
+            *(f32x4*)o = r;
+        } else {
+            float sacc = 0.f;
+            for (int sp = 0; sp < splits; ++sp) sacc += slab[(int64_t)sp * total + i];
+            *o = accumulate ? (*o + sacc) : sacc;
+        }
     }
     if (dbias != nullptr) {
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-            float s = 0.f;
-            for (int sp = 0; sp < splits; ++sp) s += bslab[(int64_t)sp * N + n];
-            dbias[n] = accumulate ? (dbias[n] + s) : s;
+            float sacc = 0.f;
+            for (int sp = 0; sp < splits; ++sp) sacc += bslab[(int64_t)sp * N + n];
+            dbias[n] = accumulate ? (dbias[n] + sacc) : sacc;
         }
     }
 }
@@ -432,10 +453,16 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     UMR_LAUNCH_CHECK();
     }
     const int64_t total = (int64_t)d->N * d->K;
-    int rb = (int)((total + 255) / 256);
-    if (rb > 4096) rb = 4096;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
-                       d->accumulate, bslab, d->dbias);
+    const bool v4 = (d->K % 4 == 0) && (d->lddw % 4 == 0) && (((uintptr_t)d->dW & 15) == 0);
+    int rb = (int)((total / (v4 ? 4 : 1) + 255) / 256);
+    if (rb > 8192) rb = 8192;
+    if (rb < 1) rb = 1;
+    if (v4)
+        hipLaunchKernelGGL(tn_reduce_kernel<4>, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
+                           d->accumulate, bslab, d->dbias);
+    else
+        hipLaunchKernelGGL(tn_reduce_kernel<1>, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
+                           d->accumulate, bslab, d->dbias);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -63,9 +63,22 @@ typedef struct umr_gemm_desc {
     int32_t a_rows_in, a_rows_out, a_row_off;
     int32_t c_rows_in, c_rows_out, c_row_off;
     int32_t aux_mod;
+    /* optional fused row reduction (the 1024 -> {1,2} output layer of a head, objectness_net.py:116,133, folded into the
+     * epilogue of the layer that produces its input): for each 256-column tile t of the output,
+     *   red_out[t][m][c] = sum_{n in tile t} C[m,n] * red_w[c][n]      (C as stored: after bias / activation / rounding)
+     * red_w: [red_c][N] f32, red_c in {1,2}; red_out: [ceil(N/256)][M][red_c] f32 partial sums, summed in fixed order by
+     * umr_head_out_finish.  no_store = 1 skips the store of C itself (inference: the activation is not needed again).
+     * Only the persistent 256x256 bf16 path implements it: call umr_gemm_nt_rowreduce_ok first; umr_gemm_nt fails
+     * (UMR_ERR_UNSUPPORTED / UMR_ERR_INVALID) rather than silently ignoring the request. */
+    const float* red_w;
+    float* red_out;
+    int32_t red_c;
+    int32_t no_store;
 } umr_gemm_desc;
 
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
+/* 1 if umr_gemm_nt would run d (ignoring red_*, no_store) on the path that implements the fused row reduction */
+int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d);
 
 /* ---- weight-gradient GEMM "TN" (reduction over rows) -----------------------
  * dW[N,K] (f32) = sum_m dY[m,N]^T . X[m,K]   (X rows shifted per tap when conv != 0,
@@ -133,6 +146,10 @@ int umr_cast(const void* src, void* dst, int64_t n, float scale, int dtype_in, i
 /* ---- head output layer 1024 -> {1,2} (+tanh / sine=4), NCHW f32 output (objectness_net.py:116,133-134) ---- */
 int umr_head_out_fwd(const void* h, const float* w, const float* bias, float* out, int64_t M, int K, int Cout, int HW, int act,
                      int dtype, umr_stream_t stream);
+/* second half of the same layer when its dot products were folded into the producing GEMM (umr_gemm_desc.red_*):
+ * out = act(bias + sum_t partials[t][m][c]), tiles added in index order (bitwise reproducible) */
+int umr_head_out_finish(const float* partials, int nparts, const float* bias, float* out, int64_t M, int Cout, int HW, int act,
+                        umr_stream_t stream);
 int64_t umr_head_out_bwd_workspace(int64_t M, int K);
 int umr_head_out_bwd(const void* h, const float* w, const float* dout, const float* yout, void* dh, float* dw, float* db,
                      void* workspace, int64_t workspace_bytes, int64_t M, int K, int Cout, int HW, int act, int relu_mask,

@@ -132,3 +132,44 @@ def test_invalid_arguments_raise():
         ops.gemm_nt(torch.zeros((4, 10), device=dev), torch.zeros((8, 10), device=dev))
     with pytest.raises(RuntimeError):
         ops.gemm_nt(torch.zeros((4, 8)), torch.zeros((8, 8)))  # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("M,C,relu", [(2 * 256 * 256, 2, True), (2 * 256 * 256 + 100, 1, False)])
+def test_gemm_nt_fused_row_reduction(M, C, relu):
+    """umr_gemm_desc.red_*: the head's 1024 -> {1,2} output layer folded into the producing GEMM's epilogue
+    (objectness_net.py:116,133).  Partials must reproduce (stored C) @ red_w^T; C itself is unchanged by the fusion."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    N, K = 1024, 512
+    A = _rnd((M // 64 + 1, K), torch.bfloat16, dev, 21).repeat(64, 1)[:M].contiguous()
+    A[::7] *= 0.5
+    B = _rnd((N, K), torch.bfloat16, dev, 22, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 23)
+    rw = _rnd((C, N), torch.float32, dev, 24, N ** -0.5)
+    act = L.ACT_RELU if relu else L.ACT_NONE
+    assert ops.gemm_nt(A, B, bias, act=act, query_rowreduce=True), "shape chosen to run on the persistent 256x256 path"
+    ref_c = ops.gemm_nt(A, B, bias, act=act)
+    out, parts = ops.gemm_nt(A, B, bias, act=act, red_w=rw)
+    assert torch.equal(out, ref_c)
+    assert parts.shape == (N // 256, M, C)
+    ref = ref_c.double() @ rw.double().t()
+    torch.testing.assert_close(parts.sum(0).double(), ref, atol=1e-4, rtol=1e-4)
+    # every column tile separately
+    for t in range(N // 256):
+        sl = slice(t * 256, (t + 1) * 256)
+        torch.testing.assert_close(parts[t].double(), ref_c[:, sl].double() @ rw[:, sl].double().t(), atol=1e-4, rtol=1e-4)
+    # inference form: C is not written at all
+    none, parts2 = ops.gemm_nt(A, B, bias, act=act, red_w=rw, no_store=True)
+    assert none is None and torch.equal(parts2, parts)
+    # finish kernel: fixed-order sum + bias + activation, NCHW
+    b4 = _rnd((C,), torch.float32, dev, 25)
+    if M % (256 * 256) == 0:
+        Bn = M // (256 * 256)
+        z = ops.head_out_finish(parts, b4, Bn, 256, 256, L.ACT_TANH)
+        zr = torch.tanh(ref + b4.double()).view(Bn, 256, 256, C).permute(0, 3, 1, 2)
+        torch.testing.assert_close(z.double(), zr, atol=1e-4, rtol=1e-4)
+    # a shape that runs on another path must refuse the request instead of ignoring it
+    small = _rnd((300, K), torch.bfloat16, dev, 26)
+    assert not ops.gemm_nt(small, B, bias, query_rowreduce=True)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(small, B, bias, red_w=rw)

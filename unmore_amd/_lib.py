@@ -23,7 +23,8 @@ class GemmDesc(ctypes.Structure):
                 ("flags", _i32), ("act", _i32), ("c2_mode", _i32), ("rows_per_batch", _i32),
                 ("conv", _i32), ("nb", _i32), ("H", _i32), ("W", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
                 ("a_rows_in", _i32), ("a_rows_out", _i32), ("a_row_off", _i32),
-                ("c_rows_in", _i32), ("c_rows_out", _i32), ("c_row_off", _i32), ("aux_mod", _i32)]
+                ("c_rows_in", _i32), ("c_rows_out", _i32), ("c_row_off", _i32), ("aux_mod", _i32),
+                ("red_w", _vp), ("red_out", _vp), ("red_c", _i32), ("no_store", _i32)]
 
 
 class GemmTnDesc(ctypes.Structure):
@@ -52,6 +53,8 @@ _lib = None
 _f32 = ctypes.c_float
 _SIGS = {
     "umr_gemm_nt": [_vp, _vp],
+    "umr_gemm_nt_rowreduce_ok": [_vp],
+    "umr_head_out_finish": [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "umr_gemm_tn": [_vp, _vp],
     "umr_gemm_tn_workspace": [_vp],
     "umr_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],

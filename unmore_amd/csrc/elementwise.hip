@@ -236,6 +236,23 @@ __global__ __launch_bounds__(256) void head_out_fwd_kernel(const T* __restrict__
     }
 }
 
+// second half of the fused output layer: the producing GEMM left per-256-column-tile partial sums
+// part[t][m][c] (umr_gemm_desc.red_out); add them in tile order, then bias + activation, NCHW f32 out
+__global__ __launch_bounds__(256) void head_out_finish_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int64_t M, int Cout, int HW, int act) {
+    const int64_t total = M * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / Cout;
+        const int c = (int)(i - m * Cout);
+        float v = 0.f;
+        for (int t = 0; t < nparts; ++t) v += part[(int64_t)t * total + i];
+        v += bias[c];
+        if (act == UMR_ACT_TANH) v = tanhf(v); else if (act == 4) v = sinf(v);
+        const int64_t b = m / HW, hw = m - b * HW;
+        out[(b * Cout + c) * HW + hw] = v;
+    }
+}
+
 // backward: g[m][c] = dout[b][c][hw] * act'(.);  dh[m][k] = sum_c g[m][c] w[c][k] (optionally * (h>0): fused ReLU
 // backward of the producer);  partial dW[c][k], db[c] per block -> workspace, reduced by head_out_reduce.
 template <typename T>
@@ -507,6 +524,15 @@ extern "C" int umr_head_out_fwd(const void* h, const float* w, const float* bias
     UMR_CHECK_ARG(h && w && bias && out && M > 0 && K > 0 && K % 4 == 0 && (Cout == 1 || Cout == 2) && HW > 0 && M % HW == 0, "head_out_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_fwd_kernel<T>, dim3(grid_for((M + 3) / 4, 1, 16384)), dim3(256), 0, s, (const T*)h, w, bias, out, M, K, Cout, HW, act));
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_head_out_finish(const float* partials, int nparts, const float* bias, float* out, int64_t M, int Cout, int HW, int act,
+                                   umr_stream_t stream) {
+    UMR_CHECK_ARG(partials && bias && out && nparts > 0 && M > 0 && (Cout == 1 || Cout == 2) && HW > 0 && M % HW == 0, "head_out_finish: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_out_finish_kernel, dim3(grid_for(M * Cout, 256, 8192)), dim3(256), 0, s, partials, nparts, bias, out, M, Cout, HW, act);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

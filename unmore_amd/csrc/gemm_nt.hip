@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 }  // namespace
 
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
+bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
 static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
     static int v = -1;
@@ -354,9 +355,23 @@ static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (bench
     return v;
 }
 
+static bool uses_256(const umr_gemm_desc* d) {
+    if (d->dtype != UMR_BF16) return false;
+    const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
+    const int ov = tile_override();
+    const bool kfit = d->conv == 0 ? (d->K % 64 == 0) : (d->Cin % 64 == 0);  // the 256 kernel has no K-tail path
+    const bool big = kfit && d->N >= 192 && t256 >= 2048;  // >= 8 full rounds of one 256x256 tile per CU (no tail, overheads amortised)
+    return kfit && (ov == 256 || (ov == 0 && big));
+}
+
+extern "C" int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d) {
+    if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    return (uses_256(d) && umr_nt256_rowreduce_path(d)) ? 1 : 0;
+}
+
 extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     UMR_CHECK_ARG(d != nullptr, "gemm_nt: null descriptor");
-    UMR_CHECK_ARG(d->A && d->B && d->C, "gemm_nt: null operand");
+    UMR_CHECK_ARG(d->A && d->B && (d->C || d->no_store), "gemm_nt: null operand");
     UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem");
     UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16, "gemm_nt: dtype");
     const int epc = d->dtype == UMR_BF16 ? 8 : 4;
@@ -378,13 +393,11 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     UMR_CHECK_ARG(grid < (1ll << 31), "gemm_nt: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == UMR_BF16) {
-        const int64_t t256 = (int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256);
-        const int ov = tile_override();
-        const bool kfit = d->conv == 0 ? (d->K % 64 == 0) : (d->Cin % 64 == 0);  // the 256 kernel has no K-tail path
-        const bool big = kfit && d->N >= 192 && t256 >= 2048;  // >= 8 full rounds of one 256x256 tile per CU (no tail, overheads amortised)
-        if (kfit && (ov == 256 || (ov == 0 && big))) return umr_launch_gemm_nt256(d, s);
+    if (d->red_w || d->no_store) {
+        UMR_CHECK_ARG(umr_gemm_nt_rowreduce_ok(d) == 1, "gemm_nt: fused row reduction / no_store requested on a path that does not implement it (umr_gemm_nt_rowreduce_ok)");
+        UMR_CHECK_ARG(!d->red_w || (d->red_out && (d->red_c == 1 || d->red_c == 2)), "gemm_nt: red_out / red_c");
     }
+    if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     dim3 g((unsigned)grid), b(256);
     const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&
                          (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) || (d->ldaux & 7) == 0) &&

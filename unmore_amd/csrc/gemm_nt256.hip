@@ -280,18 +280,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
     float* stg = (float*)smem;
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.ldc2 & 7) == 0) && ((p.ldaux & 7) == 0) &&
                         ((p.ldaux2 & 7) == 0);
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        __syncthreads();
+    // one copy of the store code in runtime loops: fully unrolled and inlined the generic epilogue is ~100 KiB of
+    // instructions per kernel and runs out of the I-cache (the persistent kernel, gemm_nt256p.hip, has the fast path)
+    auto stage_pass = [&](auto ptag) {
+        constexpr int PASS = decltype(ptag)::value;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
-            const int mt = pass * 2 + mh;
             const int lr = wr * 32 + mh * 16 + frow;
 #pragma unroll
             for (int ntl = 0; ntl < 4; ++ntl)
-                *(f32x4*)(stg + lr * EP_LD + wc * 64 + ntl * 16 + fq * 4) = acc[mt][ntl];
+                *(f32x4*)(stg + lr * EP_LD + wc * 64 + ntl * 16 + fq * 4) = acc[PASS * 2 + mh][ntl];
+        }
+    };
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        __syncthreads();
+        switch (pass) {
+            case 0: stage_pass(std::integral_constant<int, 0>{}); break;
+            case 1: stage_pass(std::integral_constant<int, 1>{}); break;
+            case 2: stage_pass(std::integral_constant<int, 2>{}); break;
+            default: stage_pass(std::integral_constant<int, 3>{}); break;
         }
         __syncthreads();
+#pragma unroll 1
         for (int task = tid; task < 64 * 32; task += 512) {
             const int lr = task >> 5, c8 = (task & 31) * 8;
             const int trow = (lr >> 5) * 128 + pass * 32 + (lr & 31);
@@ -311,6 +322,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
 }  // namespace
 
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip (persistent form)
+bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d);
+
+// would umr_launch_gemm_nt256 hand d to the persistent kernel's fast epilogue?
+bool umr_nt256_rowreduce_path(const umr_gemm_desc* d) {
+    const char* e = getenv("UMR_NT256_PERSIST");
+    if (e && atoi(e) == 0) return false;
+    return ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1) && umr_nt256p_fast_epilogue(d);
+}
 
 // launched from umr_gemm_nt (gemm_nt.hip) for bf16 problems large enough to fill the chip with 256x256 tiles
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
@@ -319,6 +338,7 @@ int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
         if (persist < 0) { const char* e = getenv("UMR_NT256_PERSIST"); persist = e ? atoi(e) : 1; }
         if (persist && ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1)) return umr_launch_gemm_nt256p(d, s);
     }
+    if (d->red_w || d->no_store) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store is only implemented by the persistent 256x256 path");
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     dim3 g((unsigned)grid), b(512);

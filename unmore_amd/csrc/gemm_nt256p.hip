@@ -267,6 +267,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
             bf16x8 ax[16];
             if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n_thr); bias1 = *(const f32x4*)(p.bias + n_thr + 4); }
+            // fused row reduction (umr_gemm_desc.red_*): this thread's 8 columns of the reduction weights
+            const bool red = p.red_w != nullptr;
+            f32x4 rw[2][2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                rw[c][0] = rw[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (red && c < p.red_c && n_ok) {
+                    rw[c][0] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n_thr);
+                    rw[c][1] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n_thr + 4);
+                }
+            }
             // aux rows are fetched two passes ahead of their use (24 VGPRs live): a load issued before the stores of
             // pass k only has to wait for stores of passes < k, which have long been acknowledged when pass k+2 reads it
             const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
@@ -289,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 stage_rows(mtag);
                 load_aux(std::integral_constant<int, MT + 2>{});
                 __syncthreads();
+                float red_acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int lr = (tid >> 5) + j * 16, cg = tid & 31;
@@ -312,7 +324,39 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
                     }
-                    Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
+                    if (!p.no_store) Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
+                    if (red) {
+                        // dot products with the values AS STORED (bf16-rounded), summed over the 32 lanes of this row:
+                        // DPP row shifts inside each 16-lane row, then row_bcast:15 into the odd rows -> lanes 31 / 63
+                        float sc[2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float a = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a += (float)(T2)v0[e] * rw[c][0][e] + (float)(T2)v1[e] * rw[c][1][e];
+                            sc[c] = a;
+                        }
+                        red_acc[j][0] = sc[0]; red_acc[j][1] = sc[1];
+                    }
+                }
+                if (red) {
+                    // (outside the per-task branch: DPP needs the whole wave; skipped rows contribute zeros)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int lr = (tid >> 5) + j * 16;
+                        const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            float a = red_acc[j][c];
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xF, 0xF, true));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x112, 0xF, 0xF, true));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x114, 0xF, 0xF, true));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x118, 0xF, 0xF, true));
+                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x142, 0xA, 0xF, false));
+                            if ((lane & 31) == 31 && m < p.M && c < p.red_c)
+                                p.red_out[((int64_t)tn * p.M + m) * p.red_c + c] = a;
+                        }
+                    }
                 }
             };
             pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
@@ -382,6 +426,14 @@ int num_cus() {
 
 }  // namespace
 
+// the epilogue class of the fast (EPI 0) instantiation
+bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
+    const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
+    return vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
+           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
+           (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+}
+
 // eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
@@ -390,10 +442,8 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     if (total < grid) grid = (int)total;
     dim3 g((unsigned)grid), b(512);
     // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
-    const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
-    const bool fast_ep = vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
-                         !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
-                         (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+    const bool fast_ep = umr_nt256p_fast_epilogue(d);
+    if ((d->red_w || d->no_store) && !fast_ep) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
 #define L256P(CV, EP)                                                                                                  \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \

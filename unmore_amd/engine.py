@@ -9,6 +9,8 @@ models/dpt/vit.py:165-201 (forward_flex), :86-90 (ProjectReadout), :104-145 +
 models/dpt/models.py:74-94 (DPT.forward), models/objectness_net.py:109-135,167-183
 (heads), timm Block semantics as restated in SURVEY.md section 8c.
 """
+import os
+
 import torch
 
 from . import _lib as L
@@ -92,6 +94,9 @@ def _pack_convT_dgrad(w, dt):  # -> [ci][(i,j,co)]
 def _rep_bias(b, reps):
     out = torch.empty(reps * b.numel(), dtype=torch.float32, device=b.device)
     return ops.permute4(b.detach(), out, (1, 1, reps, b.numel()), (0, 0, 0, 1))
+
+
+_FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch for benchmarking
 
 
 class Engine:
@@ -349,9 +354,19 @@ class Engine:
             h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
             h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
                              conv=1, act=act)
-            h3 = ops.gemm_nt(h2, self._w(P, f"{name}.{idx[2]}.weight", "lin"), self._f32(P, f"{name}.{idx[2]}.bias"), act=act)
+            w3, b3 = self._w(P, f"{name}.{idx[2]}.weight", "lin"), self._f32(P, f"{name}.{idx[2]}.bias")
             w4 = self._f32(P, f"{name}.{idx[3]}.weight")
-            out = ops.head_out_fwd(h3, w4.reshape(w4.shape[0], -1), self._f32(P, f"{name}.{idx[3]}.bias"), B, H, W, _ACT[lay["final"]])
+            w4 = w4.reshape(w4.shape[0], -1)
+            b4 = self._f32(P, f"{name}.{idx[3]}.bias")
+            if _FUSE_HEAD_OUT and ops.gemm_nt(h2, w3, b3, act=act, query_rowreduce=True):
+                # the 1024 -> {1,2} output layer rides in the epilogue of the GEMM that produces its input (one read of
+                # h3 saved); without saved activations (inference) h3 is not written at all
+                h3, parts = ops.gemm_nt(h2, w3, b3, act=act, red_w=w4.contiguous(), no_store=not save)
+                out = ops.head_out_finish(parts, b4, B, H, W, _ACT[lay["final"]])
+                del parts
+            else:
+                h3 = ops.gemm_nt(h2, w3, b3, act=act)
+                out = ops.head_out_fwd(h3, w4, b4, B, H, W, _ACT[lay["final"]])
             outs.append(out)
             if save:
                 heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=out))

@@ -46,9 +46,12 @@ def _workspace(nbytes, device):
 
 def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbias=None, rows_per_batch=0,
             act=L.ACT_NONE, mask_relu=False, mask_dgelu=False, c2_mode=0, out_f32=False,
-            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0):
+            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False):
     """C[M,N] = epi(A[M,K] . B[N,K]^T).  A: [M,K] (2-D, row stride lda) or NHWC
-    [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci))."""
+    [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci)).
+    red_w ([c, N] f32, c in {1,2}): fused row reduction (umr_gemm_desc.red_*) -> returns (C, partials [ceil(N/256), M, c]);
+    with no_store=True C is neither allocated nor written (returned as None).  query_rowreduce=True only asks the
+    library whether this call would run on the path that implements the reduction (returns bool, launches nothing)."""
     _need_gpu(A, B)
     dt = _DT[A.dtype]
     assert B.dtype == A.dtype
@@ -68,9 +71,10 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
         d.lda = A2.stride(0) if lda is None else lda
         assert A2.stride(1) == 1
     odt = torch.float32 if out_f32 else A.dtype
-    if out is None:
+    skip_c = no_store or query_rowreduce
+    if out is None and not skip_c:
         out = torch.empty((M_, N), dtype=odt, device=A.device)
-    assert out.dtype == odt and out.stride(-1) == 1
+    assert skip_c or (out.dtype == odt and out.stride(-1) == 1)
     flags = 0
     if bias is not None:
         assert bias.dtype == torch.float32
@@ -90,11 +94,11 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
         if out2 is None:
             out2 = torch.empty((M_, N), dtype=A.dtype, device=A.device)
         assert out2.dtype == A.dtype
-    o2d = out.reshape(-1, N) if out.is_contiguous() else out
+    o2d = None if out is None else (out.reshape(-1, N) if out.is_contiguous() else out)
     d.A, d.B, d.C, d.C2 = _p(A), _p(B), _p(out), _p(out2)
     d.bias, d.aux, d.aux2, d.rowbias = _p(bias), _p(aux), _p(aux2), _p(rowbias)
     d.ldb = B.stride(0)
-    d.ldc = o2d.stride(0) if o2d.dim() == 2 else N
+    d.ldc = o2d.stride(0) if (o2d is not None and o2d.dim() == 2) else N
     d.ldc2 = (out2.reshape(-1, N).stride(0) if out2 is not None else 0)
     d.ldaux = (aux.reshape(-1, N).stride(0) if aux is not None else 0)
     d.ldaux2 = (aux2.reshape(-1, N).stride(0) if aux2 is not None else 0)
@@ -105,7 +109,17 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     if c_remap is not None:
         d.c_rows_in, d.c_rows_out, d.c_row_off = c_remap
     d.aux_mod = aux_mod
+    if query_rowreduce:
+        return bool(L.lib().umr_gemm_nt_rowreduce_ok(ctypes.byref(d)))
+    partials = None
+    if red_w is not None:
+        assert red_w.dtype == torch.float32 and red_w.is_contiguous() and red_w.shape[1] == N and red_w.shape[0] in (1, 2)
+        partials = torch.empty(((N + 255) // 256, M_, red_w.shape[0]), dtype=torch.float32, device=A.device)
+        d.red_w, d.red_out, d.red_c = _p(red_w), _p(partials), red_w.shape[0]
+    d.no_store = 1 if no_store else 0
     L.check(_timed_call(d), "umr_gemm_nt")
+    if red_w is not None:
+        return out, partials
     return (out, out2) if c2_mode else out
 
 
@@ -281,6 +295,15 @@ def cast(src, dtype, scale=1.0, out=None):
 
 
 ACT_SINE = 4
+
+
+def head_out_finish(partials, bias, B, H, W, act):
+    """act(bias + sum over column tiles of the fused row-reduction partials) -> NCHW f32 [B, c, H, W]"""
+    nparts, M, Cout = partials.shape
+    assert M == B * H * W and partials.is_contiguous() and bias.dtype == torch.float32
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=partials.device)
+    L.check(L.lib().umr_head_out_finish(_p(partials), nparts, _p(bias), _p(out), M, Cout, H * W, act, _stream()), "umr_head_out_finish")
+    return out
 
 
 def head_out_fwd(h, w, bias, B, H, W, act):

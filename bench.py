@@ -102,6 +102,25 @@ def cpu_baseline(workload, seconds_budget=30.0):
                       f"(= {frac:.2f} of one {workload['H']}x{workload['W']} image), after 1 warm-up; value scaled to full-size images"}
 
 
+def measured_traffic(a):
+    """HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
+    figure of the committed rocprofv3 passes (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH doubled for gfx950; profiles/rNN_pmc_traffic.json).  null when no profile matches the run."""
+    if a.workload != "cfg2" or a.dtype != "bf16" or a.batch is not None:
+        return {"traffic": None}
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            for k in json.load(open(f))["kernels"]:
+                if k["kernel"] == "gemm_nt256p_kernel<1, 0>" and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
+                    return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
+                            "traffic_source": os.path.relpath(f, here), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
+        except (OSError, ValueError, KeyError):
+            continue
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,9 +217,10 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"},
             "train_tflops_per_gpu": 3 * fwd_gflop * B * a.steps / elapsed / 1e3,
             "final_loss": loss_val,
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel<conv3x3> bf16 512->512 (heads, fwd+dgrad)" if a.dtype == "bf16" else "gemm_nt_kernel<f32,conv3x3>",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt256p_kernel<conv3x3> bf16 512->512 (heads, fwd+dgrad)" if a.dtype == "bf16" else "gemm_nt_kernel<f32,conv3x3>",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop, "traffic": None},
+                         "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,
+                         **measured_traffic(a)},
         }
         if world == 1 and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in

@@ -35,26 +35,38 @@ def short(name):
     return name[:60]
 
 
-def durations(d):
-    acc = defaultdict(lambda: [0, 0.0])
-    for f in _find(d, "kernel_trace.csv"):
+# The persistent GEMM kernels launch one workgroup per CU whatever the problem, so the grid no longer tells shapes
+# apart: dispatches of one (kernel, grid) are split into a "large" class (duration >= half of the group's longest
+# dispatch) and a "small" class.  The large class of gemm_nt256p_kernel<1, 0> is the heads' 512->512 3x3 conv.
+def _rows(d, suffix):
+    for f in _find(d, suffix):
         for r in csv.DictReader(open(f)):
             grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
-            k = (short(r["Kernel_Name"]), grid)
-            acc[k][0] += 1
-            acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
+            yield (short(r["Kernel_Name"]), grid), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6, r
+
+
+def _classes(d, suffix, only=None):
+    rows = [x for x in _rows(d, suffix) if only is None or x[2].get("Counter_Name") == only]
+    longest = defaultdict(float)
+    for k, ms, _ in rows:
+        longest[k] = max(longest[k], ms)
+    for k, ms, r in rows:
+        yield k + ("large" if ms >= 0.5 * longest[k] else "small",), ms, r
+
+
+def durations(d):
+    acc = defaultdict(lambda: [0, 0.0])
+    for k, ms, _ in _classes(d, "kernel_trace.csv"):
+        acc[k][0] += 1
+        acc[k][1] += ms
     return acc
 
 
 def counters(d, name):
     acc = defaultdict(lambda: [0, 0.0])
-    for f in _find(d, "counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != name:
-                continue
-            k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
-            acc[k][0] += 1
-            acc[k][1] += float(r["Counter_Value"])
+    for k, _, r in _classes(d, "counter_collection.csv", only=name):
+        acc[k][0] += 1
+        acc[k][1] += float(r["Counter_Value"])
     return acc
 
 
@@ -71,7 +83,7 @@ def main():
     wr = counters(a.write, "WRITE_SIZE")
     rows = []
     for k, (n, ms) in dur.items():
-        row = {"kernel": k[0], "grid_threads": k[1], "launches": n, "avg_ms": ms / n, "total_ms": ms}
+        row = {"kernel": k[0], "grid_threads": k[1], "class": k[2], "launches": n, "avg_ms": ms / n, "total_ms": ms}
         if k in fe and fe[k][0]:
             row["fetch_bytes_per_launch"] = 2.0 * 1024.0 * fe[k][1] / fe[k][0]
         if k in wr and wr[k][0]:

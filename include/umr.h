@@ -40,7 +40,7 @@ enum umr_epi_flags {
     UMR_EPI_BIAS = 1, UMR_EPI_ADD_AUX = 2, UMR_EPI_MASK_RELU = 4, UMR_EPI_MASK_DGELU = 8,
     UMR_EPI_ADD_AUX2 = 16, UMR_EPI_OUT_F32 = 32, UMR_EPI_ROWBIAS = 64
 };
-enum umr_act { UMR_ACT_NONE = 0, UMR_ACT_RELU = 1, UMR_ACT_GELU = 2, UMR_ACT_TANH = 3 };
+enum umr_act { UMR_ACT_NONE = 0, UMR_ACT_RELU = 1, UMR_ACT_GELU = 2, UMR_ACT_TANH = 3, UMR_ACT_SIGMOID = 5 /* 4 = sine, head_out only */ };
 
 typedef struct umr_gemm_desc {
     const void* A;        /* [M,K] rows (lda) or NHWC input when conv != 0 */
@@ -197,6 +197,19 @@ int umr_linear_head_bwd_weight(const void* x, const float* dout, const float* yo
 /* C[i*sc_m + j*sc_n] (=|+=) sum_k A[i*sa_m + k*sa_k] * B[k*sb_k + j*sb_n]  (tiny f32 products, arbitrary strides) */
 int umr_small_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sa_m, int64_t sa_k, int64_t sb_k,
                        int64_t sb_n, int64_t sc_m, int64_t sc_n, int accumulate, umr_stream_t stream);
+
+/* ---- existence classifier: torchvision ResNet-50 + Linear(1000,1) + sigmoid in eval mode
+ * (models/objectness_net.py:205-223; callers object_reasoning.py:491-523, object_scoring.py:123-140).  Convolutions and
+ * Linear layers run on umr_gemm_nt; these are the remaining pieces.
+ * im2col_nchw: NCHW f32 image -> rows [B*Ho*Wo][ldk], K order (c, ky, kx) (= Conv2d weight order), tail zero: the 7x7 s2 p3 stem
+ * maxpool3x3s2: nn.MaxPool2d(kernel 3, stride 2, padding 1), NHWC
+ * bn_fold: eval-mode BatchNorm2d folded into the preceding conv's packed weight rows: w_out[co][k] = w[co][k]*s, b_out[co] =
+ *          beta - mean*s, s = gamma / sqrt(var + eps) */
+int umr_im2col_nchw(const float* images, void* out, int B, int C, int H, int W, int KH, int KW, int stride, int pad, int ldk,
+                    int dtype, umr_stream_t stream);
+int umr_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dtype, umr_stream_t stream);
+int umr_bn_fold(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps, void* w_out,
+                float* b_out, int Co, int K, int ldk, int dtype, umr_stream_t stream);
 
 #ifdef __cplusplus
 }

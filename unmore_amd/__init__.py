@@ -2,3 +2,4 @@
 from .objectness_net import ObjectnessNet  # noqa: F401
 from .trainer import TrainStep  # noqa: F401
 from .loss import objectness_loss  # noqa: F401
+from .binary_classifier import Binary_Classifier  # noqa: F401

@@ -11,6 +11,7 @@ CSRC = os.path.join(_HERE, "csrc")
 F32, BF16 = 0, 1
 EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS = 1, 2, 4, 8, 16, 32, 64
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
+ACT_SIGMOID = 5
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 
@@ -54,6 +55,9 @@ _f32 = ctypes.c_float
 _SIGS = {
     "umr_gemm_nt": [_vp, _vp],
     "umr_gemm_nt_rowreduce_ok": [_vp],
+    "umr_im2col_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_maxpool3x3s2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_bn_fold": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_head_out_finish": [_vp, _i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "umr_gemm_tn": [_vp, _vp],
     "umr_gemm_tn_workspace": [_vp],

@@ -43,6 +43,7 @@ __device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_log
     if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f); }
     else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
     else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) v[j] = tanhf(v[j]); }
+    else if (p.act == UMR_ACT_SIGMOID) { for (int j = 0; j < 4; ++j) v[j] = 1.f / (1.f + expf(-v[j])); }
     if (p.flags & UMR_EPI_OUT_F32) {
         float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
         if (full && ((p.ldc & 3) == 0)) *(f32x4*)cp = v;
@@ -111,6 +112,7 @@ __device__ __forceinline__ void epilogue_store8(const umr_gemm_desc& p, int m_lo
     if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); } }
     else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); } }
     else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) { v0[j] = tanhf(v0[j]); v1[j] = tanhf(v1[j]); } }
+    else if (p.act == UMR_ACT_SIGMOID) { for (int j = 0; j < 4; ++j) { v0[j] = 1.f / (1.f + expf(-v0[j])); v1[j] = 1.f / (1.f + expf(-v1[j])); } }
     if (p.flags & UMR_EPI_OUT_F32) Vec8<float>::store((float*)p.C + (int64_t)m * p.ldc + n, v0, v1);
     else Vec8<T>::store((T*)p.C + (int64_t)m * p.ldc + n, v0, v1);
     if (p.c2_mode == 1) {

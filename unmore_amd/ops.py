@@ -417,3 +417,37 @@ def linear_head_bwd_weight(x, dout, yout, act):
     L.check(L.lib().umr_linear_head_bwd_weight(_p(x), _p(dout), _p(yout), _p(out), _p(ws), ws.numel(), B, H, W, C, act, _DT[x.dtype],
                                                _stream()), "umr_linear_head_bwd_weight")
     return out
+
+
+# ---- existence classifier pieces (csrc/classifier.hip)
+def im2col_nchw(images, KH, KW, stride, pad, ldk, dtype):
+    """NCHW f32 [B,C,H,W] -> rows [B*Ho*Wo, ldk] (K order c,ky,kx; zero tail) for the 7x7 stem conv."""
+    _need_gpu(images)
+    assert images.dtype == torch.float32 and images.is_contiguous()
+    B, C, H, W = images.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.empty((B * Ho * Wo, ldk), dtype=dtype, device=images.device)
+    L.check(L.lib().umr_im2col_nchw(_p(images), _p(out), B, C, H, W, KH, KW, stride, pad, ldk, _DT[dtype], _stream()), "umr_im2col_nchw")
+    return out, Ho, Wo
+
+
+def maxpool3x3s2(x):
+    """nn.MaxPool2d(3, 2, 1) on NHWC [B,H,W,C]."""
+    _need_gpu(x)
+    assert x.is_contiguous()
+    B, H, W, C = x.shape
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+    L.check(L.lib().umr_maxpool3x3s2(_p(x), _p(y), B, H, W, C, _DT[x.dtype], _stream()), "umr_maxpool3x3s2")
+    return y
+
+
+def bn_fold(w2d, gamma, beta, mean, var, eps, ldk, dtype):
+    """Fold eval-mode BatchNorm into packed conv weight rows w2d [Co,K] f32 -> ([Co,ldk] dtype, bias [Co] f32)."""
+    _need_gpu(w2d)
+    assert w2d.dtype == torch.float32 and w2d.is_contiguous() and all(t.dtype == torch.float32 for t in (gamma, beta, mean, var))
+    Co, K = w2d.shape
+    w_out = torch.empty((Co, ldk), dtype=dtype, device=w2d.device)
+    b_out = torch.empty((Co,), dtype=torch.float32, device=w2d.device)
+    L.check(L.lib().umr_bn_fold(_p(w2d), _p(gamma), _p(beta), _p(mean), _p(var), eps, _p(w_out), _p(b_out), Co, K, ldk, _DT[dtype], _stream()),
+            "umr_bn_fold")
+    return w_out, b_out

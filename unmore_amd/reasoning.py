@@ -72,3 +72,16 @@ def update_bbox_with_boundary_fields(sdf_maps):
     d = torch.empty((B, 4), dtype=torch.float32, device=sdf.device)
     L.check(L.lib().umr_boundary_deltas(_p(sdf), _p(d), B, H, W, _stream()), "umr_boundary_deltas")
     return d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+
+
+def existence_checking(binary_classifier_model, image, proposals, num_img_per_batch=128):
+    """object_reasoning.py:491-523: crop every proposal, bilinear-resize to 128x128, score the crops
+    with the existence classifier in batches of 128.  image [3,H,W] f32 on the GPU; proposals [N,4] (x1,y1,x2,y2).
+    Returns the reference's dict: {'existence_scores': [N] f32 on the CPU}."""
+    scores = []
+    for i in range(0, len(proposals), num_img_per_batch):
+        crops, _ = crop_resize(image, proposals[i:i + num_img_per_batch], 128)
+        with torch.no_grad():
+            scores.append(binary_classifier_model(crops.to(torch.float32)))
+    class_scores = torch.cat(scores, dim=0).cpu()
+    return {"existence_scores": class_scores.squeeze(1)}

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
 // (K, lddw multiples of 4); the split loop keeps four independent loads in flight.
 template <int VEC>
 __global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dW, int64_t lddw, int N, int K,
-                                 int splits, int accumulate, const float* __restrict__ bslab, float* __restrict__ dbias) {
+                                 int splits, int accumulate, const float* __restrict__ bslab, float* __restrict__ dbias, int bias_parts) {
     const int64_t total = (int64_t)N * K;
     const int64_t nvec = total / VEC;
     for (int64_t iv = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += (int64_t)gridDim.x * blockDim.x) {
@@ -346,7 +346,7 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restri
     if (dbias != nullptr) {
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
             float sacc = 0.f;
-            for (int sp = 0; sp < splits; ++sp) sacc += bslab[(int64_t)sp * N + n];
+            for (int sp = 0; sp < bias_parts; ++sp) sacc += bslab[(int64_t)sp * N + n];
             dbias[n] = accumulate ? (dbias[n] + sacc) : sacc;
         }
     }
@@ -376,7 +376,7 @@ TnPlan tn_plan(const umr_gemm_tn_desc* d) {
         pl.tiles_n = (d->N + 255) / 256;
         pl.tiles_k = (d->K + 255) / 256;
         umr_tn256_plan(d, &pl.splits, &pl.rows_per_split);
-        pl.ws = ((int64_t)pl.splits * d->N * d->K + (int64_t)pl.splits * d->N) * 4;
+        pl.ws = ((int64_t)pl.splits * d->N * d->K + (int64_t)pl.splits * pl.tiles_k * d->N) * 4;  // bias partials per (split, k-tile)
         return pl;
     }
     pl.tiles_n = (d->N + TN_BN - 1) / TN_BN;
@@ -459,10 +459,10 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     if (rb < 1) rb = 1;
     if (v4)
         hipLaunchKernelGGL(tn_reduce_kernel<4>, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
-                           d->accumulate, bslab, d->dbias);
+                           d->accumulate, bslab, d->dbias, pl.big ? pl.splits * pl.tiles_k : pl.splits);
     else
         hipLaunchKernelGGL(tn_reduce_kernel<1>, dim3(rb), dim3(256), 0, s, slab, d->dW, d->lddw, d->N, d->K, pl.splits,
-                           d->accumulate, bslab, d->dbias);
+                           d->accumulate, bslab, d->dbias, pl.big ? pl.splits * pl.tiles_k : pl.splits);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

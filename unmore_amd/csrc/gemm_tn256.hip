@@ -50,7 +50,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     const int m_begin = split * rows_per_split;
     const int m_end = min(p.M, m_begin + rows_per_split);
     const int nst = (m_end - m_begin + 63) / 64;
-    const bool do_bias = (p.dbias != nullptr) && (tk == 0);
+    // dbias: the column sums of dY are spread over the k-tiles of a split (k-tile tk adds up the stages t with
+    // t % tiles_k == tk), so no workgroup carries the whole VALU cost and becomes the straggler of its round
+    const bool do_bias = (p.dbias != nullptr);
 
     // ---- staging roles: instruction i (0/1) of wave w covers sub-tile rows (w*2+i)*4 + lane/16, chunk position lane%16
     unsigned vo[4][2];      // per-lane voffsets (or OOB) of the four groups, relative to the stage's descriptor bases
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     MFMA(acc[N0 + 3][K0 + 0], FX[1][0], fy[1][3]); MFMA(acc[N0 + 3][K0 + 1], FX[1][1], fy[1][3]);   \
     __builtin_amdgcn_s_setprio(0);
 #define BIAS_ACC(N0)                                                                                \
-    if (do_bias && wk == 0) {                                                                       \
+    if (do_bias && bias_turn && wk == 0) {                                                          \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
             float s_ = 0.f;                                                                         \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                        \
@@ -228,6 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         }                                                                                           \
     }
 
+    bool bias_turn = false;
     auto stage_body = [&]() {
         // ---- phase 0: Q0 = (nh0, kh0)
 #pragma unroll
@@ -266,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
         par_off = lds0 + (unsigned)((t & 1) * TBUF);
+        bias_turn = (t % tiles_k) == tk;
         stage_body();
     }
 #undef BIAS_ACC
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
             float s_ = bsum[nt];
             s_ += __shfl_xor(s_, 16, 64);
             s_ += __shfl_xor(s_, 32, 64);
-            if (g == 0) bslab[(int64_t)split * p.N + n] = s_;
+            if (g == 0) bslab[((int64_t)split * tiles_k + tk) * p.N + n] = s_;
         }
     }
 }
@@ -330,7 +334,7 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
     const int tiles_n = (d->N + 255) / 256, tiles_k = (d->K + 255) / 256;
     dim3 g((unsigned)(tiles_n * tiles_k * splits)), b(512);
     static int mapmode = -1;
-    if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 2; }
+    if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 3; }
 #define LT(CV)                                                                                                         \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \

@@ -211,6 +211,16 @@ int umr_maxpool3x3s2(const void* x, void* y, int B, int H, int W, int C, int dty
 int umr_bn_fold(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps, void* w_out,
                 float* b_out, int Co, int K, int ldk, int dtype, umr_stream_t stream);
 
+/* ---- ground-truth synthesis on the device (datasets.py:158-159,171-222 without random crop) -------
+ * mask [B,H,W] u8 (non-zero = object) at the training resolution; center_xy [B,2] f32 (x, y) object centres in the same
+ * pixel coordinates, or NULL = bounding-box centre of each mask ((min+max)/2, datasets.py:158-159).
+ * sdf = DT(mask)/max - DT(1-mask)/max (second term only with use_bg_sdf) where DT is cv2.distanceTransform(u8, DIST_L2, 3)
+ * (OpenCV's 3x3 chamfer in 16.16 fixed point, a = 0.955, b = 1.3693); center_field [B,2,H,W] = normalize(mask *
+ * normalize((i - c_y, j - c_x))); saliency = mask > 0.  Empty masks give all-zero labels (datasets.py:128-138). */
+int64_t umr_label_synthesis_workspace(int B, int H, int W);
+int umr_label_synthesis(const uint8_t* mask, const float* center_xy, float* center_field, float* saliency, float* sdf,
+                        void* workspace, int64_t workspace_bytes, int B, int H, int W, int use_bg_sdf, umr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,24 @@
+"""Throughput of the on-device ground-truth synthesis at the training batch shape: python tools/labels_bench.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from unmore_amd.labels import synthesize_labels
+from unmore_amd.synth import ellipse_masks
+
+B, H, W = 64, 384, 384
+m = torch.from_numpy(np.asarray(ellipse_masks(B, H, W, seed=0)).astype(np.uint8)).cuda()
+for _ in range(2):
+    synthesize_labels(m)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    out = synthesize_labels(m)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"label synthesis B={B} {H}x{W}: {1e3 * dt:.2f} ms per batch = {B / dt:.0f} images/s (sdf range {float(out['sdf'].min()):.3f}..{float(out['sdf'].max()):.3f})")

@@ -33,7 +33,7 @@ constexpr int LDS2P = STG_OFF + STG_BYTES;  // 160 KiB
 
 typedef bf16_t T2;
 
-template <int CONV, int EPI>
+template <int CONV, int EPI, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
@@ -170,31 +170,63 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 
     bf16x8 fa[2][4], fb0[2][2], fb1[2][2];
 
-#define PHASE_SYNC()                                               \
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
+#define PHASE_SYNC_N(N)                                            \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");          \
     __builtin_amdgcn_s_barrier();                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
     __builtin_amdgcn_sched_barrier(0);
 #define MFMA(ACC, BF, AF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF, AF, ACC, 0, 0, 0)
-#define QUADRANT(M0, N0, FB, Gp)                                                                    \
+#define QUADRANT_D(M0, N0, FB, DMA_A, DMA_B)                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                  \
     MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
     MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    STAGE_DMA(Gp, 0);                                                                               \
+    DMA_A;                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     MFMA(acc[M0 + 2][N0 + 0], FB[0][0], fa[0][2]); MFMA(acc[M0 + 2][N0 + 1], FB[0][1], fa[0][2]);   \
     MFMA(acc[M0 + 3][N0 + 0], FB[0][0], fa[0][3]); MFMA(acc[M0 + 3][N0 + 1], FB[0][1], fa[0][3]);   \
     MFMA(acc[M0 + 0][N0 + 0], FB[1][0], fa[1][0]); MFMA(acc[M0 + 0][N0 + 1], FB[1][1], fa[1][0]);   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    STAGE_DMA(Gp, 1);                                                                               \
+    DMA_B;                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
     MFMA(acc[M0 + 2][N0 + 0], FB[1][0], fa[1][2]); MFMA(acc[M0 + 2][N0 + 1], FB[1][1], fa[1][2]);   \
     MFMA(acc[M0 + 3][N0 + 0], FB[1][0], fa[1][3]); MFMA(acc[M0 + 3][N0 + 1], FB[1][1], fa[1][3]);   \
     __builtin_amdgcn_s_setprio(0);
+#define QUADRANT(M0, N0, FB, Gp) QUADRANT_D(M0, N0, FB, STAGE_DMA(Gp, 0), STAGE_DMA(Gp, 1))
 
+#define PHASE_SYNC() PHASE_SYNC_N(6)
+    // Two-phase form of the same K-tile (PH2): phases (Q0,Q1) and (Q2,Q3) merged -- 2 barriers instead of 4.  All waves
+    // of the workgroup move in lock-step (read, wait, barrier, MFMA), and a wave cannot run far ahead of its queued
+    // MFMAs, so the matrix pipe idles for the read + barrier latency of every phase; longer phases halve that share.
+    // The counted wait of a phase publishes what the NEXT phase reads.  P0(t) reads A0,B0,B1 of tile t, P1(t) reads A1:
+    //   P1(t) issues A0,B0,B1 of tile t+2 (their regions were last read in P0(t)),  P0(t+1) issues A1 of tile t+2;
+    //   wait of P1(t): A0,B0,B1(t+1) landed, A1(t+1) may fly -> vmcnt(2);  wait of P0(t): A1(t) landed, A0,B0,B1(t+1) may
+    //   fly -> vmcnt(6).  Every group has one K-tile (two phases) to land.
+    auto tile_body2 = [&](const char* sbuf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb0[ks][i] = B_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
+        }
+        PHASE_SYNC_N(6);
+        QUADRANT_D(0, 0, fb0, STAGE_DMA(3, 0), STAGE_DMA(3, 1))
+        QUADRANT_D(0, 2, fb1, (void)0, (void)0)
+        stage_prep();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
+        PHASE_SYNC_N(2);
+        QUADRANT_D(4, 2, fb1, STAGE_DMA(0, 0); STAGE_DMA(0, 1), STAGE_DMA(1, 0); STAGE_DMA(1, 1))
+        QUADRANT_D(4, 0, fb0, STAGE_DMA(2, 0), STAGE_DMA(2, 1))
+    };
     auto tile_body = [&](const char* sbuf) {
+        if (PH2) { tile_body2(sbuf); return; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -228,6 +260,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
     stage_prep();
     STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    if (PH2) { STAGE_DMA(2, 0); STAGE_DMA(2, 1); }   // two-phase schedule: B1 of tile 1 is pre-issued as well
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -404,8 +437,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // the trailing (zero-fill) LDS-DMA groups must land before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef QUADRANT
+#undef QUADRANT_D
 #undef MFMA
 #undef PHASE_SYNC
+#undef PHASE_SYNC_N
 #undef STAGE_DMA
 #undef A_FRAG
 #undef B_FRAG
@@ -444,11 +479,20 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
     if ((d->red_w || d->no_store) && !fast_ep) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
+    // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs (tools/kbench.py) -> conv only
+    static int ph2_env = -2;
+    if (ph2_env == -2) { const char* e = getenv("UMR_NT256_PH2"); ph2_env = e ? atoi(e) : -1; }
+    const int ph2 = ph2_env >= 0 ? ph2_env : (d->conv == 1 ? 1 : 0);
 #define L256P(CV, EP)                                                                                                  \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); set_ = true; } \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP>), g, b, LDS2P, s, *d, tiles_n, (int)total);                      \
+        if (!set_) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P);  \
+            set_ = true;                                                                                               \
+        }                                                                                                              \
+        if (ph2) hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, true>), g, b, LDS2P, s, *d, tiles_n, (int)total);       \
+        else hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, false>), g, b, LDS2P, s, *d, tiles_n, (int)total);          \
     } while (0)
     if (d->conv == 0) { if (fast_ep) L256P(0, 0); else L256P(0, 1); }
     else { if (fast_ep) L256P(1, 0); else L256P(1, 1); }

@@ -28,7 +28,7 @@ constexpr int TLDS = 2 * TBUF;       // 128 KiB
 __device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
-template <int CONV>
+template <int CONV, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int ntiles, int rows_per_split,
                                                             float* slab, float* bslab, int mapmode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -196,30 +196,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 
     bf16x8 fy[2][4], fx0[2][2], fx1[2][2];  // [ks][tile]: dY of the current n-half, X(kh0), X(kh1)
 
-#define PHASE_SYNC()                                               \
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");               \
+#define PHASE_SYNC_N(N)                                            \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");          \
     __builtin_amdgcn_s_barrier();                                  \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
     __builtin_amdgcn_sched_barrier(0);
     // D[i = k_local][j = n_local] = sum_m X[m,k] dY[m,n]: first operand = X fragment, second = dY fragment
 #define MFMA(ACC, XF, YF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(XF, YF, ACC, 0, 0, 0)
-#define QUADRANT(N0, K0, FX, G)                                                                     \
+#define QUADRANT_D(N0, K0, FX, DMA_A, DMA_B)                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                  \
     MFMA(acc[N0 + 0][K0 + 0], FX[0][0], fy[0][0]); MFMA(acc[N0 + 0][K0 + 1], FX[0][1], fy[0][0]);   \
     MFMA(acc[N0 + 1][K0 + 0], FX[0][0], fy[0][1]); MFMA(acc[N0 + 1][K0 + 1], FX[0][1], fy[0][1]);   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    STAGE_DMA(G, 0);                                                                                \
+    DMA_A;                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     MFMA(acc[N0 + 2][K0 + 0], FX[0][0], fy[0][2]); MFMA(acc[N0 + 2][K0 + 1], FX[0][1], fy[0][2]);   \
     MFMA(acc[N0 + 3][K0 + 0], FX[0][0], fy[0][3]); MFMA(acc[N0 + 3][K0 + 1], FX[0][1], fy[0][3]);   \
     MFMA(acc[N0 + 0][K0 + 0], FX[1][0], fy[1][0]); MFMA(acc[N0 + 0][K0 + 1], FX[1][1], fy[1][0]);   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
-    STAGE_DMA(G, 1);                                                                                \
+    DMA_B;                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                              \
     MFMA(acc[N0 + 1][K0 + 0], FX[1][0], fy[1][1]); MFMA(acc[N0 + 1][K0 + 1], FX[1][1], fy[1][1]);   \
     MFMA(acc[N0 + 2][K0 + 0], FX[1][0], fy[1][2]); MFMA(acc[N0 + 2][K0 + 1], FX[1][1], fy[1][2]);   \
     MFMA(acc[N0 + 3][K0 + 0], FX[1][0], fy[1][3]); MFMA(acc[N0 + 3][K0 + 1], FX[1][1], fy[1][3]);   \
     __builtin_amdgcn_s_setprio(0);
+#define QUADRANT(N0, K0, FX, G) QUADRANT_D(N0, K0, FX, STAGE_DMA(G, 0), STAGE_DMA(G, 1))
+#define PHASE_SYNC() PHASE_SYNC_N(6)
 #define BIAS_ACC(N0)                                                                                \
     if (do_bias && bias_turn && wk == 0) {                                                          \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                             \
@@ -231,7 +233,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     }
 
     bool bias_turn = false;
+    // two-phase form (PH2; see gemm_nt256p.hip): P0 = (Q0,Q1) reads X0,Y0,X1 and issues Y1 of stage t+1; P1 = (Q2,Q3) reads
+    // Y1 and issues Y0,X0,X1 of stage t+2; waits vmcnt(6) / vmcnt(2)
+    auto stage_body2 = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fx0[0][t] = RF(1, 0, x_ad[t]); fx0[1][t] = RF(1, 1, x_ad[t]); }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fy[0][t] = RF(0, 0, y_ad[t]); fy[1][t] = RF(0, 1, y_ad[t]); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { fx1[0][t] = RF(2, 0, x_ad[t]); fx1[1][t] = RF(2, 1, x_ad[t]); }
+        PHASE_SYNC_N(6);
+        BIAS_ACC(0)
+        QUADRANT_D(0, 0, fx0, STAGE_DMA(3, 0), STAGE_DMA(3, 1))
+        QUADRANT_D(0, 2, fx1, (void)0, (void)0)
+        stage_prep();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { fy[0][t] = RF(3, 0, y_ad[t]); fy[1][t] = RF(3, 1, y_ad[t]); }
+        PHASE_SYNC_N(2);
+        BIAS_ACC(4)
+        QUADRANT_D(4, 2, fx1, STAGE_DMA(0, 0); STAGE_DMA(0, 1), STAGE_DMA(1, 0); STAGE_DMA(1, 1))
+        QUADRANT_D(4, 0, fx0, STAGE_DMA(2, 0), STAGE_DMA(2, 1))
+    };
     auto stage_body = [&]() {
+        if (PH2) { stage_body2(); return; }
         // ---- phase 0: Q0 = (nh0, kh0)
 #pragma unroll
         for (int t = 0; t < 2; ++t) { fx0[0][t] = RF(1, 0, x_ad[t]); fx0[1][t] = RF(1, 1, x_ad[t]); }
@@ -263,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
     stage_prep();
     STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+    if (PH2) { STAGE_DMA(2, 0); STAGE_DMA(2, 1); }
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -274,6 +299,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     }
 #undef BIAS_ACC
 #undef QUADRANT
+#undef QUADRANT_D
+#undef PHASE_SYNC_N
 #undef MFMA
 #undef PHASE_SYNC
 #undef STAGE_DMA
@@ -335,11 +362,18 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
     dim3 g((unsigned)(tiles_n * tiles_k * splits)), b(512);
     static int mapmode = -1;
     if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 3; }
+    static int ph2 = -1;
+    if (ph2 < 0) { const char* e = getenv("UMR_TN256_PH2"); ph2 = e ? atoi(e) : 1; }  // two-phase stage: +1-2 % (tools/kbench.py)
 #define LT(CV)                                                                                                         \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
-        if (!set_) { hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS); set_ = true; } \
-        hipLaunchKernelGGL((gemm_tn256_kernel<CV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);            \
+        if (!set_) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);                  \
+            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);                   \
+            set_ = true;                                                                                               \
+        }                                                                                                              \
+        if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode); \
+        else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);   \
     } while (0)
     if (d->conv == 0) LT(0); else LT(1);
 #undef LT

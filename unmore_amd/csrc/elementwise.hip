@@ -45,9 +45,10 @@ __device__ __forceinline__ float area_scale(int in, int out, int align) {
     return (float)in / (float)out;
 }
 
-template <typename T>
+// NV f32x4 vectors (4*NV channels) per thread: NV = 2 gives 16-byte bf16 accesses and half the index arithmetic
+template <typename T, int NV>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
-    const int cv = C >> 2;
+    const int cv = C / (4 * NV);
     const int64_t total = (int64_t)B * Ho * Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -60,12 +61,19 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
         float ly0, ly1, lx0, lx1;
         src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
         src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
-        const T* base = x + (int64_t)b * Hi * Wi * C + c * 4;
-        const f32x4 v00 = Vec4<T>::load(base + ((int64_t)y0 * Wi + x0) * C), v01 = Vec4<T>::load(base + ((int64_t)y0 * Wi + x1) * C);
-        const f32x4 v10 = Vec4<T>::load(base + ((int64_t)y1 * Wi + x0) * C), v11 = Vec4<T>::load(base + ((int64_t)y1 * Wi + x1) * C);
-        f32x4 o;
-        for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
-        Vec4<T>::store(y + idx * 4, o);
+        const T* base = x + (int64_t)b * Hi * Wi * C + c * 4 * NV;
+        const T* p00 = base + ((int64_t)y0 * Wi + x0) * C;
+        const T* p01 = base + ((int64_t)y0 * Wi + x1) * C;
+        const T* p10 = base + ((int64_t)y1 * Wi + x0) * C;
+        const T* p11 = base + ((int64_t)y1 * Wi + x1) * C;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f32x4 v00 = Vec4<T>::load(p00 + 4 * v), v01 = Vec4<T>::load(p01 + 4 * v);
+            const f32x4 v10 = Vec4<T>::load(p10 + 4 * v), v11 = Vec4<T>::load(p11 + 4 * v);
+            f32x4 o;
+            for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+            Vec4<T>::store(y + idx * 4 * NV + 4 * v, o);
+        }
     }
 }
 
@@ -78,9 +86,9 @@ __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, 
     if (hi > out - 1) hi = out - 1;
 }
 
-template <typename T>
+template <typename T, int NV>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
-    const int cv = C >> 2;
+    const int cv = C / (4 * NV);
     const int64_t total = (int64_t)B * Hi * Wi * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -92,8 +100,10 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
         int ylo, yhi, xlo, xhi;
         out_range(iy, sh, Ho, ylo, yhi);
         out_range(ix, sw, Wo, xlo, xhi);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const T* base = dy + (int64_t)b * Ho * Wo * C + c * 4;
+        f32x4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const T* base = dy + (int64_t)b * Ho * Wo * C + c * 4 * NV;
         for (int oy = ylo; oy <= yhi; ++oy) {
             int y0, y1; float ly0, ly1;
             src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
@@ -104,11 +114,13 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
                 src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
                 const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
                 if (wx == 0.f) continue;
-                const f32x4 g = Vec4<T>::load(base + ((int64_t)oy * Wo + ox) * C);
-                acc += g * (wy * wx);
+                const T* gp = base + ((int64_t)oy * Wo + ox) * C;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc[v] += Vec4<T>::load(gp + 4 * v) * (wy * wx);
             }
         }
-        Vec4<T>::store(dx + idx * 4, acc);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) Vec4<T>::store(dx + idx * 4 * NV + 4 * v, acc[v]);
     }
 }
 
@@ -431,8 +443,13 @@ extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, i
                                 umr_stream_t stream) {
     UMR_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_fwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
+    if (C % 8 == 0) {
+        const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
+    } else {
+        const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
+    }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }
@@ -441,8 +458,13 @@ extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi,
                                 umr_stream_t stream) {
     UMR_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
-    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
+    if (C % 8 == 0) {
+        const int64_t total = (int64_t)B * Hi * Wi * (C / 8);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
+    } else {
+        const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
+    }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -116,15 +116,35 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-__global__ void ln_bwd_reduce(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                              int nblocks, int D, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * D) return;
-    const int which = c / D, col = c - which * D;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[((int64_t)b * 2 + which) * D + col];
-    float* o = which == 0 ? dgamma : dbeta;
-    o[col] = accumulate ? o[col] + s : s;
+// fixed-order sum of the per-block partials: 64 columns x 4 interleaved block slices per workgroup, four independent
+// accumulators per thread, slices combined in index order (bitwise reproducible)
+__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int nblocks, int D, int accumulate) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < 2 * D) {
+        const int which = c / D, col = c - which * D;
+        const float* q = part + (int64_t)which * D + col;
+        const int64_t st = (int64_t)2 * D;
+        int b = sl;
+        for (; b + 12 < nblocks; b += 16) {
+            s0 += q[(int64_t)b * st];
+            s1 += q[(int64_t)(b + 4) * st];
+            s2 += q[(int64_t)(b + 8) * st];
+            s3 += q[(int64_t)(b + 12) * st];
+        }
+        for (; b < nblocks; b += 4) s0 += q[(int64_t)b * st];
+    }
+    sh[sl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && c < 2 * D) {
+        const float s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        const int which = c / D, col = c - which * D;
+        float* o = which == 0 ? dgamma : dbeta;
+        o[col] = accumulate ? o[col] + s : s;
+    }
 }
 
 }  // namespace
@@ -168,7 +188,7 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
                            (const float*)dres, (float*)dx, (float*)workspace, M, D, rpb);
     else return umr_set_error(UMR_ERR_INVALID, "layernorm_bwd: dtype");
     UMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 255) / 256), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, nb, D, accumulate);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 63) / 64), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, nb, D, accumulate);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

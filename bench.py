@@ -113,7 +113,7 @@ def measured_traffic(a):
     for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             for k in json.load(open(f))["kernels"]:
-                if k["kernel"] == "gemm_nt256p_kernel<1, 0>" and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
+                if k["kernel"].startswith("gemm_nt256p_kernel<1, 0") and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
                     return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
                             "traffic_source": os.path.relpath(f, here), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
         except (OSError, ValueError, KeyError):

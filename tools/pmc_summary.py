@@ -24,10 +24,11 @@ def _find(d, suffix):
 
 
 def short(name):
-    for tag in ("gemm_nt256p_kernel<0, 0>", "gemm_nt256p_kernel<0, 1>", "gemm_nt256p_kernel<1, 0>", "gemm_nt256p_kernel<1, 1>", "gemm_nt256_kernel<1>", "gemm_nt256_kernel<0>", "gemm_nt256_kernel<2>", "gemm_tn256_kernel<1>", "gemm_tn256_kernel<0>"):
-        if tag in name:
-            return tag
-    for tag in ("gemm_nt_kernel", "gemm_tn_kernel", "head_out_bwd", "head_out_fwd", "tn_reduce", "attn_bwd_dkv", "attn_bwd_dq",
+    import re
+    m = re.search(r"(gemm_nt256p_kernel|gemm_nt256_kernel|gemm_tn256_kernel)<[^>]*>", name)
+    if m:
+        return m.group(0)
+    for tag in ("gemm_nt_kernel", "gemm_tn_kernel", "head_out_bwd", "head_out_fwd", "head_out_finish", "tn_reduce", "attn_bwd_dkv", "attn_bwd_dq",
                 "attn_fwd", "bilinear_bwd", "bilinear_fwd", "ln_bwd_kernel", "ln_bwd_reduce", "ln_fwd", "adam_kernel",
                 "linear_head", "permute4", "segsum", "cast_kernel", "pixel_shuffle", "zero_stuff2", "patchify", "loss"):
         if tag in name:

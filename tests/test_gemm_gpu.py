@@ -173,3 +173,72 @@ def test_gemm_nt_fused_row_reduction(M, C, relu):
     assert not ops.gemm_nt(small, B, bias, query_rowreduce=True)
     with pytest.raises(RuntimeError):
         ops.gemm_nt(small, B, bias, red_w=rw)
+
+
+# ---- the large-tile (256x256) kernels only run on problems with >= 2048 tiles / many rows: parity at such sizes against
+# ---- torch fp32 ops of the same bf16 operands, computed on the GPU (the shapes are too large for a CPU fp64 reference)
+@pytest.mark.parametrize("M,N,K", [(270000, 512, 512), (2 * 256 * 256, 1024, 256)])
+def test_large_tile_nt_gemm(M, N, K):
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    A = _rnd((M // 16 + 1, K), torch.bfloat16, dev, 41).repeat(16, 1)[:M].contiguous()
+    A[::5] *= -0.5
+    B = _rnd((N, K), torch.bfloat16, dev, 42, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 43)
+    aux = _rnd((M, N), torch.bfloat16, dev, 44)
+    ref = A.float() @ B.float().t() + bias
+    assert ops.gemm_nt(A, B, bias, query_rowreduce=True), "shape chosen to run on the persistent 256x256 kernel"
+    torch.testing.assert_close(ops.gemm_nt(A, B, bias, act=L.ACT_RELU).float(), torch.relu(ref), atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(ops.gemm_nt(A, B, None, aux=aux, mask_relu=True).float(), (ref - bias) * (aux.float() > 0), atol=3e-2, rtol=3e-2)
+    out, pre = ops.gemm_nt(A, B, bias, act=L.ACT_GELU, c2_mode=2)   # generic epilogue class
+    torch.testing.assert_close(pre.float(), ref, atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(out.float(), F.gelu(ref), atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("nb,H,W,Cin,N", [(4, 256, 256, 64, 512), (9, 100, 300, 128, 320), (40, 128, 128, 64, 256)])
+def test_large_tile_conv3x3_fwd(nb, H, W, Cin, N):
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    x = _rnd((nb, H, W, Cin), torch.bfloat16, dev, 31)
+    w = _rnd((N, Cin, 3, 3), torch.bfloat16, dev, 32, (9 * Cin) ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 33)
+    wp = w.permute(0, 2, 3, 1).reshape(N, 9 * Cin).contiguous()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    out = ops.gemm_nt(x, wp, bias, conv=1)
+    torch.testing.assert_close(out.float(), ref, atol=3e-2, rtol=3e-2)
+    o4, r4 = out.float().view(nb, H, W, N), ref.view(nb, H, W, N)   # image borders: where the halo masks act
+    for a, b in ((o4[:, 0], r4[:, 0]), (o4[:, -1], r4[:, -1]), (o4[:, :, 0], r4[:, :, 0]), (o4[:, :, -1], r4[:, :, -1])):
+        torch.testing.assert_close(a, b, atol=3e-2, rtol=3e-2)
+    aux = _rnd((nb * H * W, N), torch.bfloat16, dev, 34)
+    out = ops.gemm_nt(x, wp, None, conv=1, aux=aux, mask_relu=True)
+    torch.testing.assert_close(out.float(), (ref - bias) * (aux.float() > 0), atol=3e-2, rtol=3e-2)
+
+
+def test_large_tile_tn_plain_and_conv():
+    from unmore_amd import ops
+    dev = _dev()
+    # plain: dW = dY^T X, dbias = column sums
+    M, N, K = 300000, 512, 256
+    dY = _rnd((M // 8, N), torch.bfloat16, dev, 51).repeat(8, 1)
+    X = _rnd((M // 8, K), torch.bfloat16, dev, 52).repeat(8, 1)
+    X[::3] *= -1.0
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    db = torch.empty((N,), dtype=torch.float32, device=dev)
+    ops.gemm_tn(dY, X, dW=dW, dbias=db)
+    ref = dY.float().t() @ X.float()
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(dW, ref, atol=2e-3 * scale, rtol=0)
+    refb = dY.float().sum(0)
+    torch.testing.assert_close(db, refb, atol=2e-3 * float(refb.abs().max()), rtol=0)
+    # accumulate form
+    ops.gemm_tn(dY, X, dW=dW, dbias=db, accumulate=True)
+    torch.testing.assert_close(dW, 2 * ref, atol=4e-3 * scale, rtol=0)
+    # conv weight gradient (stride 1, Wo % 64 == 0: the conv fast path of the 256 kernel)
+    nb, H, W, Cin, Co = 6, 256, 256, 64, 256
+    x = _rnd((nb, H, W, Cin), torch.bfloat16, dev, 53)
+    dy = _rnd((nb * H * W, Co), torch.bfloat16, dev, 54)
+    dwp = ops.gemm_tn(dy, x, conv=1)                                    # [Co][ky][kx][ci]
+    ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Co, Cin, 3, 3),
+                                      dy.float().view(nb, H, W, Co).permute(0, 3, 1, 2), padding=1)   # [Co,Cin,3,3]
+    got = dwp.view(Co, 3, 3, Cin).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref, atol=2e-3 * float(ref.abs().max()), rtol=0)

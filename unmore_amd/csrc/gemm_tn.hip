@@ -345,8 +345,16 @@ __global__ void tn_reduce_kernel(const float* __restrict__ slab, float* __restri
     }
     if (dbias != nullptr) {
         for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
-            float sacc = 0.f;
-            for (int sp = 0; sp < bias_parts; ++sp) sacc += bslab[(int64_t)sp * N + n];
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;   // four independent chains: the loop is latency-bound
+            int sp = 0;
+            for (; sp + 4 <= bias_parts; sp += 4) {
+                b0 += bslab[(int64_t)(sp + 0) * N + n];
+                b1 += bslab[(int64_t)(sp + 1) * N + n];
+                b2 += bslab[(int64_t)(sp + 2) * N + n];
+                b3 += bslab[(int64_t)(sp + 3) * N + n];
+            }
+            for (; sp < bias_parts; ++sp) b0 += bslab[(int64_t)sp * N + n];
+            const float sacc = (b0 + b1) + (b2 + b3);
             dbias[n] = accumulate ? (dbias[n] + sacc) : sacc;
         }
     }

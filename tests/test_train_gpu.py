@@ -189,3 +189,36 @@ def test_collapsed_sdf_head_equals_factored(dtype, H, W):
         a = torch.cat([p.grad.flatten() for _, p in nets["factored"][0].named_parameters() if p.grad is not None])
         b = torch.cat([p.grad.flatten() for _, p in nets["collapsed"][0].named_parameters() if p.grad is not None])
         assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
+
+
+def test_fused_head_output_layer_matches_unfused(monkeypatch):
+    """At >= 2048 output tiles the heads' last layer rides in the epilogue of the GEMM before it (engine.py heads section,
+    umr_gemm_desc.red_*): same outputs and gradients as the stand-alone head_out_fwd kernel, in training (h3 saved) and
+    inference (h3 never stored) form."""
+    from unmore_amd import engine, ops
+    net, _ = _net("dpt_tiny", "tiny", torch.bfloat16)
+    x = torch.from_numpy(uniform01("img:fuse", (2, 3, 256, 256))).cuda()
+    h2 = torch.zeros((2 * 256 * 256, 512), dtype=torch.bfloat16, device="cuda:0")
+    w3 = torch.zeros((1024, 512), dtype=torch.bfloat16, device="cuda:0")
+    assert ops.gemm_nt(h2, w3, torch.zeros(1024, device="cuda:0"), query_rowreduce=True), "size chosen to take the fused path"
+
+    def run(fuse):
+        monkeypatch.setattr(engine, "_FUSE_HEAD_OUT", fuse)
+        net.zero_grad(set_to_none=True)
+        out = net(images=x)
+        (out["center_fields"].square().mean() + out["sdf_maps"].abs().mean()).backward()
+        grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        with torch.no_grad():
+            inf = net.get_prediction(x)
+        return out, grads, inf
+
+    o1, g1, i1 = run(True)
+    o0, g0, i0 = run(False)
+    for k in ("center_fields", "sdf_maps"):
+        torch.testing.assert_close(o1[k], o0[k], atol=2e-3, rtol=0)     # bf16 h3 is identical; only the f32 summation order differs
+        torch.testing.assert_close(i1[k], o1[k].detach(), atol=0, rtol=0)  # no_store form = training form
+        torch.testing.assert_close(i0[k], o0[k].detach(), atol=0, rtol=0)
+    assert g1.keys() == g0.keys()
+    for n in g1:
+        scale = float(g0[n].abs().max()) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) <= 2e-2 * scale, n

@@ -242,3 +242,14 @@ def test_large_tile_tn_plain_and_conv():
                                       dy.float().view(nb, H, W, Co).permute(0, 3, 1, 2), padding=1)   # [Co,Cin,3,3]
     got = dwp.view(Co, 3, 3, Cin).permute(0, 3, 1, 2)
     torch.testing.assert_close(got, ref, atol=2e-3 * float(ref.abs().max()), rtol=0)
+    # Wo % 64 != 0: 64-row stages straddle image-row ends; M % 64 != 0: ragged last stage
+    for nb, H, W in ((50, 96, 96), (37, 70, 110)):
+        x = _rnd((nb, H, W, Cin), torch.bfloat16, dev, 55)
+        dy = _rnd((nb * H * W, Co), torch.bfloat16, dev, 56)
+        db = torch.empty((Co,), dtype=torch.float32, device=dev)
+        dwp = ops.gemm_tn(dy, x, conv=1, dbias=db)
+        ref = torch.nn.grad.conv2d_weight(x.float().permute(0, 3, 1, 2), (Co, Cin, 3, 3),
+                                          dy.float().view(nb, H, W, Co).permute(0, 3, 1, 2), padding=1)
+        torch.testing.assert_close(dwp.view(Co, 3, 3, Cin).permute(0, 3, 1, 2), ref, atol=2e-3 * float(ref.abs().max()), rtol=0)
+        refb = dy.float().sum(0)
+        torch.testing.assert_close(db, refb, atol=2e-3 * float(refb.abs().max()), rtol=0)

@@ -12,8 +12,8 @@
 // which are exactly the read sets of the quadrants Q0=(nh0,kh0) Q1=(nh0,kh1) Q2=(nh1,kh1) Q3=(nh1,kh0), so the
 // staging table of gemm_nt256.hip applies verbatim with A -> Y and B -> X.
 // Descriptor bases move with the stage (scalar arithmetic); per-lane voffsets are loop constants; the conv fast
-// path (stride 1, Wo % 64 == 0: a stage lies inside one image row) masks halo lanes once per stage.
-// Row tails of the split fall out of num_records (plain) and cannot occur on the conv fast path.
+// path (stride 1, Wo >= 64: a stage straddles at most one image-row end) masks halo lanes once per stage.
+// Row tails of the split fall out of num_records (plain) or are masked with the halo lanes (conv).
 // dbias: workgroups of k-tile 0 add up their dY fragments on the VALU (one f32 per n-tile and lane).
 #include "umr_common.h"
 #include <type_traits>
@@ -125,11 +125,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int ky = x_t[h][i] & 3, kx = x_t[h][i] >> 2;
-                    const bool ok = (unsigned)(soy + ky - 1) < (unsigned)p.H && (unsigned)(sox + x_r[h][i] + kx - 1) < (unsigned)p.W;
+                    // pixel of this lane's row: the 64-row stage may run over the end of an image row (Wo >= 64: once)
+                    int ox = sox + x_r[h][i], oy = soy;
+                    if (ox >= p.Wo) { ox -= p.Wo; ++oy; }
+                    if (oy >= p.Ho) oy = 0;   // first row of the next image (addresses are linear in the pixel index)
+                    const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.H && (unsigned)(ox + kx - 1) < (unsigned)p.W && x_r[h][i] < rows_left;
                     x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
                 }
             sox += 64;
-            if (sox >= p.Wo) { sox = 0; if (++soy >= p.Ho) { soy = 0; ++sb; } }
+            if (sox >= p.Wo) { sox -= p.Wo; if (++soy >= p.Ho) { soy = 0; ++sb; } }
         }
     };
     auto stage_issue = [&](auto gtag, auto itag) {
@@ -337,7 +341,7 @@ bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force) {
     if (d->dtype != UMR_BF16) return false;
     if (d->dy_rows_in > 0 || d->x_rows_in > 0) return false;
     if (d->conv == 2) return false;
-    if (d->conv == 1 && (d->Wo % 64) != 0) return false;
+    if (d->conv == 1 && d->Wo < 64) return false;   // a 64-row stage may straddle one image-row end, not two
     if (force) return true;  // structurally supported (tails are masked); the rest is a performance heuristic
     if (d->N < 192 || d->K < 192) return false;
     const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);

@@ -76,12 +76,14 @@ def main():
     ap.add_argument("--stats", required=True)
     ap.add_argument("--fetch", required=True)
     ap.add_argument("--write", required=True)
+    ap.add_argument("--mfma", default=None, help="directory of a --pmc MfmaUtil pass (optional)")
     ap.add_argument("--out", required=True)
     ap.add_argument("--command", default="")
     a = ap.parse_args()
     dur = durations(a.stats)
     fe = counters(a.fetch, "FETCH_SIZE")
     wr = counters(a.write, "WRITE_SIZE")
+    mf = counters(a.mfma, "MfmaUtil") if a.mfma else {}
     rows = []
     for k, (n, ms) in dur.items():
         row = {"kernel": k[0], "grid_threads": k[1], "class": k[2], "launches": n, "avg_ms": ms / n, "total_ms": ms}
@@ -89,6 +91,8 @@ def main():
             row["fetch_bytes_per_launch"] = 2.0 * 1024.0 * fe[k][1] / fe[k][0]
         if k in wr and wr[k][0]:
             row["write_bytes_per_launch"] = 1024.0 * wr[k][1] / wr[k][0]
+        if k in mf and mf[k][0]:
+            row["mfma_util_percent"] = mf[k][1] / mf[k][0]   # rocprofv3 MfmaUtil = MFMA busy cycles / (GPU active cycles x SIMDs)
         if "fetch_bytes_per_launch" in row and "write_bytes_per_launch" in row:
             row["hbm_bytes_per_launch"] = row["fetch_bytes_per_launch"] + row["write_bytes_per_launch"]
         rows.append(row)

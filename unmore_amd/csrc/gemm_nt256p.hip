@@ -473,8 +473,21 @@ bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
     const int64_t total = (int64_t)tiles_m * tiles_n;
-    int grid = num_cus();
-    if (total < grid) grid = (int)total;
+    // One workgroup fits a CU (160 KiB LDS).  The grid is a small multiple of the CU count, not exactly the CU count: if
+    // some CUs are busy when the kernel starts (an RCCL all-reduce of the previous gradient bucket runs beside backward),
+    // a one-workgroup-per-CU launch would leave the workgroups that did not get a CU to run a second full round after the
+    // others -- up to 2x the kernel time.  With several shorter workgroups per CU the dispatcher balances them itself; a
+    // workgroup still walks >= 32 tiles, so the cross-tile prefetch keeps its value, and workgroups that run together on
+    // one XCD still own neighbouring tiles (pw in the kernel).  UMR_NT256_WG_PER_CU overrides the factor.
+    static int wg_per_cu = -1;
+    if (wg_per_cu < 0) { const char* e = getenv("UMR_NT256_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 0; }
+    const int cus = num_cus();
+    int64_t kf = wg_per_cu > 0 ? wg_per_cu : total / ((int64_t)cus * 32);
+    if (kf < 1) kf = 1;
+    if (kf > 8) kf = 8;
+    int64_t grid64 = cus * kf;
+    if (total < grid64) grid64 = total;
+    const int grid = (int)grid64;
     dim3 g((unsigned)grid), b(512);
     // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
     const bool fast_ep = umr_nt256p_fast_epilogue(d);

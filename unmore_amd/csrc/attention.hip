@@ -17,8 +17,6 @@
 // (no atomics: bitwise reproducible).
 // hd^-0.5 = 1/8 is folded into Q (K in the dK/dV kernel): exact in bf16 and f32.
 #include "umr_common.h"
-#include <type_traits>
-#include <stdlib.h>
 
 namespace {
 
@@ -203,187 +201,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
-// ------------------------------------------------------------------ forward, bf16, 32x32 MFMA form
-// One wave = 32 query rows, workgroup = 4 waves = 128 query rows, K/V tiles of 64 keys.
-//   S^T[key][q] = K . Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q rows from registers, scaled by 1/8):
-//   a lane owns ONE query column (q = lane % 32) and 16 of each 32-key tile's scores (keys 8c + 4h + 0..3, h = lane / 32),
-//   so the softmax row statistics are in-lane reductions plus one exchange with lane ^ 32.
-//   P^T is the B operand of O^T[d][q] += V^T[d][key] . P^T[key][q] without an LDS round trip: the lane needs 8 consecutive
-//   keys per k-step and owns 4 of them; v_permlane32_swap on the packed bf16 pairs supplies the other 4 (one swap fills
-//   both halves' operands).  V^T fragments come from the row-major V tile by ds_read_b64_tr_b16.
-// The next K/V tile is fetched into registers while the current one is multiplied (loads issued after the barrier,
-// LDS written after the next one).
-constexpr int KT2 = 64;
-
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
-    bf16x2 t;
-    t[0] = (bf16_t)a;
-    t[1] = (bf16_t)b;
-    return __builtin_bit_cast(unsigned, t);
-}
-
-__global__ __launch_bounds__(256) void attn_fwd32_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-                                                         int N, int heads) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * KT2 * 128];
-    char* sK = smem;
-    char* sV = smem + KT2 * 128;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ql = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-    const int D = heads * HD;
-    const int64_t ld = 3 * (int64_t)D;
-    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
-    const bf16_t* kb = qb + D;
-    const bf16_t* vb = qb + 2 * D;
-    const int q = blockIdx.x * 128 + w * 32 + ql;
-    // Q fragments: B operand of k-step s = d chunk 2s + hh (8 values), scaled by 1/8 (exact)
-    bf16x8 qf[4];
-#pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s_][e] = (bf16_t)0.f;
-        if (q < N) {
-            const bf16x8 t = *(const bf16x8*)(qb + (int64_t)q * ld + (2 * s_ + hh) * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[s_][e] = (bf16_t)((float)t[e] * 0.125f);
-        }
-    }
-    f32x16 o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // staging: 64 rows x 8 chunks of 16 B per tensor = 512 chunks, 2 per thread
-    // two register sets: the loads of tile t+2 are issued while tile t is multiplied (one tile of latency cover was not
-    // enough: a workgroup's K/V stream is a dependent chain of HBM/L2 round trips otherwise)
-    uint4 rk[2][2], rv[2][2];
-    auto gload = [&](auto settag, int k0) {
-        constexpr int S = decltype(settag)::value;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + j * 256, r = c >> 3, ch = c & 7;
-            rk[S][j] = uint4{0u, 0u, 0u, 0u};
-            rv[S][j] = uint4{0u, 0u, 0u, 0u};
-            if (k0 + r < N) {
-                rk[S][j] = *(const uint4*)(kb + (int64_t)(k0 + r) * ld + ch * 8);
-                rv[S][j] = *(const uint4*)(vb + (int64_t)(k0 + r) * ld + ch * 8);
-            }
-        }
-    };
-    auto swrite = [&](auto settag) {
-        constexpr int S = decltype(settag)::value;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int c = tid + j * 256, r = c >> 3, ch = c & 7;
-            const int off = r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
-            *(uint4*)(sK + off) = rk[S][j];
-            *(uint4*)(sV + off) = rv[S][j];
-        }
-    };
-    gload(std::integral_constant<int, 0>{}, 0);
-    gload(std::integral_constant<int, 1>{}, KT2);
-    for (int k0 = 0, par = 0; k0 < N; k0 += KT2, par ^= 1) {
-        __syncthreads();
-        if (par == 0) swrite(std::integral_constant<int, 0>{}); else swrite(std::integral_constant<int, 1>{});
-        __syncthreads();
-        if (k0 + 2 * KT2 < N) {
-            if (par == 0) gload(std::integral_constant<int, 0>{}, k0 + 2 * KT2); else gload(std::integral_constant<int, 1>{}, k0 + 2 * KT2);
-        }
-        // ---- S^T = K Q^T: two 32-key tiles x four 16-wide k-steps
-        f32x16 sc[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sc[kt][e] = 0.f;
-            const int r = kt * 32 + ql;
-            const int sw = (r >> 1) & 7;
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const bf16x8 kf = *(const bf16x8*)(sK + r * 128 + (((2 * s_ + hh) ^ sw) << 4));
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], sc[kt], 0, 0, 0);
-            }
-        }
-        // ---- online softmax: this lane's 32 scores of query q; the other 32 live in lane ^ 32
-        if (k0 + KT2 > N) {   // only the last tile has keys past the end (wave-uniform)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v)
-                    if (k0 + kt * 32 + 8 * (v >> 2) + 4 * hh + (v & 3) >= N) sc[kt][v] = -INFINITY;
-        }
-        float mx = sc[0][0];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) mx = fmaxf(mx, sc[kt][v]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        // p = exp(s - m) as exp2(s * log2e - m * log2e): one fma + one v_exp_f32 per score
-        constexpr float LOG2E = 1.4426950408889634f;
-        const float m2 = m_new * LOG2E;
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { sc[kt][v] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][v], LOG2E, -m2)); ps += sc[kt][v]; }
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // some row maximum moved: rescale the accumulators
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-        }
-        // ---- O^T += V^T P^T: k-step ks = 2 kt + u covers keys 32 kt + 16 u + 8 hh + 0..7
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                // blocks c = 2u (x) and 2u+1 (y) of this lane, packed; after the swap the low half holds [own x | partner x],
-                // the high half [partner y | own y] = 8 consecutive keys each
-                unsigned x0 = pack_bf16x2(sc[kt][8 * u + 0], sc[kt][8 * u + 1]), x1 = pack_bf16x2(sc[kt][8 * u + 2], sc[kt][8 * u + 3]);
-                unsigned y0 = pack_bf16x2(sc[kt][8 * u + 4], sc[kt][8 * u + 5]), y1 = pack_bf16x2(sc[kt][8 * u + 6], sc[kt][8 * u + 7]);
-                const u32x2 r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-                const u32x2 r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-                const u32x4 pw = {r0[0], r1[0], r0[1], r1[1]};
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-                const int krow = kt * 32 + u * 16 + 8 * hh;   // first of this lane's 8 keys
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    // V^T fragment: row = d = 32 dt + ql, 8 keys from krow: two transposed 4-key reads
-                    const int g16 = (lane >> 4) & 1, i16 = lane & 15;
-                    const int qq = i16 >> 2, pp = i16 & 3;
-                    const int col = dt * 32 + g16 * 16 + pp * 4;     // 4 d values addressed by this lane
-                    const int ra = krow + qq, rb = krow + 4 + qq;
-                    const char* a0 = sV + ra * 128 + ((((col >> 3)) ^ ((ra >> 1) & 7)) << 4) + ((col & 4) << 1);
-                    const char* a1 = sV + rb * 128 + ((((col >> 3)) ^ ((rb >> 1) & 7)) << 4) + ((col & 4) << 1);
-                    const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                    const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a1);
-                    bf16x8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
-                }
-            }
-    }
-    l_run += __shfl_xor(l_run, 32, 64);
-    if (q < N) {
-        const float inv = 1.0f / l_run;
-        bf16_t* orow = out + ((int64_t)b * N + q) * D + h * HD;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 v = {o[dt][4 * c + 0] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv};
-                Vec4<bf16_t>::store(orow + dt * 32 + 8 * c + 4 * hh, v);
-            }
-        if (hh == 0 && lse) lse[(int64_t)bh * N + q] = m_run + logf(l_run);
-    }
-}
-
 // ------------------------------------------------------------------ backward prep: Dq = rowsum(dO * O)
 template <typename T>
 __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ dq_sum, int B, int N,
@@ -530,10 +347,7 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
     hipStream_t s = (hipStream_t)stream;
     dim3 g((N + 63) / 64, B * heads), b(256);
-    static int v32 = -1;
-    if (v32 < 0) { const char* e = getenv("UMR_ATTN_FWD32"); v32 = e ? atoi(e) : 1; }
-    if (dtype == UMR_BF16 && v32) hipLaunchKernelGGL(attn_fwd32_kernel, dim3((N + 127) / 128, B * heads), b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
-    else if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+    if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
     else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads);
     else return umr_set_error(UMR_ERR_INVALID, "attention_fwd: dtype");
     UMR_LAUNCH_CHECK();

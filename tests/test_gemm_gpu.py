@@ -177,7 +177,7 @@ def test_gemm_nt_fused_row_reduction(M, C, relu):
 
 # ---- the large-tile (256x256) kernels only run on problems with >= 2048 tiles / many rows: parity at such sizes against
 # ---- torch fp32 ops of the same bf16 operands, computed on the GPU (the shapes are too large for a CPU fp64 reference)
-@pytest.mark.parametrize("M,N,K", [(270000, 512, 512), (2 * 256 * 256, 1024, 256)])
+@pytest.mark.parametrize("M,N,K", [(270000, 512, 512), (2 * 256 * 256, 1024, 256), (530001, 200, 64)])
 def test_large_tile_nt_gemm(M, N, K):
     from unmore_amd import ops, _lib as L
     dev = _dev()

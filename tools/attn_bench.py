@@ -20,3 +20,13 @@ fl = 4.0 * B * H * N * N * 64
 print(f"attention fwd : {t:7.3f} ms  {fl / t / 1e9:7.1f} TFLOP/s")
 t = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H), n=20)
 print(f"attention bwd : {t:7.3f} ms  {2.5 * fl / t / 1e9:7.1f} TFLOP/s (10 N^2 D flops)")
+
+# LayerNorm at the same token count
+x = torch.randn(B * N, D, generator=g).to(dev).bfloat16()
+gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+y, mu, rs = ops.layernorm_fwd(x, gam, bet)
+t = timeit(lambda: ops.layernorm_fwd(x, gam, bet), n=20)
+print(f"layernorm fwd : {t:7.3f} ms  {2 * x.numel() * 2 / t / 1e9:6.2f} TB/s")
+dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+t = timeit(lambda: ops.layernorm_bwd(dout, x, gam, mu, rs, dg, db, dres=dout), n=20)
+print(f"layernorm bwd : {t:7.3f} ms  {4 * x.numel() * 2 / t / 1e9:6.2f} TB/s")

@@ -46,6 +46,84 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+// bf16 fast path (D % 8 == 0): 16-byte loads (8 channels per lane and chunk) and TWO rows per wave, so that twice the bytes
+// are in flight per wave and the two rows' reductions interleave (the 4-channel form measured 1.6 TB/s)
+
+__device__ __forceinline__ void ld8(const bf16_t* p, f32x4& a, f32x4& b) {
+    const bf16x8 t = *(const bf16x8*)p;
+    a = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    b = f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+}
+__device__ __forceinline__ void st8(bf16_t* p, f32x4 a, f32x4 b) {
+    bf16x8 t;
+    t[0] = (bf16_t)a[0]; t[1] = (bf16_t)a[1]; t[2] = (bf16_t)a[2]; t[3] = (bf16_t)a[3];
+    t[4] = (bf16_t)b[0]; t[5] = (bf16_t)b[1]; t[6] = (bf16_t)b[2]; t[7] = (bf16_t)b[3];
+    *(bf16x8*)p = t;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (row0 >= M) return;
+    const int nc = D >> 3;
+    f32x4 va[2][NCH], vb[2][NCH];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const bool rok = row0 + r < M;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            va[r][i] = vb[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rok && c < nc) ld8(x + (int64_t)(row0 + r) * D + c * 8, va[r][i], vb[r][i]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            s[r] += (va[r][i][0] + va[r][i][1] + va[r][i][2] + va[r][i][3]) + (vb[r][i][0] + vb[r][i][1] + vb[r][i][2] + vb[r][i][3]);
+    float mu[2], rs[2];
+    mu[0] = wave_sum(s[0]) / D;
+    mu[1] = wave_sum(s[1]) / D;
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = i * 64 + lane;
+            if (c < nc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d0 = va[r][i][j] - mu[r], d1 = vb[r][i][j] - mu[r]; q[r] += d0 * d0 + d1 * d1; }
+            }
+        }
+    rs[0] = rsqrtf(wave_sum(q[0]) / D + eps);
+    rs[1] = rsqrtf(wave_sum(q[1]) / D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+            const f32x4 g0 = *(const f32x4*)(gamma + c * 8), g1 = *(const f32x4*)(gamma + c * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c * 8), b1 = *(const f32x4*)(beta + c * 8 + 4);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (row0 + r >= M) continue;
+                f32x4 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { o0[j] = (va[r][i][j] - mu[r]) * rs[r] * g0[j] + b0[j]; o1[j] = (vb[r][i][j] - mu[r]) * rs[r] * g1[j] + b1[j]; }
+                st8(y + (int64_t)(row0 + r) * D + c * 8, o0, o1);
+            }
+        }
+    }
+    if (lane == 0) {
+        mean[row0] = mu[0]; rstd[row0] = rs[0];
+        if (row0 + 1 < M) { mean[row0 + 1] = mu[1]; rstd[row0 + 1] = rs[1]; }
+    }
+}
+
 // dx = rstd * (dy*g - mean(dy*g) - xhat*mean(dy*g*xhat)); optional residual gradient add.
 // Per-block partial dgamma/dbeta go to workspace [gridDim.x][2][D] (reduced by ln_bwd_reduce).
 template <typename T>
@@ -116,6 +194,104 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
+// bf16 fast path of the backward (see ln_fwd_bf16x8_kernel): 16-byte loads, two rows per wave and iteration
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                            bf16_t* __restrict__ dx, float* __restrict__ part, int M, int D,
+                                                            int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [4 waves][2][D]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nc = D >> 3;
+    f32x4 ag[NCH][2], ab[NCH][2], gm[NCH][2];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            ag[i][hlf] = ab[i][hlf] = gm[i][hlf] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nc) gm[i][hlf] = *(const f32x4*)(gamma + c * 8 + hlf * 4);
+        }
+    }
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int row = r0 + 2 * wv; row < r1; row += 8) {
+        f32x4 xh[2][NCH][2], dg[2][NCH][2];
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const bool rok = row + r < r1;
+            const float mu = rok ? mean[row + r] : 0.f;
+            rsv[r] = rok ? rstd[row + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 64 + lane;
+                f32x4 xv[2], dv[2];
+                xv[0] = xv[1] = dv[0] = dv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (rok && c < nc) {
+                    ld8(x + (int64_t)(row + r) * D + c * 8, xv[0], xv[1]);
+                    ld8(dy + (int64_t)(row + r) * D + c * 8, dv[0], dv[1]);
+                }
+#pragma unroll
+                for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float xhv = (rok && c < nc) ? (xv[hlf][j] - mu) * rsv[r] : 0.f;
+                        const float dgv = dv[hlf][j] * gm[i][hlf][j];
+                        xh[r][i][hlf][j] = xhv;
+                        dg[r][i][hlf][j] = dgv;
+                        s1[r] += dgv;
+                        s2[r] += dgv * xhv;
+                        ag[i][hlf][j] += dv[hlf][j] * xhv;
+                        ab[i][hlf][j] += dv[hlf][j];
+                    }
+            }
+        }
+        s1[0] = wave_sum(s1[0]) / D; s1[1] = wave_sum(s1[1]) / D;
+        s2[0] = wave_sum(s2[0]) / D; s2[1] = wave_sum(s2[1]) / D;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (row + r >= r1) continue;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int c = i * 64 + lane;
+                if (c < nc) {
+                    f32x4 o[2];
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[hlf][j] = rsv[r] * (dg[r][i][hlf][j] - s1[r] - xh[r][i][hlf][j] * s2[r]);
+                    if (dres != nullptr) {
+                        f32x4 q0, q1;
+                        ld8(dres + (int64_t)(row + r) * D + c * 8, q0, q1);
+                        o[0] += q0; o[1] += q1;
+                    }
+                    st8(dx + (int64_t)(row + r) * D + c * 8, o[0], o[1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = i * 64 + lane;
+        if (c < nc) {
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                *(f32x4*)(sh + (wv * 2 + 0) * D + c * 8 + hlf * 4) = ag[i][hlf];
+                *(f32x4*)(sh + (wv * 2 + 1) * D + c * 8 + hlf * 4) = ab[i][hlf];
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int which = c / D, col = c - which * D;
+        float s_ = 0.f;
+        for (int k = 0; k < 4; ++k) s_ += sh[(k * 2 + which) * D + col];
+        part[((int64_t)blockIdx.x * 2 + which) * D + col] = s_;
+    }
+}
+
 // fixed-order sum of the per-block partials: 64 columns x 4 interleaved block slices per workgroup, four independent
 // accumulators per thread, slices combined in index order (bitwise reproducible)
 __global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -155,7 +331,11 @@ extern "C" int umr_layernorm_fwd(const void* x, const float* gamma, const float*
     UMR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 256 * LN_MAXV, "layernorm_fwd: D must be a multiple of 8, <= 2048");
     hipStream_t s = (hipStream_t)stream;
     dim3 g((M + 3) / 4), b(256);
-    if (dtype == UMR_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    if (dtype == UMR_BF16 && D % 8 == 0 && D <= 1024)
+        hipLaunchKernelGGL(ln_fwd_bf16x8_kernel<2>, dim3((M + 7) / 8), b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    else if (dtype == UMR_BF16 && D % 8 == 0 && D <= 2048)
+        hipLaunchKernelGGL(ln_fwd_bf16x8_kernel<4>, dim3((M + 7) / 8), b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
+    else if (dtype == UMR_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
     else if (dtype == UMR_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, g, b, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
     else return umr_set_error(UMR_ERR_INVALID, "layernorm_fwd: dtype");
     UMR_LAUNCH_CHECK();
@@ -180,7 +360,13 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
     nb = (M + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)8 * D * 4;
-    if (dtype == UMR_BF16)
+    if (dtype == UMR_BF16 && D % 8 == 0 && D <= 1024)
+        hipLaunchKernelGGL(ln_bwd_bf16x8_kernel<2>, dim3(nb), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                           (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, D, rpb);
+    else if (dtype == UMR_BF16 && D % 8 == 0 && D <= 2048)
+        hipLaunchKernelGGL(ln_bwd_bf16x8_kernel<4>, dim3(nb), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
+                           (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, D, rpb);
+    else if (dtype == UMR_BF16)
         hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(nb), dim3(256), lds, s, (const bf16_t*)dy, (const bf16_t*)x, gamma, mean, rstd,
                            (const bf16_t*)dres, (bf16_t*)dx, (float*)workspace, M, D, rpb);
     else if (dtype == UMR_F32)

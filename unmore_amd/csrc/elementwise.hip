@@ -304,16 +304,35 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const T* __restrict__
     if (t == 0) { p[2 * K] = b0; p[2 * K + 1] = b1; }
 }
 
-__global__ void head_out_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K, int Cout) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// fixed-order sum of the per-block partials: 64 entries x 4 interleaved block slices per workgroup, four independent
+// accumulation chains per thread (the one-thread-per-entry loop over 2048 blocks took 0.7 ms)
+__global__ __launch_bounds__(256) void head_out_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                              int nblocks, int K, int Cout) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cl;
     const int per = 2 * K + 2;
-    if (idx >= per) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * per + idx];
-    if (idx < K) dw[idx] = s;
-    else if (idx < 2 * K) { if (Cout == 2) dw[idx] = s; }
-    else if (idx == 2 * K) db[0] = s;
-    else if (Cout == 2) db[1] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < per) {
+        const float* q = part + idx;
+        int b = sl;
+        for (; b + 12 < nblocks; b += 16) {
+            s0 += q[(int64_t)b * per];
+            s1 += q[(int64_t)(b + 4) * per];
+            s2 += q[(int64_t)(b + 8) * per];
+            s3 += q[(int64_t)(b + 12) * per];
+        }
+        for (; b < nblocks; b += 4) s0 += q[(int64_t)b * per];
+    }
+    sh[sl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && idx < per) {
+        const float s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        if (idx < K) dw[idx] = s;
+        else if (idx < 2 * K) { if (Cout == 2) dw[idx] = s; }
+        else if (idx == 2 * K) db[0] = s;
+        else if (Cout == 2) db[1] = s;
+    }
 }
 
 // ---------------------------------------------------------------- fused loss (train_objectness_net.py:215-254)
@@ -577,7 +596,7 @@ extern "C" int umr_head_out_bwd(const void* h, const float* w, const float* dout
     hipStream_t s = (hipStream_t)stream;
     DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)h, w, dout, yout, (T*)dh, (float*)workspace, M, K, Cout, HW, act, relu_mask, rpb));
     UMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_out_reduce_kernel, dim3((2 * K + 2 + 255) / 256), dim3(256), 0, s, (const float*)workspace, dw, db, nb, K, Cout);
+    hipLaunchKernelGGL(head_out_reduce_kernel, dim3((2 * K + 2 + 63) / 64), dim3(256), 0, s, (const float*)workspace, dw, db, nb, K, Cout);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -190,8 +190,16 @@ __global__ void segsum_kernel(const T* __restrict__ x, TO* __restrict__ out, int
         const int c = (int)(idx % C);
         const int r = (int)(idx / C);
         const T* p = x + (int64_t)r * seg_stride + c;
-        float s = 0.f;
-        for (int k = 0; k < reps; ++k) s += to_f32<T>(p[(int64_t)k * rep_stride]);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains (the loop is latency-bound)
+        int k = 0;
+        for (; k + 4 <= reps; k += 4) {
+            s0 += to_f32<T>(p[(int64_t)(k + 0) * rep_stride]);
+            s1 += to_f32<T>(p[(int64_t)(k + 1) * rep_stride]);
+            s2 += to_f32<T>(p[(int64_t)(k + 2) * rep_stride]);
+            s3 += to_f32<T>(p[(int64_t)(k + 3) * rep_stride]);
+        }
+        for (; k < reps; ++k) s0 += to_f32<T>(p[(int64_t)k * rep_stride]);
+        float s = (s0 + s1) + (s2 + s3);
         if (accumulate) s += to_f32<TO>(out[idx]);
         out[idx] = from_f32<TO>(s);
     }

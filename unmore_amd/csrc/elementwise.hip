@@ -48,31 +48,36 @@ __device__ __forceinline__ float area_scale(int in, int out, int align) {
 // NV f32x4 vectors (4*NV channels) per thread: NV = 2 gives 16-byte bf16 accesses and half the index arithmetic
 template <typename T, int NV>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+    // grid.y = (b, oy) pairs (strided), grid.x x 256 threads = the (ox, channel-vector) pairs of one output row: the
+    // per-thread index arithmetic is one 32-bit division (the flat 64-bit form spent more time dividing than loading)
     const int cv = C / (4 * NV);
-    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv);
-        int64_t r = idx / cv;
-        const int ox = (int)(r % Wo); r /= Wo;
-        const int oy = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        int y0, y1, x0, x1;
-        float ly0, ly1, lx0, lx1;
+    for (int by = blockIdx.y; by < B * Ho; by += gridDim.y) {
+        const int b = by / Ho, oy = by - b * Ho;
+        int y0, y1;
+        float ly0, ly1;
         src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
-        src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
-        const T* base = x + (int64_t)b * Hi * Wi * C + c * 4 * NV;
-        const T* p00 = base + ((int64_t)y0 * Wi + x0) * C;
-        const T* p01 = base + ((int64_t)y0 * Wi + x1) * C;
-        const T* p10 = base + ((int64_t)y1 * Wi + x0) * C;
-        const T* p11 = base + ((int64_t)y1 * Wi + x1) * C;
+        const T* r0 = x + ((int64_t)b * Hi + y0) * Wi * C;
+        const T* r1 = x + ((int64_t)b * Hi + y1) * Wi * C;
+        T* yr = y + (int64_t)by * Wo * C;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+            const int ox = i / cv, c = (i - ox * cv) * 4 * NV;
+            int x0, x1;
+            float lx0, lx1;
+            src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+            const T* p00 = r0 + (int64_t)x0 * C + c;
+            const T* p01 = r0 + (int64_t)x1 * C + c;
+            const T* p10 = r1 + (int64_t)x0 * C + c;
+            const T* p11 = r1 + (int64_t)x1 * C + c;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const f32x4 v00 = Vec4<T>::load(p00 + 4 * v), v01 = Vec4<T>::load(p01 + 4 * v);
-            const f32x4 v10 = Vec4<T>::load(p10 + 4 * v), v11 = Vec4<T>::load(p11 + 4 * v);
-            f32x4 o;
-            for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
-            Vec4<T>::store(y + idx * 4 * NV + 4 * v, o);
+            for (int v = 0; v < NV; ++v) {
+                const f32x4 v00 = Vec4<T>::load(p00 + 4 * v), v01 = Vec4<T>::load(p01 + 4 * v);
+                const f32x4 v10 = Vec4<T>::load(p10 + 4 * v), v11 = Vec4<T>::load(p11 + 4 * v);
+                f32x4 o;
+                for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+                Vec4<T>::store(yr + (int64_t)ox * C + c + 4 * v, o);
+            }
         }
     }
 }
@@ -88,39 +93,41 @@ __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, 
 
 template <typename T, int NV>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+    // same 2-D decomposition as the forward: grid.y = (b, iy), grid.x covers the (ix, channel-vector) pairs of one input row
     const int cv = C / (4 * NV);
-    const int64_t total = (int64_t)B * Hi * Wi * cv;
+    const int rowlen = Wi * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % cv);
-        int64_t r = idx / cv;
-        const int ix = (int)(r % Wi); r /= Wi;
-        const int iy = (int)(r % Hi);
-        const int b = (int)(r / Hi);
-        int ylo, yhi, xlo, xhi;
+    for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
+        const int b = by / Hi, iy = by - b * Hi;
+        int ylo, yhi;
         out_range(iy, sh, Ho, ylo, yhi);
-        out_range(ix, sw, Wo, xlo, xhi);
-        f32x4 acc[NV];
+        const T* base = dy + (int64_t)b * Ho * Wo * C;
+        T* xr = dx + (int64_t)by * Wi * C;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+            const int ix = i / cv, c = (i - ix * cv) * 4 * NV;
+            int xlo, xhi;
+            out_range(ix, sw, Wo, xlo, xhi);
+            f32x4 acc[NV];
 #pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const T* base = dy + (int64_t)b * Ho * Wo * C + c * 4 * NV;
-        for (int oy = ylo; oy <= yhi; ++oy) {
-            int y0, y1; float ly0, ly1;
-            src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
-            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = xlo; ox <= xhi; ++ox) {
-                int x0, x1; float lx0, lx1;
-                src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
-                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
-                if (wx == 0.f) continue;
-                const T* gp = base + ((int64_t)oy * Wo + ox) * C;
+            for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int oy = ylo; oy <= yhi; ++oy) {
+                int y0, y1; float ly0, ly1;
+                src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
+                const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = xlo; ox <= xhi; ++ox) {
+                    int x0, x1; float lx0, lx1;
+                    src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+                    const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const T* gp = base + ((int64_t)oy * Wo + ox) * C + c;
 #pragma unroll
-                for (int v = 0; v < NV; ++v) acc[v] += Vec4<T>::load(gp + 4 * v) * (wy * wx);
+                    for (int v = 0; v < NV; ++v) acc[v] += Vec4<T>::load(gp + 4 * v) * (wy * wx);
+                }
             }
-        }
 #pragma unroll
-        for (int v = 0; v < NV; ++v) Vec4<T>::store(dx + idx * 4 * NV + 4 * v, acc[v]);
+            for (int v = 0; v < NV; ++v) Vec4<T>::store(xr + (int64_t)ix * C + c + 4 * v, acc[v]);
+        }
     }
 }
 
@@ -470,12 +477,14 @@ extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, i
                                 umr_stream_t stream) {
     UMR_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (C % 8 == 0) {
-        const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
-    } else {
-        const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners));
+    {
+        const int nv = (C % 8 == 0) ? 2 : 1;
+        const int rowlen = Wo * (C / (4 * nv));
+        int64_t gy = (int64_t)B * Ho;
+        if (gy > 65535) gy = 65535;
+        const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
+        if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
     }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
@@ -485,12 +494,14 @@ extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi,
                                 umr_stream_t stream) {
     UMR_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_bwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    if (C % 8 == 0) {
-        const int64_t total = (int64_t)B * Hi * Wi * (C / 8);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
-    } else {
-        const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
-        DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), dim3(grid_for(total, 256, 65536)), dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners));
+    {
+        const int nv = (C % 8 == 0) ? 2 : 1;
+        const int rowlen = Wi * (C / (4 * nv));
+        int64_t gy = (int64_t)B * Hi;
+        if (gy > 65535) gy = 65535;
+        const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
+        if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
     }
     UMR_LAUNCH_CHECK();
     return UMR_OK;

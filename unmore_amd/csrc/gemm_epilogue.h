@@ -26,7 +26,7 @@ __device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_log
         else { for (int j = 0; j < 4; ++j) a[j] = (j < nv) ? to_f32<T>(ap[j]) : 0.f; }
         if (p.flags & UMR_EPI_ADD_AUX) v += a;
         else if (p.flags & UMR_EPI_MASK_RELU) { for (int j = 0; j < 4; ++j) v[j] = a[j] > 0.f ? v[j] : 0.f; }
-        else { for (int j = 0; j < 4; ++j) v[j] *= dgelu_erf(a[j]); }
+        else { for (int j = 0; j < 4; ++j) v[j] *= dgelu_sel<T>(a[j]); }
     }
     if (p.flags & UMR_EPI_ADD_AUX2) {
         const T* ap = (const T*)p.aux2 + (int64_t)m * p.ldaux2 + n;
@@ -41,7 +41,7 @@ __device__ __forceinline__ void epilogue_store(const umr_gemm_desc& p, int m_log
         else { for (int j = 0; j < 4; ++j) if (j < nv) cp[j] = from_f32<T>(v[j]); }
     }
     if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f); }
-    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]); }
+    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) v[j] = gelu_sel<T>(v[j]); }
     else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) v[j] = tanhf(v[j]); }
     else if (p.act == UMR_ACT_SIGMOID) { for (int j = 0; j < 4; ++j) v[j] = 1.f / (1.f + expf(-v[j])); }
     if (p.flags & UMR_EPI_OUT_F32) {
@@ -100,7 +100,7 @@ __device__ __forceinline__ void epilogue_store8(const umr_gemm_desc& p, int m_lo
         else if (p.flags & UMR_EPI_MASK_RELU) {
             for (int j = 0; j < 4; ++j) { v0[j] = a0[j] > 0.f ? v0[j] : 0.f; v1[j] = a1[j] > 0.f ? v1[j] : 0.f; }
         } else {
-            for (int j = 0; j < 4; ++j) { v0[j] *= dgelu_erf(a0[j]); v1[j] *= dgelu_erf(a1[j]); }
+            for (int j = 0; j < 4; ++j) { v0[j] *= dgelu_sel<T>(a0[j]); v1[j] *= dgelu_sel<T>(a1[j]); }
         }
     }
     if (p.flags & UMR_EPI_ADD_AUX2) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ void epilogue_store8(const umr_gemm_desc& p, int m_lo
     }
     if (p.c2_mode == 2) Vec8<T>::store((T*)p.C2 + (int64_t)m * p.ldc2 + n, v0, v1);
     if (p.act == UMR_ACT_RELU) { for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); } }
-    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) { v0[j] = gelu_erf(v0[j]); v1[j] = gelu_erf(v1[j]); } }
+    else if (p.act == UMR_ACT_GELU) { for (int j = 0; j < 4; ++j) { v0[j] = gelu_sel<T>(v0[j]); v1[j] = gelu_sel<T>(v1[j]); } }
     else if (p.act == UMR_ACT_TANH) { for (int j = 0; j < 4; ++j) { v0[j] = tanhf(v0[j]); v1[j] = tanhf(v1[j]); } }
     else if (p.act == UMR_ACT_SIGMOID) { for (int j = 0; j < 4; ++j) { v0[j] = 1.f / (1.f + expf(-v0[j])); v1[j] = 1.f / (1.f + expf(-v1[j])); } }
     if (p.flags & UMR_EPI_OUT_F32) Vec8<float>::store((float*)p.C + (int64_t)m * p.ldc + n, v0, v1);

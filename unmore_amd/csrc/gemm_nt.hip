@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     if constexpr (EPI == 0) {
         const int c8 = (tid & 15) * 8, n = n0 + c8;
         const bool n_ok = n < p.N;
-        const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
+        const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) != 0;
         const bool use_aux2 = (p.flags & UMR_EPI_ADD_AUX2) != 0;
         f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
         if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n); bias1 = *(const f32x4*)(p.bias + n + 4); }
@@ -285,9 +285,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
                     f32x4 a0, a1;
                     Raw8<T>::cvt(ra[PASS * 4 + k], a0, a1);
                     if (p.flags & UMR_EPI_ADD_AUX) { v0 += a0; v1 += a1; }
-                    else {
+                    else if (p.flags & UMR_EPI_MASK_RELU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = a0[e] > 0.f ? v0[e] : 0.f; v1[e] = a1[e] > 0.f ? v1[e] : 0.f; }
+                    } else if constexpr (sizeof(T) == 2) {   // GELU'-mask (16-bit mode only: the cheap erf form)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] *= dgelu_sel<T>(a0[e]); v1[e] *= dgelu_sel<T>(a1[e]); }
                     }
                 }
                 if (use_aux2) {
@@ -299,6 +302,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
                 if (p.act == UMR_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
+                } else if (p.act == UMR_ACT_GELU) {
+                    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = gelu_sel<T>(v0[e]); v1[e] = gelu_sel<T>(v1[e]); }
+                    }
                 }
                 Vec8<T>::store((T*)p.C + (int64_t)m * p.ldc + n, v0, v1);
                 if (p.c2_mode == 1) {
@@ -400,10 +408,11 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     dim3 g((unsigned)grid), b(256);
     const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&
-                         (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) || (d->ldaux & 7) == 0) &&
+                         (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) || (d->ldaux & 7) == 0) &&
                          (!(d->flags & UMR_EPI_ADD_AUX2) || (d->ldaux2 & 7) == 0) && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
-                         !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
-                         (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+                         !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_OUT_F32)) &&
+                         (!(d->flags & UMR_EPI_MASK_DGELU) || d->dtype == UMR_BF16) &&   // GELU forms: 16-bit mode only (cheap erf)
+                         (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU || (d->act == UMR_ACT_GELU && d->dtype == UMR_BF16));
 #define LAUNCH(T, CV)                                                                                   \
     do {                                                                                                \
         if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 0>), g, b, LDS_BYTES, s, *d, tiles_n);   \

@@ -53,6 +53,36 @@ __device__ __forceinline__ float dgelu_erf(float x) {
     return cdf + x * pdf;
 }
 
+// Throughput-mode (bf16 storage) forms: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16 resolution) on
+// one v_rcp_f32 + one v_exp_f32 + six FMAs instead of libm's erff (~40 instructions with two divergent branches); the fp32
+// parity mode keeps erff.  The derivative shares the exponential: e^{-z^2} with z = x/sqrt(2) is sqrt(2 pi) * pdf(x).
+__device__ __forceinline__ void erf_exp_fast(float x, float& erf_z, float& e) {   // erf(x/sqrt2), exp(-x^2/2)
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * e;
+    erf_z = x < 0.f ? -r : r;
+}
+template <typename T> __device__ __forceinline__ float gelu_sel(float x) {
+    if constexpr (sizeof(T) == 2) {
+        float ez, e;
+        erf_exp_fast(x, ez, e);
+        return 0.5f * x * (1.0f + ez);
+    } else {
+        return gelu_erf(x);
+    }
+}
+template <typename T> __device__ __forceinline__ float dgelu_sel(float x) {
+    if constexpr (sizeof(T) == 2) {
+        float ez, e;
+        erf_exp_fast(x, ez, e);
+        return 0.5f * (1.0f + ez) + x * 0.39894228040143267794f * e;
+    } else {
+        return dgelu_erf(x);
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

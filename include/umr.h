@@ -64,12 +64,13 @@ typedef struct umr_gemm_desc {
     int32_t c_rows_in, c_rows_out, c_row_off;
     int32_t aux_mod;
     /* optional fused row reduction (the 1024 -> {1,2} output layer of a head, objectness_net.py:116,133, folded into the
-     * epilogue of the layer that produces its input): for each 256-column tile t of the output,
-     *   red_out[t][m][c] = sum_{n in tile t} C[m,n] * red_w[c][n]      (C as stored: after bias / activation / rounding)
-     * red_w: [red_c][N] f32, red_c in {1,2}; red_out: [ceil(N/256)][M][red_c] f32 partial sums, summed in fixed order by
+     * epilogue of the layer that produces its input): for each 64-column slice t of the output,
+     *   red_out[t][m][c] = sum_{n in slice t} C[m,n] * red_w[c][n]      (C as stored: after bias / activation / rounding)
+     * red_w: [red_c][N] f32, red_c in {1,2}; red_out: [ceil(N/64)][M][red_c] f32 partial sums, summed in fixed order by
      * umr_head_out_finish.  no_store = 1 skips the store of C itself (inference: the activation is not needed again).
-     * Only the persistent 256x256 bf16 path implements it: call umr_gemm_nt_rowreduce_ok first; umr_gemm_nt fails
-     * (UMR_ERR_UNSUPPORTED / UMR_ERR_INVALID) rather than silently ignoring the request. */
+     * Only the persistent 256x256 bf16 path with a bias / ReLU-only epilogue implements it: call
+     * umr_gemm_nt_rowreduce_ok first; umr_gemm_nt fails (UMR_ERR_UNSUPPORTED / UMR_ERR_INVALID) rather than silently
+     * ignoring the request. */
     const float* red_w;
     float* red_out;
     int32_t red_c;

@@ -151,12 +151,12 @@ def test_gemm_nt_fused_row_reduction(M, C, relu):
     ref_c = ops.gemm_nt(A, B, bias, act=act)
     out, parts = ops.gemm_nt(A, B, bias, act=act, red_w=rw)
     assert torch.equal(out, ref_c)
-    assert parts.shape == (N // 256, M, C)
+    assert parts.shape == (N // 64, M, C)
     ref = ref_c.double() @ rw.double().t()
     torch.testing.assert_close(parts.sum(0).double(), ref, atol=1e-4, rtol=1e-4)
-    # every column tile separately
-    for t in range(N // 256):
-        sl = slice(t * 256, (t + 1) * 256)
+    # every 64-column slice separately
+    for t in range(N // 64):
+        sl = slice(t * 64, (t + 1) * 64)
         torch.testing.assert_close(parts[t].double(), ref_c[:, sl].double() @ rw[:, sl].double().t(), atol=1e-4, rtol=1e-4)
     # inference form: C is not written at all
     none, parts2 = ops.gemm_nt(A, B, bias, act=act, red_w=rw, no_store=True)

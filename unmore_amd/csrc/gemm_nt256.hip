@@ -323,12 +323,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(const umr_gemm_desc 
 
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip (persistent form)
 bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d);
+bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d);
 
 // would umr_launch_gemm_nt256 hand d to the persistent kernel's fast epilogue?
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d) {
     const char* e = getenv("UMR_NT256_PERSIST");
     if (e && atoi(e) == 0) return false;
-    return ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1) && umr_nt256p_fast_epilogue(d);
+    return ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1) && umr_nt256p_plain_epilogue(d);
 }
 
 // launched from umr_gemm_nt (gemm_nt.hip) for bf16 problems large enough to fill the chip with 256x256 tiles

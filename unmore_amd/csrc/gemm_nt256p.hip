@@ -291,7 +291,78 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         const int v = it * G + pw;
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
         const int m0 = tm * BM2, n0 = tn * BN2;
-        if (EPI == 0) {
+        if (EPI == 3) {
+            // bias + optional ReLU only (the forward GEMMs / convs): the epilogue math runs on the accumulators in their
+            // fragment layout (a lane's 4 columns per 16-column tile -> 4 bias vectors per thread), the results are
+            // staged as bf16 -- 64 tile rows per pass instead of 32, so 4 passes / 8 barriers instead of 8 / 16 and half
+            // the LDS traffic -- and leave as plain 16-byte copies.
+            f32x4 bq[4];
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) {
+                const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                bq[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((p.flags & UMR_EPI_BIAS) && n < p.N) bq[ntl] = *(const f32x4*)(p.bias + n);
+            }
+            // fused row reduction (umr_gemm_desc.red_*): this lane's 16 columns of the reduction weights; the partial dot
+            // products of a row are summed over the 4 lanes that share it (fq) and written per 64-column wave slice
+            const bool red = p.red_w != nullptr;
+            f32x4 rw[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int ntl = 0; ntl < 4; ++ntl) {
+                    const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                    rw[c][ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (red && c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
+                }
+            char* stb = smem + STG_OFF;
+            auto pass3 = [&](auto ptag) {
+                constexpr int PS = decltype(ptag)::value;
+                if (PS > 0) __syncthreads();
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    const int lr = wr * 32 + mh * 16 + frow;
+                    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) {
+                        f32x4 v = acc[PS * 2 + mh][ntl] + bq[ntl];
+                        if (p.act == UMR_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        bf16x4 t;
+                        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+                        const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
+                        *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
+                        if (red) {   // dot products with the values AS STORED (bf16-rounded)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { rs0 += (float)t[e] * rw[0][ntl][e]; rs1 += (float)t[e] * rw[1][ntl][e]; }
+                        }
+                    }
+                    if (red) {
+                        rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
+                        rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
+                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
+                        if (fq == 0 && m < p.M && n0 + wc * 64 < p.N) {
+                            float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
+                            ro[0] = rs0;
+                            if (p.red_c == 2) ro[1] = rs1;
+                        }
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
+                    const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
+                    if (m < p.M && n < p.N && !p.no_store)
+                        *(uint4*)((T2*)p.C + (int64_t)m * p.ldc + n) = *(const uint4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                }
+            };
+            pass3(std::integral_constant<int, 0>{}); pass3(std::integral_constant<int, 1>{});
+            pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
+            __syncthreads();
+        } else if (EPI == 0) {
             // bias / aux add / ReLU mask / ReLU, bf16 out, all strides 16-B aligned (checked by the launcher).
             // All global LOADS (bias, aux) are issued before the first store: vmcnt retires in order, so a load issued
             // after a store would wait for that store's write acknowledgement -- once per pass.
@@ -300,17 +371,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
             bf16x8 ax[16];
             if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n_thr); bias1 = *(const f32x4*)(p.bias + n_thr + 4); }
-            // fused row reduction (umr_gemm_desc.red_*): this thread's 8 columns of the reduction weights
-            const bool red = p.red_w != nullptr;
-            f32x4 rw[2][2];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                rw[c][0] = rw[c][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (red && c < p.red_c && n_ok) {
-                    rw[c][0] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n_thr);
-                    rw[c][1] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n_thr + 4);
-                }
-            }
             // aux rows are fetched two passes ahead of their use (24 VGPRs live): a load issued before the stores of
             // pass k only has to wait for stores of passes < k, which have long been acknowledged when pass k+2 reads it
             const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
@@ -333,7 +393,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 stage_rows(mtag);
                 load_aux(std::integral_constant<int, MT + 2>{});
                 __syncthreads();
-                float red_acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int lr = (tid >> 5) + j * 16, cg = tid & 31;
@@ -357,39 +416,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
                     }
-                    if (!p.no_store) Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
-                    if (red) {
-                        // dot products with the values AS STORED (bf16-rounded), summed over the 32 lanes of this row:
-                        // DPP row shifts inside each 16-lane row, then row_bcast:15 into the odd rows -> lanes 31 / 63
-                        float sc[2];
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            float a = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) a += (float)(T2)v0[e] * rw[c][0][e] + (float)(T2)v1[e] * rw[c][1][e];
-                            sc[c] = a;
-                        }
-                        red_acc[j][0] = sc[0]; red_acc[j][1] = sc[1];
-                    }
-                }
-                if (red) {
-                    // (outside the per-task branch: DPP needs the whole wave; skipped rows contribute zeros)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int lr = (tid >> 5) + j * 16;
-                        const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
-#pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            float a = red_acc[j][c];
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x111, 0xF, 0xF, true));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x112, 0xF, 0xF, true));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x114, 0xF, 0xF, true));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x118, 0xF, 0xF, true));
-                            a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x142, 0xA, 0xF, false));
-                            if ((lane & 31) == 31 && m < p.M && c < p.red_c)
-                                p.red_out[((int64_t)tn * p.M + m) * p.red_c + c] = a;
-                        }
-                    }
+                    Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
                 }
             };
             pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
@@ -462,6 +489,11 @@ int num_cus() {
 }  // namespace
 
 // the epilogue class of the fast (EPI 0) instantiation
+bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d);
+// the epilogue class that implements red_* / no_store: bias / ReLU only
+bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) {
+    return umr_nt256p_fast_epilogue(d) && !(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU));
+}
 bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
     const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
     return vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
@@ -491,7 +523,6 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     dim3 g((unsigned)grid), b(512);
     // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
-    if ((d->red_w || d->no_store) && !fast_ep) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
     // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs (tools/kbench.py) -> conv only
     static int ph2_env = -2;
     if (ph2_env == -2) { const char* e = getenv("UMR_NT256_PH2"); ph2_env = e ? atoi(e) : -1; }
@@ -507,8 +538,15 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
         if (ph2) hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, true>), g, b, LDS2P, s, *d, tiles_n, (int)total);       \
         else hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, false>), g, b, LDS2P, s, *d, tiles_n, (int)total);          \
     } while (0)
-    if (d->conv == 0) { if (fast_ep) L256P(0, 0); else L256P(0, 1); }
-    else { if (fast_ep) L256P(1, 0); else L256P(1, 1); }
+    // EPI 3: the fast class without aux / fused reduction (bias + ReLU only): bf16-staged epilogue
+    static int ep3 = -1;
+    if (ep3 < 0) { const char* e = getenv("UMR_NT256_EPI3"); ep3 = e ? atoi(e) : 1; }
+    const bool no_aux = !(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU));
+    if ((d->red_w || d->no_store) && !(fast_ep && no_aux))
+        return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs a bias / ReLU-only epilogue");
+    const bool plain_ep = fast_ep && no_aux && (ep3 || d->red_w || d->no_store);
+    if (d->conv == 0) { if (plain_ep) L256P(0, 3); else if (fast_ep) L256P(0, 0); else L256P(0, 1); }
+    else { if (plain_ep) L256P(1, 3); else if (fast_ep) L256P(1, 0); else L256P(1, 1); }
 #undef L256P
     UMR_LAUNCH_CHECK();
     return UMR_OK;

@@ -49,7 +49,7 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
             conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False):
     """C[M,N] = epi(A[M,K] . B[N,K]^T).  A: [M,K] (2-D, row stride lda) or NHWC
     [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci)).
-    red_w ([c, N] f32, c in {1,2}): fused row reduction (umr_gemm_desc.red_*) -> returns (C, partials [ceil(N/256), M, c]);
+    red_w ([c, N] f32, c in {1,2}): fused row reduction (umr_gemm_desc.red_*) -> returns (C, partials [ceil(N/64), M, c]);
     with no_store=True C is neither allocated nor written (returned as None).  query_rowreduce=True only asks the
     library whether this call would run on the path that implements the reduction (returns bool, launches nothing)."""
     _need_gpu(A, B)
@@ -114,7 +114,7 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     partials = None
     if red_w is not None:
         assert red_w.dtype == torch.float32 and red_w.is_contiguous() and red_w.shape[1] == N and red_w.shape[0] in (1, 2)
-        partials = torch.empty(((N + 255) // 256, M_, red_w.shape[0]), dtype=torch.float32, device=A.device)
+        partials = torch.empty(((N + 63) // 64, M_, red_w.shape[0]), dtype=torch.float32, device=A.device)
         d.red_w, d.red_out, d.red_c = _p(red_w), _p(partials), red_w.shape[0]
     d.no_store = 1 if no_store else 0
     L.check(_timed_call(d), "umr_gemm_nt")

@@ -112,8 +112,11 @@ def measured_traffic(a):
     here = os.path.dirname(os.path.abspath(__file__))
     for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
-            for k in json.load(open(f))["kernels"]:
-                if k["kernel"].startswith("gemm_nt256p_kernel<1, 0") and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
+            ks = json.load(open(f))["kernels"]
+            # the head conv runs as <conv, epilogue class 3> (forward, sdf data gradient) and <conv, 0> (ReLU-masked data gradient)
+            ks = sorted(ks, key=lambda k: 0 if k["kernel"].startswith("gemm_nt256p_kernel<1, 3") else 1)
+            for k in ks:
+                if k["kernel"].startswith(("gemm_nt256p_kernel<1, 3", "gemm_nt256p_kernel<1, 0")) and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
                     return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
                             "traffic_source": os.path.relpath(f, here), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
         except (OSError, ValueError, KeyError):

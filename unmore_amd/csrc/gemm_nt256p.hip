@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
         const int m0 = tm * BM2, n0 = tn * BN2;
         if (EPI == 3) {
-            // bias + optional ReLU only (the forward GEMMs / convs): the epilogue math runs on the accumulators in their
+            // fast class: bias, aux add / ReLU mask, ReLU.  The epilogue math runs on the accumulators in their
             // fragment layout (a lane's 4 columns per 16-column tile -> 4 bias vectors per thread), the results are
             // staged as bf16 -- 64 tile rows per pass instead of 32, so 4 passes / 8 barriers instead of 8 / 16 and half
             // the LDS traffic -- and leave as plain 16-byte copies.
@@ -315,9 +315,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     rw[c][ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (red && c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
                 }
+            // aux operand (residual add / ReLU mask) in the same fragment layout: 8-byte loads, fetched one pass ahead so that
+            // no load is issued behind a store it would have to wait for (vmcnt retires in order)
+            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
+            bf16x4 axq[2][2][4];
+            auto load_aux3 = [&](auto ptag) {
+                constexpr int PS = decltype(ptag)::value;
+                if (PS < 4 && use_aux) {
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
+#pragma unroll
+                        for (int ntl = 0; ntl < 4; ++ntl) {
+                            const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                            if (m < p.M && n < p.N) axq[PS & 1][mh][ntl] = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                        }
+                    }
+                }
+            };
+            load_aux3(std::integral_constant<int, 0>{});
             char* stb = smem + STG_OFF;
             auto pass3 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
+                load_aux3(std::integral_constant<int, PS + 1>{});
                 if (PS > 0) __syncthreads();
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
@@ -326,6 +346,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
                         f32x4 v = acc[PS * 2 + mh][ntl] + bq[ntl];
+                        if (use_aux) {
+                            const bf16x4 a = axq[PS & 1][mh][ntl];
+                            if (p.flags & UMR_EPI_ADD_AUX) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = (float)a[e] > 0.f ? v[e] : 0.f;
+                            }
+                        }
                         if (p.act == UMR_ACT_RELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -362,67 +392,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             pass3(std::integral_constant<int, 0>{}); pass3(std::integral_constant<int, 1>{});
             pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
             __syncthreads();
-        } else if (EPI == 0) {
-            // bias / aux add / ReLU mask / ReLU, bf16 out, all strides 16-B aligned (checked by the launcher).
-            // All global LOADS (bias, aux) are issued before the first store: vmcnt retires in order, so a load issued
-            // after a store would wait for that store's write acknowledgement -- once per pass.
-            const int n_thr = n0 + (tid & 31) * 8;
-            const bool n_ok = n_thr < p.N;
-            f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
-            bf16x8 ax[16];
-            if ((p.flags & UMR_EPI_BIAS) && n_ok) { bias0 = *(const f32x4*)(p.bias + n_thr); bias1 = *(const f32x4*)(p.bias + n_thr + 4); }
-            // aux rows are fetched two passes ahead of their use (24 VGPRs live): a load issued before the stores of
-            // pass k only has to wait for stores of passes < k, which have long been acknowledged when pass k+2 reads it
-            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
-            auto load_aux = [&](auto mtag) {
-                constexpr int MT = decltype(mtag)::value;
-                if (MT < 8 && use_aux) {
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int lr = (tid >> 5) + j * 16;
-                        const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
-                        if (m < p.M && n_ok) ax[(MT & 7) * 2 + j] = *(const bf16x8*)((const T2*)p.aux + (int64_t)m * p.ldaux + n_thr);
-                    }
-                }
-            };
-            load_aux(std::integral_constant<int, 0>{});
-            load_aux(std::integral_constant<int, 1>{});
-            auto pass = [&](auto mtag) {
-                constexpr int MT = decltype(mtag)::value;
-                if (MT > 0) __syncthreads();
-                stage_rows(mtag);
-                load_aux(std::integral_constant<int, MT + 2>{});
-                __syncthreads();
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int lr = (tid >> 5) + j * 16, cg = tid & 31;
-                    const int m = m0 + (lr >> 4) * 128 + MT * 16 + (lr & 15);
-                    if (m >= p.M || !n_ok) continue;
-                    const int sw = lr & 15;
-                    f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
-                    f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
-                    v0 += bias0; v1 += bias1;
-                    if (use_aux) {
-                        const bf16x8 a = ax[MT * 2 + j];
-                        if (p.flags & UMR_EPI_ADD_AUX) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v0[e] += (float)a[e]; v1[e] += (float)a[4 + e]; }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v0[e] = (float)a[e] > 0.f ? v0[e] : 0.f; v1[e] = (float)a[4 + e] > 0.f ? v1[e] : 0.f; }
-                        }
-                    }
-                    if (p.act == UMR_ACT_RELU) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], 0.f); v1[e] = fmaxf(v1[e], 0.f); }
-                    }
-                    Vec8<T2>::store((T2*)p.C + (int64_t)m * p.ldc + n_thr, v0, v1);
-                }
-            };
-            pass(std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{});
-            pass(std::integral_constant<int, 2>{}); pass(std::integral_constant<int, 3>{});
-            pass(std::integral_constant<int, 4>{}); pass(std::integral_constant<int, 5>{});
-            pass(std::integral_constant<int, 6>{}); pass(std::integral_constant<int, 7>{});
         } else {
             // generic epilogue (every flag / activation / remap of include/umr.h): ONE copy of the store code in a
             // runtime loop over the passes -- unrolled it is ~100 KiB of instructions and runs out of the I-cache
@@ -488,12 +457,10 @@ int num_cus() {
 
 }  // namespace
 
-// the epilogue class of the fast (EPI 0) instantiation
+// the epilogue class of the fast (EPI 3) instantiation
 bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d);
-// the epilogue class that implements red_* / no_store: bias / ReLU only
-bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) {
-    return umr_nt256p_fast_epilogue(d) && !(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU));
-}
+// the epilogue class that implements red_* / no_store
+bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) { return umr_nt256p_fast_epilogue(d); }
 bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
     const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
     return vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
@@ -521,7 +488,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     if (total < grid64) grid64 = total;
     const int grid = (int)grid64;
     dim3 g((unsigned)grid), b(512);
-    // EPI 0: bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides; EPI 1: everything else
+    // fast class = bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
     // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs (tools/kbench.py) -> conv only
     static int ph2_env = -2;
@@ -538,15 +505,11 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
         if (ph2) hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, true>), g, b, LDS2P, s, *d, tiles_n, (int)total);       \
         else hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, false>), g, b, LDS2P, s, *d, tiles_n, (int)total);          \
     } while (0)
-    // EPI 3: the fast class without aux / fused reduction (bias + ReLU only): bf16-staged epilogue
-    static int ep3 = -1;
-    if (ep3 < 0) { const char* e = getenv("UMR_NT256_EPI3"); ep3 = e ? atoi(e) : 1; }
-    const bool no_aux = !(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU));
-    if ((d->red_w || d->no_store) && !(fast_ep && no_aux))
-        return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs a bias / ReLU-only epilogue");
-    const bool plain_ep = fast_ep && no_aux && (ep3 || d->red_w || d->no_store);
-    if (d->conv == 0) { if (plain_ep) L256P(0, 3); else if (fast_ep) L256P(0, 0); else L256P(0, 1); }
-    else { if (plain_ep) L256P(1, 3); else if (fast_ep) L256P(1, 0); else L256P(1, 1); }
+    // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged, optional fused row reduction); EPI 1: everything else
+    if ((d->red_w || d->no_store) && !fast_ep)
+        return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
+    if (d->conv == 0) { if (fast_ep) L256P(0, 3); else L256P(0, 1); }
+    else { if (fast_ep) L256P(1, 3); else L256P(1, 1); }
 #undef L256P
     UMR_LAUNCH_CHECK();
     return UMR_OK;

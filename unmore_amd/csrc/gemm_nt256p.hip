@@ -328,7 +328,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                         for (int ntl = 0; ntl < 4; ++ntl) {
                             const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                            if (m < p.M && n < p.N) axq[PS & 1][mh][ntl] = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                            bf16x4 a4;
+                            a4[0] = a4[1] = a4[2] = a4[3] = (bf16_t)0.f;   // out-of-range rows / columns: defined values
+                            if (m < p.M && n < p.N) a4 = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                            axq[PS & 1][mh][ntl] = a4;
                         }
                     }
                 }

@@ -190,9 +190,48 @@ def test_large_tile_nt_gemm(M, N, K):
     assert ops.gemm_nt(A, B, bias, query_rowreduce=True), "shape chosen to run on the persistent 256x256 kernel"
     torch.testing.assert_close(ops.gemm_nt(A, B, bias, act=L.ACT_RELU).float(), torch.relu(ref), atol=3e-2, rtol=3e-2)
     torch.testing.assert_close(ops.gemm_nt(A, B, None, aux=aux, mask_relu=True).float(), (ref - bias) * (aux.float() > 0), atol=3e-2, rtol=3e-2)
-    out, pre = ops.gemm_nt(A, B, bias, act=L.ACT_GELU, c2_mode=2)   # generic epilogue class
+    out, pre = ops.gemm_nt(A, B, bias, act=L.ACT_GELU, c2_mode=2)   # GELU epilogue class
     torch.testing.assert_close(pre.float(), ref, atol=3e-2, rtol=3e-2)
     torch.testing.assert_close(out.float(), F.gelu(ref), atol=3e-2, rtol=3e-2)
+    out = ops.gemm_nt(A, B, bias, act=L.ACT_TANH)                   # generic epilogue class
+    torch.testing.assert_close(out.float(), torch.tanh(ref), atol=3e-2, rtol=3e-2)
+
+
+def test_transformer_shape_gemms_on_large_tiles():
+    """The ViT-B GEMMs at the cfg2 token count (64 x 577 rows: a ragged last row tile) run on the 256x256 kernels: the GELU
+    epilogue class (GELU + saved pre-activation, GELU'-masked gradient), residual add, and the one-round split weight gradient."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    M, D = 64 * 577, 768
+    x = _rnd((M, D), torch.bfloat16, dev, 61)
+    x4 = _rnd((M, 4 * D), torch.bfloat16, dev, 62)
+    w1 = _rnd((4 * D, D), torch.bfloat16, dev, 63, D ** -0.5)
+    w2 = _rnd((D, 4 * D), torch.bfloat16, dev, 64, (4 * D) ** -0.5)
+    b4 = _rnd((4 * D,), torch.float32, dev, 65)
+    b1 = _rnd((D,), torch.float32, dev, 66)
+    assert ops.gemm_nt(x, w1, b4, query_rowreduce=True) and ops.gemm_nt(x4, w2, b1, query_rowreduce=True), "expected the 256x256 path"
+    ref = x.float() @ w1.float().t() + b4
+    h, pre = ops.gemm_nt(x, w1, b4, act=L.ACT_GELU, c2_mode=2)
+    torch.testing.assert_close(pre.float(), ref, atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(h.float(), F.gelu(ref), atol=3e-2, rtol=3e-2)
+    h1 = ops.gemm_nt(x, w1, b4, act=L.ACT_GELU)
+    assert torch.equal(h1, h)
+    # GELU'-masked gradient: dpre = (dy . W2) * gelu'(pre)
+    g = ops.gemm_nt(x, w2.t().contiguous(), None, aux=pre, mask_dgelu=True)
+    p32 = pre.float()
+    dg = 0.5 * (1 + torch.erf(p32 / 2 ** 0.5)) + p32 * torch.exp(-0.5 * p32 * p32) / (2 * torch.pi) ** 0.5
+    torch.testing.assert_close(g.float(), (x.float() @ w2.float()) * dg, atol=3e-2, rtol=3e-2)
+    # residual add
+    y = ops.gemm_nt(x4, w2, b1, aux=x)
+    torch.testing.assert_close(y.float(), x4.float() @ w2.float().t() + b1 + x.float(), atol=5e-2, rtol=3e-2)
+    # weight gradient + bias gradient (split over rows, one round)
+    dW = torch.empty((4 * D, D), dtype=torch.float32, device=dev)
+    db = torch.empty((4 * D,), dtype=torch.float32, device=dev)
+    ops.gemm_tn(x4, x, dW=dW, dbias=db)
+    rw = x4.float().t() @ x.float()
+    torch.testing.assert_close(dW, rw, atol=2e-3 * float(rw.abs().max()), rtol=0)
+    rb = x4.float().sum(0)
+    torch.testing.assert_close(db, rb, atol=2e-3 * float(rb.abs().max()), rtol=0)
 
 
 @pytest.mark.parametrize("nb,H,W,Cin,N", [(4, 256, 256, 64, 512), (9, 100, 300, 128, 320), (40, 128, 128, 64, 256)])

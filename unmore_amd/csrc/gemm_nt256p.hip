@@ -395,6 +395,105 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             pass3(std::integral_constant<int, 0>{}); pass3(std::integral_constant<int, 1>{});
             pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
             __syncthreads();
+        } else if (EPI == 4) {
+            // GELU class (the transformer MLP): act == GELU with the pre-activation optionally saved to C2 (c2_mode 2), or
+            // the GELU'-masked gradient (MASK_DGELU).  Same bf16 staging as the fast class, in its own instantiation so that
+            // the erf code does not sit in the instruction stream of the conv / 1x1 kernels.
+            f32x4 bq[4];
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) {
+                const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                bq[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((p.flags & UMR_EPI_BIAS) && n < p.N) bq[ntl] = *(const f32x4*)(p.bias + n);
+            }
+            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_DGELU)) != 0;
+            const bool two_out = p.c2_mode == 2;
+            bf16x4 axq[2][2][4];
+            auto load_aux4 = [&](auto ptag) {
+                constexpr int PS = decltype(ptag)::value;
+                if (PS < 4 && use_aux) {
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
+#pragma unroll
+                        for (int ntl = 0; ntl < 4; ++ntl) {
+                            const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                            bf16x4 a4;
+                            a4[0] = a4[1] = a4[2] = a4[3] = (bf16_t)0.f;
+                            if (m < p.M && n < p.N) a4 = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                            axq[PS & 1][mh][ntl] = a4;
+                        }
+                    }
+                }
+            };
+            load_aux4(std::integral_constant<int, 0>{});
+            char* stb = smem + STG_OFF;
+            auto copy_out = [&](T2* dst, int ld, int PS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
+                    const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
+                    if (m < p.M && n < p.N)
+                        *(uint4*)(dst + (int64_t)m * ld + n) = *(const uint4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                }
+            };
+            auto pass4 = [&](auto ptag) {
+                constexpr int PS = decltype(ptag)::value;
+                load_aux4(std::integral_constant<int, PS + 1>{});
+                f32x4 vv[2][4];
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) {
+                        f32x4 v = acc[PS * 2 + mh][ntl] + bq[ntl];
+                        if (use_aux) {
+                            const bf16x4 a = axq[PS & 1][mh][ntl];
+                            if (p.flags & UMR_EPI_ADD_AUX) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] *= dgelu_sel<T2>((float)a[e]);
+                            }
+                        }
+                        vv[mh][ntl] = v;
+                    }
+                auto stage = [&]() {
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh) {
+                        const int lr = wr * 32 + mh * 16 + frow;
+#pragma unroll
+                        for (int ntl = 0; ntl < 4; ++ntl) {
+                            const f32x4 v = vv[mh][ntl];
+                            bf16x4 t;
+                            t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+                            const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
+                            *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
+                        }
+                    }
+                };
+                if (PS > 0) __syncthreads();
+                if (two_out) {   // the pre-activation, as the backward pass wants it
+                    stage();
+                    __syncthreads();
+                    copy_out((T2*)p.C2, p.ldc2, PS);
+                    __syncthreads();
+                }
+                if (p.act == UMR_ACT_GELU) {
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int ntl = 0; ntl < 4; ++ntl)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vv[mh][ntl][e] = gelu_sel<T2>(vv[mh][ntl][e]);
+                }
+                stage();
+                __syncthreads();
+                copy_out((T2*)p.C, p.ldc, PS);
+            };
+            pass4(std::integral_constant<int, 0>{}); pass4(std::integral_constant<int, 1>{});
+            pass4(std::integral_constant<int, 2>{}); pass4(std::integral_constant<int, 3>{});
+            __syncthreads();
         } else {
             // generic epilogue (every flag / activation / remap of include/umr.h): ONE copy of the store code in a
             // runtime loop over the passes -- unrolled it is ~100 KiB of instructions and runs out of the I-cache
@@ -471,6 +570,15 @@ bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
            (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
 }
 
+// the GELU class (EPI 4): GELU (optionally saving the pre-activation) or the GELU'-masked gradient
+static bool umr_nt256p_gelu_epilogue(const umr_gemm_desc* d) {
+    const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0) && ((d->ldc2 & 7) == 0);
+    const bool dg = (d->flags & UMR_EPI_MASK_DGELU) != 0;
+    return vec_ok && (d->c2_mode == 0 || d->c2_mode == 2) && d->c_rows_in <= 0 && d->aux_mod <= 0 && !d->red_w && !d->no_store &&
+           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_RELU)) &&
+           ((d->act == UMR_ACT_GELU && !dg) || (d->act == UMR_ACT_NONE && dg));
+}
+
 // eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
@@ -508,10 +616,11 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
         if (ph2) hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, true>), g, b, LDS2P, s, *d, tiles_n, (int)total);       \
         else hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, false>), g, b, LDS2P, s, *d, tiles_n, (int)total);          \
     } while (0)
-    // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged, optional fused row reduction); EPI 1: everything else
+    // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged, optional fused row reduction); EPI 4: the GELU
+    // class (plain GEMM only); EPI 1: everything else
     if ((d->red_w || d->no_store) && !fast_ep)
         return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
-    if (d->conv == 0) { if (fast_ep) L256P(0, 3); else L256P(0, 1); }
+    if (d->conv == 0) { if (fast_ep) L256P(0, 3); else if (umr_nt256p_gelu_epilogue(d)) L256P(0, 4); else L256P(0, 1); }
     else { if (fast_ep) L256P(1, 3); else L256P(1, 1); }
 #undef L256P
     UMR_LAUNCH_CHECK();

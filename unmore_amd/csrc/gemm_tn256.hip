@@ -345,13 +345,23 @@ bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force) {
     if (force) return true;  // structurally supported (tails are masked); the rest is a performance heuristic
     if (d->N < 192 || d->K < 192) return false;
     const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);
-    // enough rows that >= ~1000 workgroups of >= 16 stages exist
-    return (int64_t)d->M >= 1024 * 64 * 16 / (tiles < 1 ? 1 : tiles) && d->M >= 64 * 64;
+    // enough rows that one workgroup per CU gets >= 16 stages
+    return (int64_t)d->M >= 256 * 64 * 16 / (tiles < 1 ? 1 : tiles) && d->M >= 64 * 64;
 }
 
 void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split) {
     const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);
-    int64_t want = 1024 / tiles;  // ~4 rounds of one workgroup per CU
+    static int rounds_env = -2;
+    if (rounds_env == -2) { const char* e = getenv("UMR_TN256_ROUNDS"); rounds_env = e ? atoi(e) : -1; }
+    // Rounds of one workgroup per CU: every split writes a 256 KiB fp32 partial per tile and the reduction reads it back,
+    // so few-row problems (the transformer weight gradients: 37 k tokens) want ONE round of long splits -- 4 rounds cost
+    // +50 % there (tools/vit_block_bench.py) -- while the pixel-sized ones (>= 64 stages per split even at 4 rounds) keep
+    // 4 rounds for the tail balance.
+    int64_t rounds = (int64_t)d->M * tiles / (256ll * 4096);
+    if (rounds < 1) rounds = 1;
+    if (rounds > 4) rounds = 4;
+    if (rounds_env > 0) rounds = rounds_env;
+    int64_t want = rounds * 256 / tiles;
     if (want < 1) want = 1;
     const int64_t max_by_rows = ((int64_t)d->M + 64 * 16 - 1) / (64 * 16);
     if (want > max_by_rows) want = max_by_rows;

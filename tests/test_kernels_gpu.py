@@ -81,6 +81,25 @@ def test_attention_large_scores_f32():
     torch.testing.assert_close(out.double(), ref, atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("N", [130, 577])
+def test_attention_bf16_deferred_rescale_and_lse(N):
+    """bf16 forward: a late key that tops the running max by far more than the deferral threshold, a gentle upward drift
+    that stays below it, and the log-sum-exp the backward pass consumes."""
+    from unmore_amd import ops
+    dev = _dev()
+    B, heads = 2, 2
+    qkv = _rnd((B * N, 3 * 128), torch.bfloat16, dev, 5, 0.5)
+    qkv[100, 128:192] = qkv[7, 0:64] * 40.0                      # batch 0, head 0: key 100 aligned with query 7
+    ramp = torch.linspace(0.5, 3.0, N, device=dev).unsqueeze(1)   # batch 1: key norms grow along the sequence
+    qkv[N:, 128:256] = (qkv[N:, 128:256].float() * ramp).to(torch.bfloat16)
+    out, lse = ops.attention_fwd(qkv, B, N, heads)
+    t = qkv.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    sc = (t[0] * 0.125) @ t[1].transpose(-2, -1)
+    ref = (sc.softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, 128)
+    torch.testing.assert_close(out.double(), ref, atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(lse.double().reshape(B, heads, N), torch.logsumexp(sc, -1), atol=2e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("p,H,W", [(16, 64, 96), (14, 42, 28)])
 def test_patchify(dtype, p, H, W):

@@ -17,6 +17,7 @@
 // (no atomics: bitwise reproducible).
 // hd^-0.5 = 1/8 is folded into Q (K in the dK/dV kernel): exact in bf16 and f32.
 #include "umr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -201,6 +202,190 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
     }
 }
 
+// ------------------------------------------------------------------ forward, bf16 throughput form
+// Same mapping as above (one wave = 16 query columns of S^T, P^T is directly the B operand of O^T += V^T P^T), rebuilt
+// around the fact that at head dim 64 the kernel is bound by vector-instruction issue, not by the matrix pipe: the loop
+// above spends ~160 VALU / LDS instructions per 8 MFMAs.  Here, per 64-key tile:
+//   * K/V arrive by LDS-DMA into a two-deep ring (no VGPR round trip, no address VALU in the loop; rows >= N read as
+//     zeros through the buffer descriptor), one barrier per tile;
+//   * exp(s - m) is ONE v_fma + ONE v_exp (log2 e folded into the fma, in f32 -- Q keeps its exact 1/8 prescale);
+//   * the row sum l rides on the matrix pipe (an all-ones A fragment: one extra MFMA per 32 keys instead of 8 adds +
+//     cross-lane sums, and it sums the bf16-rounded P the numerator uses);
+//   * the running max is only raised when a tile exceeds it by more than 2^8 in the exponent (deferred rescale): after the
+//     first tile the O rescale -- 16 accumulator registers through the VALU -- is almost never executed;
+//   * key masking only in the last tile.
+// (built with -fno-honor-nans: fmaxf on MFMA results otherwise costs a canonicalising v_max per operand.  Not inline asm:
+// the compiler does not see an asm statement's reads when it pads the MFMA -> VALU read hazard.)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
+// max over lanes l, l^16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) and l, l^32
+__device__ __forceinline__ float xor16_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return max2f(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+__device__ __forceinline__ float xor32_max(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return max2f(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
+template <int OFF>
+__device__ __forceinline__ u32x2 ds_tr_b64(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int N, int heads) {
+    constexpr int TK = 64;                 // keys per tile
+    constexpr int OPB = TK * 128;          // one operand tile: 8 KiB
+    constexpr int STB = 2 * OPB;           // K | V
+    __shared__ __attribute__((aligned(16))) char smem[2 * STB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const bf16_t* kb = qb + D;
+    const bf16_t* vb = qb + 2 * D;
+    const int q = blockIdx.x * 64 + w * 16 + li;
+    const RowFrag<bf16_t> qf = rowfrag_global<bf16_t>(q < N ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+
+    // ---- staging: wave w, instruction i fills LDS rows (w*2+i)*8 .. +8 of a tile (1 KiB); lane -> (row, slot), and
+    // the swizzle is applied on the global side (slot s of row r holds chunk s ^ kswz(r))
+    const unsigned rec = (unsigned)(((int64_t)(N - 1) * ld + HD) * 2);   // rows >= N are out of range -> zeros
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, rec, 0x00020000);
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (w * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ kswz<bf16_t>(r);
+        voff[i] = (unsigned)(r * (int)ld * 2 + c * 16);
+    }
+    const unsigned tile_stride = (unsigned)(TK * (int)ld * 2);
+    auto issue_tile = [&](int j) {
+        char* dst = smem + (j & 1) * STB + w * 2048;
+        const unsigned so = (unsigned)j * tile_stride;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst), 16, voff[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst + 1024), 16, voff[1], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, UMR_LDS_PTR(dst + OPB), 16, voff[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, UMR_LDS_PTR(dst + OPB + 1024), 16, voff[1], so, 0, 0);
+    };
+
+    // ---- read side, lane constants.  K fragment of key row 16*sub + li: chunks (4 i + g) ^ kswz; kswz(16 sub + li + 32 half)
+    // == kswz(li), so sub / half / stage are immediate offsets.  V^T by transposing reads: rows 4 g + (li >> 2) (+16),
+    // chunk pair dt, same argument for the swizzle.
+    const int swk = kswz<bf16_t>(li);
+    const char* kad0 = smem + li * 128 + (((0 + g) ^ swk) << 4);
+    const char* kad1 = smem + li * 128 + (((4 + g) ^ swk) << 4);
+    const int vr = 4 * g + (li >> 2), pp = li & 3;
+    const int swv = kswz<bf16_t>(vr) ^ (pp >> 1);
+    unsigned vad[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        vad[dt] = (unsigned)(uintptr_t)UMR_LDS_PTR(smem) + OPB + vr * 128 + (((dt * 2) ^ swv) << 4) + ((pp & 1) << 3);
+
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+
+    f32x4 o[4], lacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY;
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr float DEFER = 8.0f / LOG2E;   // raise the running max only when a tile tops it by 2^8
+
+    const int ntiles = (N + TK - 1) / TK;
+    issue_tile(0);
+    for (int j = 0; j < ntiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // tile j landed for everyone; everyone is done reading buffer (j+1)&1
+        if (j + 1 < ntiles) issue_tile(j + 1);
+        const int sb = (j & 1) * STB;
+        // S^T tiles: 4 x (16 keys x 16 queries)
+        f32x4 s[4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const bf16x8 k0 = *(const bf16x8*)(kad0 + sb + sub * 2048);
+            const bf16x8 k1 = *(const bf16x8*)(kad1 + sb + sub * 2048);
+            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf.v[1], s[sub], 0, 0, 0);
+        }
+        if (j == ntiles - 1) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j * TK + 16 * sub + 4 * g + e >= N) s[sub][e] = -INFINITY;
+        }
+        // 16 scores -> 8 v_max3, then the four
+        // lane groups of a query column by two row swaps instead of two ds_bpermute round trips
+        float mx = max3f(s[0][0], s[0][1], s[0][2]);
+        mx = max3f(mx, s[0][3], s[1][0]);
+        mx = max3f(mx, s[1][1], s[1][2]);
+        mx = max3f(mx, s[1][3], s[2][0]);
+        mx = max3f(mx, s[2][1], s[2][2]);
+        mx = max3f(mx, s[2][3], s[3][0]);
+        mx = max3f(mx, s[3][1], s[3][2]);
+        mx = max3f(mx, s[3][3], s[3][3]);
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
+        const bool up = mx > m_run + DEFER;     // first tile: m_run = -inf -> true
+        if (__builtin_amdgcn_ballot_w64(up) != 0ull) {
+            const float m_new = up ? mx : m_run;
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // exp2(-inf) = 0 on the first tile
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] *= alpha;
+            lacc *= alpha;
+        }
+        const float nmc = -m_run * LOG2E;
+        // start the transposing V reads of the first half while the exponentials run
+        const unsigned vb0 = (unsigned)sb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x2 t0[4], t1[4];
+            if (half == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<0>(vad[dt] + vb0); t1[dt] = ds_tr_b64<2048>(vad[dt] + vb0); }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<4096>(vad[dt] + vb0); t1[dt] = ds_tr_b64<4096 + 2048>(vad[dt] + vb0); }
+            }
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pb[e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * half][e], LOG2E, nmc));
+                pb[4 + e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * half + 1][e], LOG2E, nmc));
+            }
+            // the wait names the registers the transposing reads fill, so that no consumer can be scheduled above it
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3])
+                         :: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 f = {t0[dt][0], t0[dt][1], t1[dt][0], t1[dt][1]};
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), pb, o[dt], 0, 0, 0);
+            }
+            lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, lacc, 0, 0, 0);
+        }
+    }
+    if (q < N) {
+        const float l_run = lacc[0];
+        const float inv = 1.0f / l_run;
+        bf16_t* orow = out + ((int64_t)b * N + q) * D + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) Vec4<bf16_t>::store(orow + dt * 16 + 4 * g, o[dt] * inv);
+        if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run + logf(l_run);
+    }
+}
+
 // ------------------------------------------------------------------ backward prep: Dq = rowsum(dO * O)
 template <typename T>
 __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restrict__ dout, float* __restrict__ dq_sum, int B, int N,
@@ -347,7 +532,10 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
     hipStream_t s = (hipStream_t)stream;
     dim3 g((N + 63) / 64, B * heads), b(256);
-    if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+    static int fast_fwd = -1;   // UMR_ATTN_FAST=0: the generic kernel for bf16 too (A/B)
+    if (fast_fwd < 0) { const char* e = getenv("UMR_ATTN_FAST"); fast_fwd = e ? atoi(e) : 1; }
+    if (dtype == UMR_BF16 && fast_fwd) hipLaunchKernelGGL(attn_fwd_bf16_kernel, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+    else if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
     else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads);
     else return umr_set_error(UMR_ERR_INVALID, "attention_fwd: dtype");
     UMR_LAUNCH_CHECK();

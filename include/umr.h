@@ -119,7 +119,9 @@ int umr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const f
 
 /* ---- fused attention (timm Attention / F.scaled_dot_product_attention; scale head_dim^-0.5) ----
  * qkv [B*N, 3*heads*64] as produced by the qkv GEMM; out [B*N, heads*64]; lse f32 [B*heads*N].
- * bwd writes dqkv in the qkv layout; dsum_ws is f32 [B*heads*N] scratch. head_dim must be 64. */
+ * bwd writes dqkv in the qkv layout; dsum_ws is scratch of umr_attention_bwd_workspace(B, N, heads) bytes
+ * (per batch-head: -lse*log2(e) and rowsum(dO*O), rows padded to 64 queries). head_dim must be 64. */
+int64_t umr_attention_bwd_workspace(int B, int N, int heads);
 int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, int N, int heads, int head_dim, int dtype,
                       umr_stream_t stream);
 int umr_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum_ws, void* dqkv,

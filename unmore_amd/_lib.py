@@ -68,6 +68,7 @@ _SIGS = {
     "umr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
     "umr_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_attention_bwd_workspace": [_i32, _i32, _i32],
     "umr_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_bilinear_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_bilinear_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -116,7 +117,7 @@ def lib():
         _lib.umr_last_error_string.restype = ctypes.c_char_p
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
-                   "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace"):
+                   "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

@@ -237,6 +237,7 @@ __device__ __forceinline__ u32x2 ds_tr_b64(unsigned addr) {
     return v;
 }
 
+template <int QB>   // 16-query blocks per wave: a workgroup covers 64 * QB queries; K / V^T fragments are read once per QB MFMAs
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int N, int heads) {
     constexpr int TK = 64;                 // keys per tile
@@ -252,8 +253,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* kb = qb + D;
     const bf16_t* vb = qb + 2 * D;
-    const int q = blockIdx.x * 64 + w * 16 + li;
-    const RowFrag<bf16_t> qf = rowfrag_global<bf16_t>(q < N ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+    const int q0 = blockIdx.x * (64 * QB) + w * (16 * QB) + li;   // query of block qi: q0 + 16 qi
+    RowFrag<bf16_t> qf[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) qf[qi] = rowfrag_global<bf16_t>(q0 + 16 * qi < N ? qb + (int64_t)(q0 + 16 * qi) * ld : nullptr, g, 0.125f);
 
     // ---- staging: wave w, instruction i fills LDS rows (w*2+i)*8 .. +8 of a tile (1 KiB); lane -> (row, slot), and
     // the swizzle is applied on the global side (slot s of row r holds chunk s ^ kswz(r))
@@ -294,10 +297,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
-    f32x4 o[4], lacc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o[QB][4], lacc[QB];
+    float m_run[QB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY;
+    for (int qi = 0; qi < QB; ++qi) {
+        lacc[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[qi] = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     constexpr float LOG2E = 1.4426950408889634f;
     constexpr float DEFER = 8.0f / LOG2E;   // raise the running max only when a tile tops it by 2^8
 
@@ -308,45 +316,61 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
         __builtin_amdgcn_s_barrier();          // tile j landed for everyone; everyone is done reading buffer (j+1)&1
         if (j + 1 < ntiles) issue_tile(j + 1);
         const int sb = (j & 1) * STB;
-        // S^T tiles: 4 x (16 keys x 16 queries)
-        f32x4 s[4];
+        // S^T tiles: 4 x (16 keys x 16 queries) per query block
+        f32x4 s[QB][4];
 #pragma unroll
         for (int sub = 0; sub < 4; ++sub) {
             const bf16x8 k0 = *(const bf16x8*)(kad0 + sb + sub * 2048);
             const bf16x8 k1 = *(const bf16x8*)(kad1 + sb + sub * 2048);
-            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf.v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            s[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf.v[1], s[sub], 0, 0, 0);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][sub], 0, 0, 0);
+            }
         }
         if (j == ntiles - 1) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (j * TK + 16 * sub + 4 * g + e >= N) s[sub][e] = -INFINITY;
-        }
-        // 16 scores -> 8 v_max3, then the four
-        // lane groups of a query column by two row swaps instead of two ds_bpermute round trips
-        float mx = max3f(s[0][0], s[0][1], s[0][2]);
-        mx = max3f(mx, s[0][3], s[1][0]);
-        mx = max3f(mx, s[1][1], s[1][2]);
-        mx = max3f(mx, s[1][3], s[2][0]);
-        mx = max3f(mx, s[2][1], s[2][2]);
-        mx = max3f(mx, s[2][3], s[3][0]);
-        mx = max3f(mx, s[3][1], s[3][2]);
-        mx = max3f(mx, s[3][3], s[3][3]);
-        mx = xor16_max(mx);
-        mx = xor32_max(mx);
-        const bool up = mx > m_run + DEFER;     // first tile: m_run = -inf -> true
-        if (__builtin_amdgcn_ballot_w64(up) != 0ull) {
-            const float m_new = up ? mx : m_run;
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // exp2(-inf) = 0 on the first tile
-            m_run = m_new;
+                    if (j * TK + 16 * sub + 4 * g + e >= N) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] *= alpha;
-            lacc *= alpha;
+                        for (int qi = 0; qi < QB; ++qi) s[qi][sub][e] = -INFINITY;
+                    }
         }
-        const float nmc = -m_run * LOG2E;
-        // start the transposing V reads of the first half while the exponentials run
+        float nmc[QB];
+        bool any_up = false;
+        float mxs[QB];
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            // 16 scores -> 8 v_max3, then the four lane groups of a query column by two row swaps instead of two
+            // ds_bpermute round trips
+            float mx = max3f(s[qi][0][0], s[qi][0][1], s[qi][0][2]);
+            mx = max3f(mx, s[qi][0][3], s[qi][1][0]);
+            mx = max3f(mx, s[qi][1][1], s[qi][1][2]);
+            mx = max3f(mx, s[qi][1][3], s[qi][2][0]);
+            mx = max3f(mx, s[qi][2][1], s[qi][2][2]);
+            mx = max3f(mx, s[qi][2][3], s[qi][3][0]);
+            mx = max3f(mx, s[qi][3][1], s[qi][3][2]);
+            mx = max2f(mx, s[qi][3][3]);
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
+            mxs[qi] = mx;
+            any_up = any_up || (mx > m_run[qi] + DEFER);     // first tile: m_run = -inf -> true
+        }
+        if (__builtin_amdgcn_ballot_w64(any_up) != 0ull) {
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const float m_new = (mxs[qi] > m_run[qi] + DEFER) ? mxs[qi] : m_run[qi];
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * LOG2E);   // exp2(-inf) = 0 on the first tile
+                m_run[qi] = m_new;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+                lacc[qi] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) nmc[qi] = -m_run[qi] * LOG2E;
         const unsigned vb0 = (unsigned)sb;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -358,12 +382,14 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<4096>(vad[dt] + vb0); t1[dt] = ds_tr_b64<4096 + 2048>(vad[dt] + vb0); }
             }
-            bf16x8 pb;
+            bf16x8 pb[QB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pb[e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * half][e], LOG2E, nmc));
-                pb[4 + e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[2 * half + 1][e], LOG2E, nmc));
-            }
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pb[qi][e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][2 * half][e], LOG2E, nmc[qi]));
+                    pb[qi][4 + e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][2 * half + 1][e], LOG2E, nmc[qi]));
+                }
             // the wait names the registers the transposing reads fill, so that no consumer can be scheduled above it
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3])
@@ -371,18 +397,25 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const u32x4 f = {t0[dt][0], t0[dt][1], t1[dt][0], t1[dt][1]};
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), pb, o[dt], 0, 0, 0);
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi)
+                    o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), pb[qi], o[qi][dt], 0, 0, 0);
             }
-            lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb, lacc, 0, 0, 0);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) lacc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qi], lacc[qi], 0, 0, 0);
         }
     }
-    if (q < N) {
-        const float l_run = lacc[0];
-        const float inv = 1.0f / l_run;
-        bf16_t* orow = out + ((int64_t)b * N + q) * D + h * HD;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) Vec4<bf16_t>::store(orow + dt * 16 + 4 * g, o[dt] * inv);
-        if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run + logf(l_run);
+    for (int qi = 0; qi < QB; ++qi) {
+        const int q = q0 + 16 * qi;
+        if (q < N) {
+            const float l_run = lacc[qi][0];
+            const float inv = 1.0f / l_run;
+            bf16_t* orow = out + ((int64_t)b * N + q) * D + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) Vec4<bf16_t>::store(orow + dt * 16 + 4 * g, o[qi][dt] * inv);
+            if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run[qi] + logf(l_run);
+        }
     }
 }
 
@@ -405,6 +438,329 @@ __global__ void attn_bwd_prep_kernel(const T* __restrict__ o, const T* __restric
         s += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
     }
     dq_sum[((int64_t)b * heads + h) * N + n] = s;
+}
+
+// ------------------------------------------------------------------ backward, bf16 throughput form
+// Same recipe as the bf16 forward: 64-row tiles by LDS-DMA into a two-deep ring, one barrier per tile, one fma + one exp per
+// recomputed probability (the prep kernel stores -lse * log2 e), fragments read once per two 16-row blocks of the wave.
+// No masking anywhere: rows >= N of K / V / Q / dO arrive as zeros (buffer bounds), so out-of-range keys contribute
+// K^T dS = 0 to dQ and out-of-range queries contribute Q^T dS = 0, dO^T P = 0 to dK, dV whatever finite P they get.
+// Workspace (f32): per (batch, head) [2][Npad], Npad = N rounded up to 64: row 0 = -lse * log2 e, row 1 = rowsum(dO * O);
+// the padding (zeros) makes the per-tile f32x4 loads of the dK/dV kernel unconditional.
+__global__ void attn_bwd_prep_bf16_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                          float* __restrict__ ws, int B, int N, int Npad, int heads) {
+    // 8 lanes per (b, n, h) row of 64 values, one 16-byte chunk each: consecutive lanes read consecutive memory
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = idx >> 3;                       // (b, n_pad, h), h fastest
+    const int c = (int)(idx & 7);
+    const int64_t total = (int64_t)B * Npad * heads;
+    if (row >= total) return;
+    const int h = (int)(row % heads);
+    const int64_t bn = row / heads;
+    const int b = (int)(bn / Npad), n = (int)(bn - (int64_t)b * Npad);
+    float ds = 0.f;
+    if (n < N) {
+        const int64_t off = (((int64_t)b * N + n) * heads + h) * HD + c * 8;
+        const bf16x8 a = *(const bf16x8*)(o + off), d = *(const bf16x8*)(dout + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ds += (float)a[e] * (float)d[e];
+    }
+    ds += __shfl_xor(ds, 1, 64);
+    ds += __shfl_xor(ds, 2, 64);
+    ds += __shfl_xor(ds, 4, 64);
+    if (c == 0) {
+        const int64_t bh = (int64_t)b * heads + h;
+        ws[(bh * 2) * Npad + n] = n < N ? -lse[bh * N + n] * 1.4426950408889634f : 0.f;
+        ws[(bh * 2 + 1) * Npad + n] = ds;
+    }
+}
+
+template <int QB>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
+                                                               int Npad, int heads) {
+    constexpr int TK = 64, OPB = TK * 128, STB = 2 * OPB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const bf16_t* kb = qb + D;
+    const bf16_t* vb = qb + 2 * D;
+    const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
+    const float* dsum_b = nl2_b + Npad;
+    const int q0 = blockIdx.x * (64 * QB) + w * (16 * QB) + li;
+    RowFrag<bf16_t> qf[QB], dof[QB];
+    float nl2q[QB], d_q[QB];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        const int q = q0 + 16 * qi;
+        const bool qok = q < N;
+        qf[qi] = rowfrag_global<bf16_t>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+        dof[qi] = rowfrag_global<bf16_t>(qok ? dout + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
+        nl2q[qi] = qok ? nl2_b[q] : 0.f;
+        d_q[qi] = qok ? dsum_b[q] : 0.f;
+    }
+    const unsigned rec = (unsigned)(((int64_t)(N - 1) * ld + HD) * 2);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, rec, 0x00020000);
+    unsigned voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (w * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ kswz<bf16_t>(r);
+        voff[i] = (unsigned)(r * (int)ld * 2 + c * 16);
+    }
+    const unsigned tile_stride = (unsigned)(TK * (int)ld * 2);
+    auto issue_tile = [&](int j) {
+        char* dst = smem + (j & 1) * STB + w * 2048;
+        const unsigned so = (unsigned)j * tile_stride;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst), 16, voff[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst + 1024), 16, voff[1], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, UMR_LDS_PTR(dst + OPB), 16, voff[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, UMR_LDS_PTR(dst + OPB + 1024), 16, voff[1], so, 0, 0);
+    };
+    const int swk = kswz<bf16_t>(li);
+    const char* kad0 = smem + li * 128 + (((0 + g) ^ swk) << 4);
+    const char* kad1 = smem + li * 128 + (((4 + g) ^ swk) << 4);
+    const int vr = 4 * g + (li >> 2), pp = li & 3;
+    const int swv = kswz<bf16_t>(vr) ^ (pp >> 1);
+    unsigned tad[4];   // K^T by transposing reads of the K tile
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        tad[dt] = (unsigned)(uintptr_t)UMR_LDS_PTR(smem) + vr * 128 + (((dt * 2) ^ swv) << 4) + ((pp & 1) << 3);
+
+    f32x4 acc[QB][4];
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int ntiles = (N + TK - 1) / TK;
+    issue_tile(0);
+    for (int j = 0; j < ntiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < ntiles) issue_tile(j + 1);
+        const int sb = (j & 1) * STB;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 s[QB][2], dp[QB][2];
+#pragma unroll
+            for (int su = 0; su < 2; ++su) {
+                const int off = sb + (2 * half + su) * 2048;
+                const bf16x8 k0 = *(const bf16x8*)(kad0 + off), k1 = *(const bf16x8*)(kad1 + off);
+                const bf16x8 v0 = *(const bf16x8*)(kad0 + off + OPB), v1 = *(const bf16x8*)(kad1 + off + OPB);
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi) {
+                    s[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    s[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][su], 0, 0, 0);      // S^T[key][query]
+                    dp[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qi].v[1], dp[qi][su], 0, 0, 0);   // dP^T[key][query]
+                }
+            }
+            u32x2 t0[4], t1[4];
+            const unsigned tb = (unsigned)sb;
+            if (half == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<0>(tad[dt] + tb); t1[dt] = ds_tr_b64<2048>(tad[dt] + tb); }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<4096>(tad[dt] + tb); t1[dt] = ds_tr_b64<4096 + 2048>(tad[dt] + tb); }
+            }
+            bf16x8 dsb[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int su = 0; su < 2; ++su)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][su][e], LOG2E, nl2q[qi]));
+                        dsb[qi][4 * su + e] = (bf16_t)(pe * (dp[qi][su][e] - d_q[qi]));
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3])
+                         :: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {   // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+                const u32x4 f = {t0[dt][0], t0[dt][1], t1[dt][0], t1[dt][1]};
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi)
+                    acc[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), dsb[qi], acc[qi][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QB; ++qi) {
+        const int q = q0 + 16 * qi;
+        if (q < N) {
+            bf16_t* orow = dqkv + ((int64_t)b * N + q) * ld + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) Vec4<bf16_t>::store(orow + dt * 16 + 4 * g, acc[qi][dt] * 0.125f);
+        }
+    }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
+                                                                int Npad, int heads) {
+    constexpr int TQ = 64, OPB = TQ * 128, STB = 2 * OPB;
+    // [stage][Q | dO][64 rows][128 B], then per stage 1 KiB: 64 x -lse*log2e | 64 x dsum | unused (zero-filled by the DMA)
+    __shared__ __attribute__((aligned(16))) char smem[2 * STB + 2 * 1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    const int D = heads * HD;
+    const int64_t ld = 3 * (int64_t)D;
+    const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
+    const bf16_t* kb = qb + D;
+    const bf16_t* vb = qb + 2 * D;
+    const bf16_t* dob = dout + (int64_t)b * N * D + h * HD;
+    const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
+    const int key0 = blockIdx.x * (64 * KB) + w * (16 * KB) + li;
+    RowFrag<bf16_t> kf[KB], vf[KB];
+#pragma unroll
+    for (int ki = 0; ki < KB; ++ki) {
+        const int key = key0 + 16 * ki;
+        kf[ki] = rowfrag_global<bf16_t>(key < N ? kb + (int64_t)key * ld : nullptr, g, 0.125f);
+        vf[ki] = rowfrag_global<bf16_t>(key < N ? vb + (int64_t)key * ld : nullptr, g, 1.0f);
+    }
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (unsigned)(((int64_t)(N - 1) * ld + HD) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (unsigned)(((int64_t)(N - 1) * D + HD) * 2), 0x00020000);
+    unsigned voffq[2], voffo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (w * 2 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ kswz<bf16_t>(r);
+        voffq[i] = (unsigned)(r * (int)ld * 2 + c * 16);
+        voffo[i] = (unsigned)(r * D * 2 + c * 16);
+    }
+    // the tile's 64 + 64 row statistics ride on the same DMA stream (wave 0, one instruction: lanes 0-15 -lse*log2e,
+    // 16-31 dsum, the rest out of range): no VMEM load in the loop has to be waited for behind the next tile's DMA
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)nl2_b, 0, (unsigned)(2 * Npad * 4), 0x00020000);
+    const unsigned voffs = lane < 16 ? (unsigned)(lane * 16) : lane < 32 ? (unsigned)(Npad * 4 + (lane - 16) * 16) : 0x80000000u;
+    const unsigned strq = (unsigned)(TQ * (int)ld * 2), stro = (unsigned)(TQ * D * 2);
+    auto issue_tile = [&](int j) {
+        char* dst = smem + (j & 1) * STB + w * 2048;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, UMR_LDS_PTR(dst), 16, voffq[0], (unsigned)j * strq, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, UMR_LDS_PTR(dst + 1024), 16, voffq[1], (unsigned)j * strq, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, UMR_LDS_PTR(dst + OPB), 16, voffo[0], (unsigned)j * stro, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, UMR_LDS_PTR(dst + OPB + 1024), 16, voffo[1], (unsigned)j * stro, 0, 0);
+        if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, UMR_LDS_PTR(smem + 2 * STB + (j & 1) * 1024), 16, voffs, (unsigned)j * 256u, 0, 0);
+    };
+    const int swk = kswz<bf16_t>(li);
+    const char* rad0 = smem + li * 128 + (((0 + g) ^ swk) << 4);
+    const char* rad1 = smem + li * 128 + (((4 + g) ^ swk) << 4);
+    const int vr = 4 * g + (li >> 2), pp = li & 3;
+    const int swv = kswz<bf16_t>(vr) ^ (pp >> 1);
+    unsigned tad[4];   // transposing reads; + OPB for the dO tile
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+        tad[dt] = (unsigned)(uintptr_t)UMR_LDS_PTR(smem) + vr * 128 + (((dt * 2) ^ swv) << 4) + ((pp & 1) << 3);
+
+    f32x4 accK[KB][4], accV[KB][4];
+#pragma unroll
+    for (int ki = 0; ki < KB; ++ki)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { accK[ki][i] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[ki][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    constexpr float LOG2E = 1.4426950408889634f;
+    const int ntiles = (N + TQ - 1) / TQ;
+    issue_tile(0);
+    for (int j = 0; j < ntiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 1 < ntiles) issue_tile(j + 1);
+        const int sb = (j & 1) * STB;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 s[KB][2], dp[KB][2], nl2v[2], dsv[2];
+#pragma unroll
+            for (int su = 0; su < 2; ++su) {
+                const char* st = smem + 2 * STB + (j & 1) * 1024 + (16 * (2 * half + su) + 4 * g) * 4;
+                nl2v[su] = *(const f32x4*)st;
+                dsv[su] = *(const f32x4*)(st + 256);
+            }
+#pragma unroll
+            for (int su = 0; su < 2; ++su) {
+                const int off = sb + (2 * half + su) * 2048;
+                const bf16x8 a0 = *(const bf16x8*)(rad0 + off), a1 = *(const bf16x8*)(rad1 + off);
+                const bf16x8 o0 = *(const bf16x8*)(rad0 + off + OPB), o1 = *(const bf16x8*)(rad1 + off + OPB);
+#pragma unroll
+                for (int ki = 0; ki < KB; ++ki) {
+                    s[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[ki].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    s[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[ki].v[1], s[ki][su], 0, 0, 0);      // S[query][key]
+                    dp[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, vf[ki].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    dp[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, vf[ki].v[1], dp[ki][su], 0, 0, 0);    // dP[query][key]
+                }
+            }
+            u32x2 t0[4], t1[4];
+            const unsigned tb = (unsigned)sb;
+            if (half == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<OPB>(tad[dt] + tb); t1[dt] = ds_tr_b64<OPB + 2048>(tad[dt] + tb); }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<OPB + 4096>(tad[dt] + tb); t1[dt] = ds_tr_b64<OPB + 4096 + 2048>(tad[dt] + tb); }
+            }
+            bf16x8 pb[KB], dsb[KB];
+#pragma unroll
+            for (int ki = 0; ki < KB; ++ki)
+#pragma unroll
+                for (int su = 0; su < 2; ++su)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ki][su][e], LOG2E, nl2v[su][e]));
+                        pb[ki][4 * su + e] = (bf16_t)pe;
+                        dsb[ki][4 * su + e] = (bf16_t)(pe * (dp[ki][su][e] - dsv[su][e]));
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3])
+                         :: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {   // dV^T[d][key] += dO^T[d][query] P[query][key]
+                const u32x4 f = {t0[dt][0], t0[dt][1], t1[dt][0], t1[dt][1]};
+#pragma unroll
+                for (int ki = 0; ki < KB; ++ki)
+                    accV[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), pb[ki], accV[ki][dt], 0, 0, 0);
+            }
+            u32x2 u0[4], u1[4];
+            if (half == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { u0[dt] = ds_tr_b64<0>(tad[dt] + tb); u1[dt] = ds_tr_b64<2048>(tad[dt] + tb); }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { u0[dt] = ds_tr_b64<4096>(tad[dt] + tb); u1[dt] = ds_tr_b64<4096 + 2048>(tad[dt] + tb); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(u0[0]), "+v"(u0[1]), "+v"(u0[2]), "+v"(u0[3]), "+v"(u1[0]), "+v"(u1[1]), "+v"(u1[2]), "+v"(u1[3])
+                         :: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {   // dK^T[d][key] += Q^T[d][query] dS[query][key]
+                const u32x4 f = {u0[dt][0], u0[dt][1], u1[dt][0], u1[dt][1]};
+#pragma unroll
+                for (int ki = 0; ki < KB; ++ki)
+                    accK[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), dsb[ki], accK[ki][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int ki = 0; ki < KB; ++ki) {
+        const int key = key0 + 16 * ki;
+        if (key < N) {
+            bf16_t* krow = dqkv + ((int64_t)b * N + key) * ld + D + h * HD;
+            bf16_t* vrow = krow + D;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                Vec4<bf16_t>::store(krow + dt * 16 + 4 * g, accK[ki][dt] * 0.125f);
+                Vec4<bf16_t>::store(vrow + dt * 16 + 4 * g, accV[ki][dt]);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ backward: dQ
@@ -534,12 +890,24 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     dim3 g((N + 63) / 64, B * heads), b(256);
     static int fast_fwd = -1;   // UMR_ATTN_FAST=0: the generic kernel for bf16 too (A/B)
     if (fast_fwd < 0) { const char* e = getenv("UMR_ATTN_FAST"); fast_fwd = e ? atoi(e) : 1; }
-    if (dtype == UMR_BF16 && fast_fwd) hipLaunchKernelGGL(attn_fwd_bf16_kernel, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+    if (dtype == UMR_BF16 && fast_fwd) {
+        if (N >= 128 && fast_fwd != 2) {   // 32 queries per wave: half the LDS reads per MFMA
+            dim3 g2((N + 127) / 128, B * heads);
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+        } else {
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+        }
+    }
     else if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
     else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads);
     else return umr_set_error(UMR_ERR_INVALID, "attention_fwd: dtype");
     UMR_LAUNCH_CHECK();
     return UMR_OK;
+}
+
+extern "C" int64_t umr_attention_bwd_workspace(int B, int N, int heads) {
+    if (B <= 0 || N <= 0 || heads <= 0) return 0;
+    return (int64_t)B * heads * 2 * ((N + 63) / 64 * 64) * 4;
 }
 
 extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* dsum_ws, void* dqkv,
@@ -550,7 +918,22 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * N * heads;
     dim3 gp((unsigned)((total + 255) / 256)), g((N + 63) / 64, B * heads), b(256);
-    if (dtype == UMR_BF16) {
+    static int fast_bwd = -1;   // UMR_ATTN_FAST=0: the generic kernels for bf16 too (A/B)
+    if (fast_bwd < 0) { const char* e = getenv("UMR_ATTN_FAST"); fast_bwd = e ? atoi(e) : 1; }
+    if (dtype == UMR_BF16 && fast_bwd) {
+        const int Npad = (N + 63) / 64 * 64;
+        const int64_t tp = (int64_t)B * heads * Npad * 8;
+        hipLaunchKernelGGL(attn_bwd_prep_bf16_kernel, dim3((unsigned)((tp + 255) / 256)), b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, lse,
+                           dsum_ws, B, N, Npad, heads);
+        if (N >= 128 && fast_bwd != 2) {
+            dim3 g2((N + 127) / 128, B * heads);
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+        }
+    } else if (dtype == UMR_BF16) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, gp, b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, dsum_ws, B, N, heads);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);
         hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);

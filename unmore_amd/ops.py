@@ -205,7 +205,7 @@ def attention_bwd(qkv, out, dout, lse, B, N, heads):
     _need_gpu(qkv, out, dout)
     assert dout.is_contiguous() and out.is_contiguous()
     dqkv = torch.empty_like(qkv)
-    dsum = torch.empty(B * heads * N, dtype=torch.float32, device=qkv.device)
+    dsum = torch.empty(L.lib().umr_attention_bwd_workspace(B, N, heads) // 4, dtype=torch.float32, device=qkv.device)
     L.check(L.lib().umr_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(dsum), _p(dqkv), B, N, heads, 64, _DT[qkv.dtype],
                                       _stream()), "umr_attention_bwd")
     return dqkv

@@ -49,7 +49,7 @@ def test_layernorm(dtype, M, D):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,N,heads", [(2, 65, 2), (1, 577, 3), (3, 100, 1), (2, 17, 2)])
+@pytest.mark.parametrize("B,N,heads", [(2, 65, 2), (1, 577, 3), (3, 100, 1), (2, 17, 2), (1, 1370, 2), (2, 128, 1), (1, 129, 2)])
 def test_attention(dtype, B, N, heads):
     from unmore_amd import ops
     dev = _dev()

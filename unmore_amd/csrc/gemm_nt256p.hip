@@ -33,8 +33,23 @@ constexpr int LDS2P = STG_OFF + STG_BYTES;  // 160 KiB
 
 typedef bf16_t T2;
 
-template <int CONV, int EPI, bool PH2>
+// per 16-bit half: 0xFFFF where the bf16 is > 0 (its bits, read as a signed 16-bit integer, are positive), else 0
+__device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
+    typedef __attribute__((ext_vector_type(2))) short s16x2;
+    const s16x2 one = {1, 1}, zero = {0, 0};
+    s16x2 v = __builtin_bit_cast(s16x2, a);
+    v = __builtin_elementwise_min(v, one);
+    v = __builtin_elementwise_max(v, zero);
+    v = zero - v;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// EPI: 1 = generic epilogue, 3 = fast class (AUXM: 0 none, 1 residual add, 2 ReLU mask; RED: fused row reduction), 4 = GELU class.
+// The fast class is specialised at compile time: as runtime flag tests its 32 values per thread and pass cost ~1000
+// issue cycles per wave (4 branches per 4 values), and an epilogue pass is pure issue time on 2 waves per SIMD.
+template <int CONV, int EPI, int AUXM, bool RED>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles) {
+    constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
     constexpr unsigned OOB = 0x80000000u;
@@ -276,12 +291,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         }
     };
     int c_par = 0;
+    // Fast / GELU classes: the accumulators start from the bias instead of zero.  The bias vectors of the NEXT tile are
+    // fetched at the start of each epilogue (first tile: here): a load issued where it is needed would be waited for at once,
+    // and vmcnt retires in order -- that wait drained the next tile's prefetched K-tiles (~1900 cycles per tile, measured
+    // with s_memtime stamps).  Fetched there, everything issued before it has long landed when the epilogue ends.
+    constexpr bool BIAS_INIT = (EPI == 3 || EPI == 4);
+    f32x4 bqn[4];
+    auto fetch_bias = [&](int it_) {
+        const int v_ = it_ * G + pw;
+        const int tn_ = v_ - (v_ / tiles_n) * tiles_n;
+#pragma unroll
+        for (int ntl = 0; ntl < 4; ++ntl) {
+            const int n = tn_ * BN2 + wc * 64 + ntl * 16 + fq * 4;
+            bqn[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((p.flags & UMR_EPI_BIAS) && it_ < n_my && n < p.N) bqn[ntl] = *(const f32x4*)(p.bias + n);
+        }
+    };
+    if (BIAS_INIT) fetch_bias(0);
 #pragma unroll 1
     for (int it = 0; it < n_my; ++it) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 4; ++j) acc[i][j] = BIAS_INIT ? bqn[j] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int t = 0; t < nt; ++t) {
             tile_body(smem + c_par * BUF2);
@@ -292,36 +324,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
         const int m0 = tm * BM2, n0 = tn * BN2;
         if (EPI == 3) {
-            // fast class: bias, aux add / ReLU mask, ReLU.  The epilogue math runs on the accumulators in their
-            // fragment layout (a lane's 4 columns per 16-column tile -> 4 bias vectors per thread), the results are
-            // staged as bf16 -- 64 tile rows per pass instead of 32, so 4 passes / 8 barriers instead of 8 / 16 and half
-            // the LDS traffic -- and leave as plain 16-byte copies.
-            f32x4 bq[4];
-#pragma unroll
-            for (int ntl = 0; ntl < 4; ++ntl) {
-                const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                bq[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((p.flags & UMR_EPI_BIAS) && n < p.N) bq[ntl] = *(const f32x4*)(p.bias + n);
-            }
+            // fast class: (bias already in the accumulators), aux add / ReLU mask, ReLU.  The math runs on the accumulators in
+            // their fragment layout, the results are staged as bf16 -- 64 tile rows per pass, 4 passes / 8 barriers, half the
+            // LDS traffic of an f32 staging -- and leave as plain 16-byte copies.
+            fetch_bias(it + 1);
+            // ReLU without a branch: max with 0 or with -inf
+            const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
             // fused row reduction (umr_gemm_desc.red_*): this lane's 16 columns of the reduction weights; the partial dot
             // products of a row are summed over the 4 lanes that share it (fq) and written per 64-column wave slice
-            const bool red = p.red_w != nullptr;
             f32x4 rw[2][4];
+            if (RED) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-                for (int ntl = 0; ntl < 4; ++ntl) {
-                    const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                    rw[c][ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (red && c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
-                }
-            // aux operand (residual add / ReLU mask) in the same fragment layout: 8-byte loads, fetched one pass ahead so that
-            // no load is issued behind a store it would have to wait for (vmcnt retires in order)
-            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU)) != 0;
+                    for (int ntl = 0; ntl < 4; ++ntl) {
+                        const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
+                        rw[c][ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
+                    }
+            }
+            // Residual operand (AUXM 1): added in f32 before the one rounding, so it is read in the fragment layout (8-byte
+            // loads), one pass ahead so that no load is issued behind a store it would have to wait for.
             bf16x4 axq[2][2][4];
             auto load_aux3 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && use_aux) {
+                if (PS < 4 && AUXM == 1) {
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh) {
                         const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
@@ -336,11 +363,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     }
                 }
             };
+            // ReLU-mask operand (AUXM 2): masking commutes with the bf16 rounding, so it is applied to the staged bf16 values in
+            // the copy-out layout -- 16-byte loads, a wave reads whole 512-byte row segments -- again one pass ahead.
+            u32x4 axc[2][4];
+            auto load_auxc = [&](auto ptag) {
+                constexpr int PS = decltype(ptag)::value;
+                if (PS < 4 && AUXM == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
+                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
+                        u32x4 a = {0u, 0u, 0u, 0u};
+                        if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                        axc[PS & 1][j] = a;
+                    }
+                }
+            };
             load_aux3(std::integral_constant<int, 0>{});
+            load_auxc(std::integral_constant<int, 0>{});
             char* stb = smem + STG_OFF;
             auto pass3 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
                 load_aux3(std::integral_constant<int, PS + 1>{});
+                load_auxc(std::integral_constant<int, PS + 1>{});
                 if (PS > 0) __syncthreads();
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
@@ -348,31 +393,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
-                        f32x4 v = acc[PS * 2 + mh][ntl] + bq[ntl];
-                        if (use_aux) {
+                        f32x4 v = acc[PS * 2 + mh][ntl];
+                        if (AUXM == 1) {
                             const bf16x4 a = axq[PS & 1][mh][ntl];
-                            if (p.flags & UMR_EPI_ADD_AUX) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = (float)a[e] > 0.f ? v[e] : 0.f;
-                            }
+                            for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
                         }
-                        if (p.act == UMR_ACT_RELU) {
+                        if (AUXM != 2) {   // (with a ReLU mask the activation is never ReLU: the mask is the ReLU's derivative)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
                         }
                         bf16x4 t;
                         t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
                         const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
                         *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
-                        if (red) {   // dot products with the values AS STORED (bf16-rounded)
+                        if (RED) {   // dot products with the values AS STORED (bf16-rounded)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { rs0 += (float)t[e] * rw[0][ntl][e]; rs1 += (float)t[e] * rw[1][ntl][e]; }
                         }
                     }
-                    if (red) {
+                    if (RED) {
                         rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
                         rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
                         const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
@@ -388,8 +428,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 for (int j = 0; j < 4; ++j) {
                     const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
                     const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                    if (m < p.M && n < p.N && !p.no_store)
-                        *(uint4*)((T2*)p.C + (int64_t)m * p.ldc + n) = *(const uint4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                    u32x4 o = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                    if (AUXM == 2) {
+                        // keep a bf16 where the mask operand is > 0, i.e. where its 16 bits read as a positive integer:
+                        // min(a, 1) -> max(.., 0) is 1 or 0 per half, 0 - that is 0xFFFF or 0
+                        const u32x4 a = axc[PS & 1][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] &= pos_mask_bf16x2(a[e]);
+                    }
+                    if (m < p.M && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
                 }
             };
             pass3(std::integral_constant<int, 0>{}); pass3(std::integral_constant<int, 1>{});
@@ -399,13 +446,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // GELU class (the transformer MLP): act == GELU with the pre-activation optionally saved to C2 (c2_mode 2), or
             // the GELU'-masked gradient (MASK_DGELU).  Same bf16 staging as the fast class, in its own instantiation so that
             // the erf code does not sit in the instruction stream of the conv / 1x1 kernels.
-            f32x4 bq[4];
-#pragma unroll
-            for (int ntl = 0; ntl < 4; ++ntl) {
-                const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                bq[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if ((p.flags & UMR_EPI_BIAS) && n < p.N) bq[ntl] = *(const f32x4*)(p.bias + n);
-            }
+            fetch_bias(it + 1);
             const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_DGELU)) != 0;
             const bool two_out = p.c2_mode == 2;
             bf16x4 axq[2][2][4];
@@ -445,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
-                        f32x4 v = acc[PS * 2 + mh][ntl] + bq[ntl];
+                        f32x4 v = acc[PS * 2 + mh][ntl];   // bias included (accumulator start value)
                         if (use_aux) {
                             const bf16x4 a = axq[PS & 1][mh][ntl];
                             if (p.flags & UMR_EPI_ADD_AUX) {
@@ -559,15 +600,17 @@ int num_cus() {
 
 }  // namespace
 
-// the epilogue class of the fast (EPI 3) instantiation
-bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d);
-// the epilogue class that implements red_* / no_store
-bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) { return umr_nt256p_fast_epilogue(d); }
+// the epilogue class of the fast (EPI 3) instantiations
 bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
     const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0);
+    const bool mask = (d->flags & UMR_EPI_MASK_RELU) != 0, add = (d->flags & UMR_EPI_ADD_AUX) != 0;
     return vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
-           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) &&
-           (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU);
+           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) && !(mask && add) &&
+           (d->act == UMR_ACT_NONE || (d->act == UMR_ACT_RELU && !mask));
+}
+// the epilogue class that implements red_* / no_store (the reduction only without an aux operand)
+bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) {
+    return umr_nt256p_fast_epilogue(d) && (!d->red_w || (d->conv == 0 && !(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU))));
 }
 
 // the GELU class (EPI 4): GELU (optionally saving the pre-activation) or the GELU'-masked gradient
@@ -601,27 +644,35 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     dim3 g((unsigned)grid), b(512);
     // fast class = bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
-    // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs (tools/kbench.py) -> conv only
-    static int ph2_env = -2;
-    if (ph2_env == -2) { const char* e = getenv("UMR_NT256_PH2"); ph2_env = e ? atoi(e) : -1; }
-    const int ph2 = ph2_env >= 0 ? ph2_env : (d->conv == 1 ? 1 : 0);
-#define L256P(CV, EP)                                                                                                  \
+#define L256P(CV, EP, AX, RD)                                                                                          \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
         if (!set_) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P);  \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, AX, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        if (ph2) hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, true>), g, b, LDS2P, s, *d, tiles_n, (int)total);       \
-        else hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, false>), g, b, LDS2P, s, *d, tiles_n, (int)total);          \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total);              \
     } while (0)
-    // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged, optional fused row reduction); EPI 4: the GELU
-    // class (plain GEMM only); EPI 1: everything else
-    if ((d->red_w || d->no_store) && !fast_ep)
-        return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class");
-    if (d->conv == 0) { if (fast_ep) L256P(0, 3); else if (umr_nt256p_gelu_epilogue(d)) L256P(0, 4); else L256P(0, 1); }
-    else { if (fast_ep) L256P(1, 3); else L256P(1, 1); }
+    // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged; one instantiation per aux mode, plus the fused
+    // row reduction); EPI 4: the GELU class (plain GEMM only); EPI 1: everything else
+    if ((d->red_w || d->no_store) && !umr_nt256p_plain_epilogue(d))
+        return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class (no aux operand with the reduction)");
+    const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
+    if (d->conv == 0) {
+        if (fast_ep) {
+            if (d->red_w) L256P(0, 3, 0, true);
+            else if (auxm == 0) L256P(0, 3, 0, false);
+            else if (auxm == 1) L256P(0, 3, 1, false);
+            else L256P(0, 3, 2, false);
+        } else if (umr_nt256p_gelu_epilogue(d)) L256P(0, 4, 0, false);
+        else L256P(0, 1, 0, false);
+    } else {
+        if (fast_ep) {
+            if (auxm == 0) L256P(1, 3, 0, false);
+            else if (auxm == 1) L256P(1, 3, 1, false);
+            else L256P(1, 3, 2, false);
+        } else L256P(1, 1, 0, false);
+    }
 #undef L256P
     UMR_LAUNCH_CHECK();
     return UMR_OK;

@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libumr.so")
+LIB_PATH = os.environ.get("UMR_LIB") or os.path.join(_HERE, "lib", "libumr.so")   # UMR_LIB: an instrumented build (tools/probe)
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1

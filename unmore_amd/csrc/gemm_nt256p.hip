@@ -33,6 +33,26 @@ constexpr int LDS2P = STG_OFF + STG_BYTES;  // 160 KiB
 
 typedef bf16_t T2;
 
+// two packed bf16 gradients times GELU'(two packed bf16 pre-activations)
+__device__ __forceinline__ unsigned mul_dgelu_bf16x2(unsigned g, unsigned x) {
+    const float lo = __builtin_bit_cast(float, g << 16) * dgelu_sel<bf16_t>(__builtin_bit_cast(float, x << 16));
+    const float hi = __builtin_bit_cast(float, g & 0xFFFF0000u) * dgelu_sel<bf16_t>(__builtin_bit_cast(float, x & 0xFFFF0000u));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 r;
+    r[0] = (bf16_t)lo; r[1] = (bf16_t)hi;
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// two packed bf16 + two packed bf16, each sum in f32, rounded once
+__device__ __forceinline__ unsigned add_bf16x2(unsigned x, unsigned y) {
+    const float lo = __builtin_bit_cast(float, x << 16) + __builtin_bit_cast(float, y << 16);
+    const float hi = __builtin_bit_cast(float, x & 0xFFFF0000u) + __builtin_bit_cast(float, y & 0xFFFF0000u);
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 r;
+    r[0] = (bf16_t)lo; r[1] = (bf16_t)hi;
+    return __builtin_bit_cast(unsigned, r);
+}
+
 // per 16-bit half: 0xFFFF where the bf16 is > 0 (its bits, read as a signed 16-bit integer, are positive), else 0
 __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
     typedef __attribute__((ext_vector_type(2))) short s16x2;
@@ -308,17 +328,33 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         }
     };
     if (BIAS_INIT) fetch_bias(0);
+    // -DUMR_NT256P_TIMESTAMPS (tools/probe/ts_probe.py builds its own library with it): workgroup 0 / thread 0 writes
+    // s_memtime stamps of the first 16 tiles to red_out when red_c == 9 -- how the per-tile budget was taken apart
+#ifdef UMR_NT256P_TIMESTAMPS
+    const bool dbg = (p.red_c == 9) && blockIdx.x == 0 && tid == 0;
+    unsigned long long* dbgp = (unsigned long long*)p.red_out;
+#define TS(slot) do { if (dbg && it < 16) dbgp[it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define TS(slot) do { } while (0)
+#endif
 #pragma unroll 1
     for (int it = 0; it < n_my; ++it) {
+        TS(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = BIAS_INIT ? bqn[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        TS(1);
 #pragma unroll 1
         for (int t = 0; t < nt; ++t) {
             tile_body(smem + c_par * BUF2);
             c_par ^= 1;
+#ifdef UMR_NT256P_TIMESTAMPS
+            if (t == 0) TS(2);
+            if (t == 1) TS(3);
+#endif
         }
+        TS(4);
         // ---- epilogue of output tile `it`; the next tile's first K-tiles are already in flight
         const int v = it * G + pw;
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
@@ -343,32 +379,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         if (c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
                     }
             }
-            // Residual operand (AUXM 1): added in f32 before the one rounding, so it is read in the fragment layout (8-byte
-            // loads), one pass ahead so that no load is issued behind a store it would have to wait for.
-            bf16x4 axq[2][2][4];
-            auto load_aux3 = [&](auto ptag) {
-                constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && AUXM == 1) {
-#pragma unroll
-                    for (int mh = 0; mh < 2; ++mh) {
-                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
-#pragma unroll
-                        for (int ntl = 0; ntl < 4; ++ntl) {
-                            const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                            bf16x4 a4;
-                            a4[0] = a4[1] = a4[2] = a4[3] = (bf16_t)0.f;   // out-of-range rows / columns: defined values
-                            if (m < p.M && n < p.N) a4 = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                            axq[PS & 1][mh][ntl] = a4;
-                        }
-                    }
-                }
-            };
-            // ReLU-mask operand (AUXM 2): masking commutes with the bf16 rounding, so it is applied to the staged bf16 values in
-            // the copy-out layout -- 16-byte loads, a wave reads whole 512-byte row segments -- again one pass ahead.
+            // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
+            // 512-byte row segments (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per
+            // instruction, and the epilogue of a residual-add GEMM took 25 k cycles against 6.7 k without aux).  Loads are issued
+            // one pass ahead so that none is issued behind a store it would have to wait for.  ReLU mask (AUXM 2): masking
+            // commutes with the rounding -- bit-identical.  Residual add (AUXM 1): bf16(bf16(acc) + aux), i.e. the GEMM result
+            // is rounded to the storage type before the residual is added, as a separate Linear + add in bf16 would do.
             u32x4 axc[2][4];
             auto load_auxc = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && AUXM == 2) {
+                if (PS < 4 && AUXM != 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
@@ -379,12 +399,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     }
                 }
             };
-            load_aux3(std::integral_constant<int, 0>{});
             load_auxc(std::integral_constant<int, 0>{});
             char* stb = smem + STG_OFF;
             auto pass3 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                load_aux3(std::integral_constant<int, PS + 1>{});
                 load_auxc(std::integral_constant<int, PS + 1>{});
                 if (PS > 0) __syncthreads();
 #pragma unroll
@@ -394,12 +412,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
                         f32x4 v = acc[PS * 2 + mh][ntl];
-                        if (AUXM == 1) {
-                            const bf16x4 a = axq[PS & 1][mh][ntl];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
-                        }
-                        if (AUXM != 2) {   // (with a ReLU mask the activation is never ReLU: the mask is the ReLU's derivative)
+                        if (AUXM == 0) {   // (an aux operand excludes ReLU: umr_nt256p_fast_epilogue)
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
                         }
@@ -436,76 +449,57 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] &= pos_mask_bf16x2(a[e]);
                     }
+                    if (AUXM == 1) {
+                        const u32x4 a = axc[PS & 1][j];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], a[e]);
+                    }
                     if (m < p.M && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
                 }
             };
-            pass3(std::integral_constant<int, 0>{}); pass3(std::integral_constant<int, 1>{});
+            pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});
             pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
+            TS(6);
             __syncthreads();
+            TS(7);
         } else if (EPI == 4) {
             // GELU class (the transformer MLP): act == GELU with the pre-activation optionally saved to C2 (c2_mode 2), or
             // the GELU'-masked gradient (MASK_DGELU).  Same bf16 staging as the fast class, in its own instantiation so that
-            // the erf code does not sit in the instruction stream of the conv / 1x1 kernels.
+            // the erf code does not sit in the instruction stream of the conv / 1x1 kernels.  The GELU' factor is applied in
+            // the copy-out layout (16-byte coalesced loads of the pre-activation, one pass ahead), to the stored bf16 value.
             fetch_bias(it + 1);
-            const bool use_aux = (p.flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_DGELU)) != 0;
-            const bool two_out = p.c2_mode == 2;
-            bf16x4 axq[2][2][4];
-            auto load_aux4 = [&](auto ptag) {
+            constexpr bool dgelu = (AUXM == 2);   // instantiated as <0, 4, 0> (GELU forward) and <0, 4, 2> (GELU'-masked gradient)
+            const bool two_out = !dgelu && p.c2_mode == 2;
+            u32x4 axc[2][4];
+            auto load_auxc = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && use_aux) {
+                if (PS < 4 && dgelu) {
 #pragma unroll
-                    for (int mh = 0; mh < 2; ++mh) {
-                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
-#pragma unroll
-                        for (int ntl = 0; ntl < 4; ++ntl) {
-                            const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                            bf16x4 a4;
-                            a4[0] = a4[1] = a4[2] = a4[3] = (bf16_t)0.f;
-                            if (m < p.M && n < p.N) a4 = *(const bf16x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                            axq[PS & 1][mh][ntl] = a4;
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
+                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
+                        u32x4 a = {0u, 0u, 0u, 0u};
+                        if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                        axc[PS & 1][j] = a;
                     }
                 }
             };
-            load_aux4(std::integral_constant<int, 0>{});
+            load_auxc(std::integral_constant<int, 0>{});
             char* stb = smem + STG_OFF;
-            auto copy_out = [&](T2* dst, int ld, int PS) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                    const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                    if (m < p.M && n < p.N)
-                        *(uint4*)(dst + (int64_t)m * ld + n) = *(const uint4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
-                }
-            };
             auto pass4 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                load_aux4(std::integral_constant<int, PS + 1>{});
-                f32x4 vv[2][4];
-#pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) {
-                        f32x4 v = acc[PS * 2 + mh][ntl];   // bias included (accumulator start value)
-                        if (use_aux) {
-                            const bf16x4 a = axq[PS & 1][mh][ntl];
-                            if (p.flags & UMR_EPI_ADD_AUX) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)a[e];
-                            } else {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] *= dgelu_sel<T2>((float)a[e]);
-                            }
-                        }
-                        vv[mh][ntl] = v;
-                    }
-                auto stage = [&]() {
+                load_auxc(std::integral_constant<int, PS + 1>{});
+                auto stage = [&](bool gelu) {
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh) {
                         const int lr = wr * 32 + mh * 16 + frow;
 #pragma unroll
                         for (int ntl = 0; ntl < 4; ++ntl) {
-                            const f32x4 v = vv[mh][ntl];
+                            f32x4 v = acc[PS * 2 + mh][ntl];   // bias included (accumulator start value)
+                            if (gelu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = gelu_sel<T2>(v[e]);
+                            }
                             bf16x4 t;
                             t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
                             const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
@@ -513,24 +507,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         }
                     }
                 };
+                auto copy_out = [&](T2* dst, int ld, bool scale) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
+                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
+                        u32x4 o = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                        if (scale) {
+                            const u32x4 a = axc[PS & 1][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = mul_dgelu_bf16x2(o[e], a[e]);
+                        }
+                        if (m < p.M && n < p.N) *(u32x4*)(dst + (int64_t)m * ld + n) = o;
+                    }
+                };
                 if (PS > 0) __syncthreads();
                 if (two_out) {   // the pre-activation, as the backward pass wants it
-                    stage();
+                    stage(false);
                     __syncthreads();
-                    copy_out((T2*)p.C2, p.ldc2, PS);
+                    copy_out((T2*)p.C2, p.ldc2, false);
                     __syncthreads();
                 }
-                if (p.act == UMR_ACT_GELU) {
-#pragma unroll
-                    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-                        for (int ntl = 0; ntl < 4; ++ntl)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) vv[mh][ntl][e] = gelu_sel<T2>(vv[mh][ntl][e]);
-                }
-                stage();
+                stage(!dgelu);
                 __syncthreads();
-                copy_out((T2*)p.C, p.ldc, PS);
+                copy_out((T2*)p.C, p.ldc, dgelu);
             };
             pass4(std::integral_constant<int, 0>{}); pass4(std::integral_constant<int, 1>{});
             pass4(std::integral_constant<int, 2>{}); pass4(std::integral_constant<int, 3>{});
@@ -576,6 +576,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // the trailing (zero-fill) LDS-DMA groups must land before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef QUADRANT
+#undef TS
 #undef QUADRANT_D
 #undef MFMA
 #undef PHASE_SYNC
@@ -606,7 +607,7 @@ bool umr_nt256p_fast_epilogue(const umr_gemm_desc* d) {
     const bool mask = (d->flags & UMR_EPI_MASK_RELU) != 0, add = (d->flags & UMR_EPI_ADD_AUX) != 0;
     return vec_ok && d->c2_mode == 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
            !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_DGELU)) && !(mask && add) &&
-           (d->act == UMR_ACT_NONE || (d->act == UMR_ACT_RELU && !mask));
+           (d->act == UMR_ACT_NONE || (d->act == UMR_ACT_RELU && !mask && !add));
 }
 // the epilogue class that implements red_* / no_store (the reduction only without an aux operand)
 bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) {
@@ -617,8 +618,8 @@ bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d) {
 static bool umr_nt256p_gelu_epilogue(const umr_gemm_desc* d) {
     const bool vec_ok = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && ((d->ldaux & 7) == 0) && ((d->ldc2 & 7) == 0);
     const bool dg = (d->flags & UMR_EPI_MASK_DGELU) != 0;
-    return vec_ok && (d->c2_mode == 0 || d->c2_mode == 2) && d->c_rows_in <= 0 && d->aux_mod <= 0 && !d->red_w && !d->no_store &&
-           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_RELU)) &&
+    return vec_ok && (d->c2_mode == 0 || (d->c2_mode == 2 && !dg)) && d->c_rows_in <= 0 && d->aux_mod <= 0 && !d->red_w && !d->no_store &&
+           !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_ADD_AUX2 | UMR_EPI_OUT_F32 | UMR_EPI_MASK_RELU | UMR_EPI_ADD_AUX)) &&
            ((d->act == UMR_ACT_GELU && !dg) || (d->act == UMR_ACT_NONE && dg));
 }
 
@@ -664,7 +665,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
             else if (auxm == 0) L256P(0, 3, 0, false);
             else if (auxm == 1) L256P(0, 3, 1, false);
             else L256P(0, 3, 2, false);
-        } else if (umr_nt256p_gelu_epilogue(d)) L256P(0, 4, 0, false);
+        } else if (umr_nt256p_gelu_epilogue(d)) { if (d->flags & UMR_EPI_MASK_DGELU) L256P(0, 4, 2, false); else L256P(0, 4, 0, false); }
         else L256P(0, 1, 0, false);
     } else {
         if (fast_ep) {

@@ -46,7 +46,7 @@ def _workspace(nbytes, device):
 
 def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbias=None, rows_per_batch=0,
             act=L.ACT_NONE, mask_relu=False, mask_dgelu=False, c2_mode=0, out_f32=False,
-            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False):
+            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False, _stamps=None):
     """C[M,N] = epi(A[M,K] . B[N,K]^T).  A: [M,K] (2-D, row stride lda) or NHWC
     [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci)).
     red_w ([c, N] f32, c in {1,2}): fused row reduction (umr_gemm_desc.red_*) -> returns (C, partials [ceil(N/64), M, c]);
@@ -117,6 +117,8 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
         partials = torch.empty(((N + 63) // 64, M_, red_w.shape[0]), dtype=torch.float32, device=A.device)
         d.red_w, d.red_out, d.red_c = _p(red_w), _p(partials), red_w.shape[0]
     d.no_store = 1 if no_store else 0
+    if _stamps is not None:   # instrumented library only (tools/probe/ts_probe.py): int64 [16, 8] cycle stamps
+        d.red_out, d.red_c = _p(_stamps), 9
     L.check(_timed_call(d), "umr_gemm_nt")
     if red_w is not None:
         return out, partials

@@ -382,10 +382,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
             // 512-byte row segments (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per
             // instruction, and the epilogue of a residual-add GEMM took 25 k cycles against 6.7 k without aux).  Loads are issued
-            // one pass ahead so that none is issued behind a store it would have to wait for.  ReLU mask (AUXM 2): masking
+            // two passes ahead (their first touch is an HBM round trip, longer than one pass).  ReLU mask (AUXM 2): masking
             // commutes with the rounding -- bit-identical.  Residual add (AUXM 1): bf16(bf16(acc) + aux), i.e. the GEMM result
             // is rounded to the storage type before the residual is added, as a separate Linear + add in bf16 would do.
-            u32x4 axc[2][4];
+            u32x4 axc[3][4];   // loads run two passes ahead of their use
             auto load_auxc = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
                 if (PS < 4 && AUXM != 0) {
@@ -395,15 +395,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
                         u32x4 a = {0u, 0u, 0u, 0u};
                         if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                        axc[PS & 1][j] = a;
+                        axc[PS % 3][j] = a;
                     }
                 }
             };
             load_auxc(std::integral_constant<int, 0>{});
+            load_auxc(std::integral_constant<int, 1>{});
             char* stb = smem + STG_OFF;
             auto pass3 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                load_auxc(std::integral_constant<int, PS + 1>{});
+                load_auxc(std::integral_constant<int, PS + 2>{});
                 if (PS > 0) __syncthreads();
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
@@ -445,12 +446,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     if (AUXM == 2) {
                         // keep a bf16 where the mask operand is > 0, i.e. where its 16 bits read as a positive integer:
                         // min(a, 1) -> max(.., 0) is 1 or 0 per half, 0 - that is 0xFFFF or 0
-                        const u32x4 a = axc[PS & 1][j];
+                        const u32x4 a = axc[PS % 3][j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] &= pos_mask_bf16x2(a[e]);
                     }
                     if (AUXM == 1) {
-                        const u32x4 a = axc[PS & 1][j];
+                        const u32x4 a = axc[PS % 3][j];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], a[e]);
                     }
@@ -466,11 +467,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // GELU class (the transformer MLP): act == GELU with the pre-activation optionally saved to C2 (c2_mode 2), or
             // the GELU'-masked gradient (MASK_DGELU).  Same bf16 staging as the fast class, in its own instantiation so that
             // the erf code does not sit in the instruction stream of the conv / 1x1 kernels.  The GELU' factor is applied in
-            // the copy-out layout (16-byte coalesced loads of the pre-activation, one pass ahead), to the stored bf16 value.
+            // the copy-out layout (16-byte coalesced loads of the pre-activation, two passes ahead), to the stored bf16 value.
             fetch_bias(it + 1);
             constexpr bool dgelu = (AUXM == 2);   // instantiated as <0, 4, 0> (GELU forward) and <0, 4, 2> (GELU'-masked gradient)
             const bool two_out = !dgelu && p.c2_mode == 2;
-            u32x4 axc[2][4];
+            u32x4 axc[3][4];   // loads run two passes ahead of their use
             auto load_auxc = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
                 if (PS < 4 && dgelu) {
@@ -480,15 +481,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
                         u32x4 a = {0u, 0u, 0u, 0u};
                         if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                        axc[PS & 1][j] = a;
+                        axc[PS % 3][j] = a;
                     }
                 }
             };
             load_auxc(std::integral_constant<int, 0>{});
+            load_auxc(std::integral_constant<int, 1>{});
             char* stb = smem + STG_OFF;
             auto pass4 = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
-                load_auxc(std::integral_constant<int, PS + 1>{});
+                load_auxc(std::integral_constant<int, PS + 2>{});
                 auto stage = [&](bool gelu) {
 #pragma unroll
                     for (int mh = 0; mh < 2; ++mh) {
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
                         u32x4 o = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
                         if (scale) {
-                            const u32x4 a = axc[PS & 1][j];
+                            const u32x4 a = axc[PS % 3][j];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = mul_dgelu_bf16x2(o[e], a[e]);
                         }

@@ -251,6 +251,13 @@ def test_large_tile_conv3x3_fwd(nb, H, W, Cin, N):
     aux = _rnd((nb * H * W, N), torch.bfloat16, dev, 34)
     out = ops.gemm_nt(x, wp, None, conv=1, aux=aux, mask_relu=True)
     torch.testing.assert_close(out.float(), (ref - bias) * (aux.float() > 0), atol=3e-2, rtol=3e-2)
+    # the mask is applied to the stored bf16 values: bit-identical to masking the unmasked output
+    plain = ops.gemm_nt(x, wp, None, conv=1)
+    assert torch.equal(out, torch.where(aux > 0, plain, torch.zeros_like(plain)))
+    # residual add (fusion blocks: conv2 + skip): bf16(bf16(conv + bias) + aux)
+    out = ops.gemm_nt(x, wp, bias, conv=1, aux=aux)
+    with_bias = ops.gemm_nt(x, wp, bias, conv=1)
+    assert torch.equal(out, (with_bias.float() + aux.float()).to(torch.bfloat16))
 
 
 def test_large_tile_tn_plain_and_conv():

@@ -11,8 +11,9 @@
 //     X0 / X1 : X  columns of k-half 0 / 1 of the four wave columns (c' = wk*32 + k_local)
 // which are exactly the read sets of the quadrants Q0=(nh0,kh0) Q1=(nh0,kh1) Q2=(nh1,kh1) Q3=(nh1,kh0), so the
 // staging table of gemm_nt256.hip applies verbatim with A -> Y and B -> X.
-// Descriptor bases move with the stage (scalar arithmetic); per-lane voffsets are loop constants; the conv fast
-// path (stride 1, Wo >= 64: a stage straddles at most one image-row end) masks halo lanes once per stage.
+// Descriptors are per split (loop invariant), the stage is the DMA's scalar offset, per-lane voffsets are loop constants;
+// the conv path (stride 1, Wo >= 64: a stage straddles at most one image-row end) masks halo lanes once per stage --
+// a bit test against two scalar conditions when Wo % 64 == 0.
 // Row tails of the split fall out of num_records (plain) or are masked with the halo lanes (conv).
 // dbias: workgroups of k-tile 0 add up their dY fragments on the VALU (one f32 per n-tile and lane).
 #include "umr_common.h"
@@ -28,7 +29,9 @@ constexpr int TLDS = 2 * TBUF;       // 128 KiB
 __device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
 // sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
-template <int CONV, bool PH2>
+// WF (conv only): Wo % 64 == 0 -- a 64-row stage never runs over the end of an image row, so the halo test of a stage is
+// two scalar conditions and a bit test per lane instead of a per-lane pixel walk
+template <int CONV, bool PH2, bool WF>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int ntiles, int rows_per_split,
                                                             float* slab, float* bslab, int mapmode) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     unsigned vo[4][2];      // per-lane voffsets (or OOB) of the four groups, relative to the stage's descriptor bases
     unsigned x_eff[2][2];   // conv: X groups after the per-stage halo mask
     int x_r[2][2], x_t[2][2];  // conv: row within the stage, packed tap offsets (tky+1) | (tkx+1) << 2
+    unsigned x_bits[2][2];     // conv, WF: 1 << ky | (row 0 and kx == 0) << 3 | (row 63 and kx == 2) << 4
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = (w * 2 + i) * 4 + (lane >> 4);
@@ -72,6 +76,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
             unsigned v = OOB;
             x_r[h][i] = r;
             x_t[h][i] = 0;
+            x_bits[h][i] = 0;
             if (kcol < p.K) {
                 if (CONV == 0) {
                     v = (unsigned)(((int64_t)r * p.ldx + (kcol - k0)) * SZ);
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
                     const int tap = kcol / p.Cin, ci = kcol - tap * p.Cin;
                     const int ky = tap / 3, kx = tap - ky * 3;  // offsets ky-1, kx-1 relative to the output pixel
                     x_t[h][i] = ky | (kx << 2);
+                    x_bits[h][i] = (1u << ky) | ((r == 0 && kx == 0) ? 8u : 0u) | ((r == 63 && kx == 2) ? 16u : 0u);
                     v = (unsigned)(((int64_t)(r + ky * p.W + kx) * p.Cin + ci) * SZ);
                 }
             }
@@ -97,41 +103,56 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         soy = rem / p.Wo;
         sox = rem - soy * p.Wo;
     }
-    // descriptor bases / extents of the cursor stage.  They are kept as scalars and the descriptors are rebuilt at
-    // each issue from values forced into SGPRs: carried across the loop as 128-bit descriptors the compiler parks
-    // them in VGPRs and wraps every LDS-DMA in a readfirstlane waterfall loop.
-    const char* yb_s = nullptr;
-    const char* xb_s = nullptr;
-    unsigned ynrec_s = 0, xnrec_s = 0;
-    auto uni_ptr = [](const char* q_) -> const char* {
-        const uint64_t u = (uint64_t)q_;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        return (const char*)(((uint64_t)hi << 32) | lo);
-    };
+    // Descriptors are per SPLIT and never change (so they live in SGPRs); the stage is selected by the scalar offset of the
+    // DMA instruction.  (Per-stage descriptor bases cost ~60 scalar instructions per stage to rebuild -- carried across the
+    // loop as 128-bit values the compiler parks them in VGPRs and wraps every LDS-DMA in a readfirstlane waterfall loop.)
+    // The host plan keeps rows_per_split * row bytes below 2^31.  Row tails: dY / plain X rows >= m_end lie beyond
+    // num_records; conv X masks them with the halo lanes in the last stage.
+    const int rows_split = m_end - m_begin;
+    auto nrec = [](int64_t v) -> unsigned { return v > 0x7FFFFFFFll ? 0x7FFFFFFFu : (v < 0 ? 0u : (unsigned)v); };
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const char*)p.dY + ((int64_t)m_begin * p.lddy + n0) * SZ), 0, nrec(((int64_t)rows_split * p.lddy - n0) * SZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = (CONV == 0)
+        ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + ((int64_t)m_begin * p.ldx + k0) * SZ), 0,
+                                            nrec(((int64_t)rows_split * p.ldx - k0) * SZ), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + ((int64_t)m_begin - (p.W + 1)) * p.Cin * SZ), 0,
+                                            rows_split > 0 ? 0x7FFFFFFFu : 0u, 0x00020000);   // stride-1 'same' conv: pixel index == row index
+    const unsigned y_step = (unsigned)(64 * p.lddy * SZ), x_step = (unsigned)(64 * (CONV == 0 ? p.ldx : p.Cin) * SZ);
+    unsigned soffY = 0, soffX = 0;
     auto stage_prep = [&]() {
-        const int mbase = m_begin + st_tile * 64;
-        int rows_left = m_end - mbase;
-        rows_left = rows_left < 0 ? 0 : (rows_left > 64 ? 64 : rows_left);
-        const char* yb = (const char*)p.dY + ((int64_t)mbase * p.lddy + n0) * SZ;
-        yb_s = yb; ynrec_s = (unsigned)(rows_left * p.lddy * SZ);
-        if (CONV == 0) {
-            const char* xb = (const char*)p.X + ((int64_t)mbase * p.ldx + k0) * SZ;
-            xb_s = xb; xnrec_s = (unsigned)(rows_left * p.ldx * SZ);
-        } else {
-            const char* xb = (const char*)p.X + ((((int64_t)sb * p.H + soy) * p.W + sox) - (p.W + 1)) * p.Cin * SZ;
-            xb_s = xb; xnrec_s = rows_left > 0 ? 0x7FFFFFFFu : 0u;
+        soffY = (unsigned)st_tile * y_step;
+        soffX = (unsigned)st_tile * x_step;
+        if (CONV != 0) {
+            const int rows_left = rows_split - st_tile * 64;   // may be <= 0 for the cursor's run-ahead stages
+            if (WF) {
+                // vertical: rows above / below the image (scalar); horizontal: only pixel 0 of the first stage and pixel
+                // Wo-1 of the last stage of an image row can fall outside
+                const unsigned sw = (soy == 0 ? 1u : 0u) | (soy == p.Ho - 1 ? 4u : 0u) | (sox == 0 ? 8u : 0u) | (sox == p.Wo - 64 ? 16u : 0u);
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int ky = x_t[h][i] & 3, kx = x_t[h][i] >> 2;
-                    // pixel of this lane's row: the 64-row stage may run over the end of an image row (Wo >= 64: once)
-                    int ox = sox + x_r[h][i], oy = soy;
-                    if (ox >= p.Wo) { ox -= p.Wo; ++oy; }
-                    if (oy >= p.Ho) oy = 0;   // first row of the next image (addresses are linear in the pixel index)
-                    const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.H && (unsigned)(ox + kx - 1) < (unsigned)p.W && x_r[h][i] < rows_left;
-                    x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
+                    for (int i = 0; i < 2; ++i) x_eff[h][i] = (x_bits[h][i] & sw) ? OOB : vo[1 + h][i];
+                if (rows_left < 64) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (x_r[h][i] >= rows_left) x_eff[h][i] = OOB;
                 }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int ky = x_t[h][i] & 3, kx = x_t[h][i] >> 2;
+                        // pixel of this lane's row: the 64-row stage may run over the end of an image row (Wo >= 64: once)
+                        int ox = sox + x_r[h][i], oy = soy;
+                        if (ox >= p.Wo) { ox -= p.Wo; ++oy; }
+                        if (oy >= p.Ho) oy = 0;   // first row of the next image (addresses are linear in the pixel index)
+                        const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.H && (unsigned)(ox + kx - 1) < (unsigned)p.W && x_r[h][i] < rows_left;
+                        x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
+                    }
+            }
             sox += 64;
             if (sox >= p.Wo) { sox -= p.Wo; if (++soy >= p.Ho) { soy = 0; ++sb; } }
         }
@@ -140,12 +161,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
         char* dst = smem + (st_tile & 1) * TBUF + G * TSUB + (w * 2 + I) * 1024;
         if (G == 0 || G == 3) {
-            const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)uni_ptr(yb_s), 0, __builtin_amdgcn_readfirstlane(ynrec_s), 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], soffY, 0, 0);
         } else {
             const unsigned v = (CONV == 0) ? vo[G][I] : x_eff[G - 1][I];
-            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)uni_ptr(xb_s), 0, __builtin_amdgcn_readfirstlane(xnrec_s), 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(dst), 16, v, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(dst), 16, v, soffX, 0, 0);
         }
         if (G == 3 && I == 1) ++st_tile;
     };
@@ -295,10 +314,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    int bias_next = tk;   // stages tk, tk + tiles_k, ... carry this workgroup's share of the dbias sums
 #pragma unroll 1
     for (int t = 0; t < nst; ++t) {
         par_off = lds0 + (unsigned)((t & 1) * TBUF);
-        bias_turn = (t % tiles_k) == tk;
+        bias_turn = (t == bias_next);
+        if (bias_turn) bias_next += tiles_k;
         stage_body();
     }
 #undef BIAS_ACC
@@ -367,6 +388,13 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
     if (want > max_by_rows) want = max_by_rows;
     int64_t rps = ((int64_t)d->M + want - 1) / want;
     rps = (rps + 63) / 64 * 64;
+    {   // the kernel addresses a split with 32-bit offsets from its first row
+        const int64_t rowb = 2 * (int64_t)(d->conv ? (d->Cin > d->lddy ? d->Cin : d->lddy) : (d->ldx > d->lddy ? d->ldx : d->lddy));
+        const int64_t halo = d->conv ? (2 * (int64_t)d->W + 4) * d->Cin * 2 : 0;
+        int64_t cap = ((1ll << 31) - halo - 65536) / rowb / 64 * 64;
+        if (cap < 64) cap = 64;
+        if (rps > cap) rps = cap;
+    }
     *rows_per_split = (int)rps;
     *splits = (int)(((int64_t)d->M + rps - 1) / rps);
 }
@@ -378,18 +406,20 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
     if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 3; }
     static int ph2 = -1;
     if (ph2 < 0) { const char* e = getenv("UMR_TN256_PH2"); ph2 = e ? atoi(e) : 1; }  // two-phase stage: +1-2 % (tools/kbench.py)
-#define LT(CV)                                                                                                         \
+#define LT(CV, WFV)                                                                                                    \
     do {                                                                                                               \
         static bool set_ = false;                                                                                      \
         if (!set_) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);                  \
-            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);                   \
+            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, false, WFV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);             \
+            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, true, WFV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);              \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode); \
-        else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);   \
+        if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode); \
+        else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);   \
     } while (0)
-    if (d->conv == 0) LT(0); else LT(1);
+    if (d->conv == 0) LT(0, false);
+    else if (d->Wo % 64 == 0) LT(1, true);
+    else LT(1, false);
 #undef LT
     UMR_LAUNCH_CHECK();
     return UMR_OK;

@@ -14,15 +14,16 @@ assert os.environ.get("UMR_LIB"), "run with UMR_LIB=<instrumented library>"
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
 M = 64 * 384 * 384 // 4
-for K, N, aux in ((768, 512, 0), (512, 1024, 0), (768, 512, 2), (768, 768, 1)):
+for K, N, aux in ((768, 512, 0), (512, 1024, 0), (512, 1024, 3), (768, 512, 2), (768, 768, 1)):   # aux 3 = fused row reduction
     A = torch.randn(M // 64, K, generator=g).to(dev).bfloat16().repeat(64, 1)
     w = (torch.randn(N, K, generator=g) * 0.03).to(dev).bfloat16()
     bias = torch.zeros(N, device=dev)
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    ax = torch.randn(M // 64, N, generator=g).to(dev).bfloat16().repeat(64, 1) if aux else None
+    ax = torch.randn(M // 64, N, generator=g).to(dev).bfloat16().repeat(64, 1) if aux in (1, 2) else None
+    rw = torch.ones(2, N, device=dev) if aux == 3 else None
     stamps = torch.zeros(16 * 8, dtype=torch.int64, device=dev)
     for _ in range(3):
-        ops.gemm_nt(A, w, bias, act=(L.ACT_RELU if aux == 0 else L.ACT_NONE), out=out, aux=ax, mask_relu=(aux == 2), _stamps=stamps)
+        ops.gemm_nt(A, w, bias, act=(L.ACT_RELU if aux in (0, 3) else L.ACT_NONE), out=out, aux=ax, mask_relu=(aux == 2), red_w=rw, _stamps=stamps)
     torch.cuda.synchronize()
     t = stamps.cpu().view(16, 8)
     print(f"K={K} N={N} aux mode {aux}: shader-clock cycles per tile segment (tiles 2..7 of workgroup 0)")

@@ -10,8 +10,8 @@
 // staging cursor (two K-tiles ahead of the MFMAs) rolls over from the last K-tile of output tile i into the
 // first K-tiles of output tile i+1, so those loads are in flight during -- and have landed by the end of -- the
 // epilogue of tile i.  The epilogue therefore cannot borrow the staging buffers: it goes through a separate
-// 32-KiB LDS region (8 passes of 32 rows x 256 columns, XOR-swizzled 16-B chunks), and its global stores drain
-// behind the next tile's first phases.
+// 32-KiB LDS region (fast / GELU classes: 4 passes of 64 rows x 256 bf16 columns; generic class: 8 passes of 32 rows of
+// f32; XOR-swizzled 16-B chunks), and its global stores drain behind the next tile's first phases.
 //
 // Addressing is arranged so that a tile switch costs scalar work only: per-lane voffsets are tile-independent
 // (rows relative to the tile origin) and row/column validity comes from the buffer descriptor's num_records
@@ -329,10 +329,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     };
     if (BIAS_INIT) fetch_bias(0);
     // -DUMR_NT256P_TIMESTAMPS (tools/probe/ts_probe.py builds its own library with it): workgroup 0 / thread 0 writes
-    // s_memtime stamps of the first 16 tiles to red_out when red_c == 9 -- how the per-tile budget was taken apart
+    // s_memtime stamps of the first 16 tiles to the rowbias pointer when rows_per_batch == -9 -- how the per-tile budget was taken apart
 #ifdef UMR_NT256P_TIMESTAMPS
-    const bool dbg = (p.red_c == 9) && blockIdx.x == 0 && tid == 0;
-    unsigned long long* dbgp = (unsigned long long*)p.red_out;
+    const bool dbg = (p.rows_per_batch == -9) && blockIdx.x == 0 && tid == 0;
+    unsigned long long* dbgp = (unsigned long long*)p.rowbias;
 #define TS(slot) do { if (dbg && it < 16) dbgp[it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TS(slot) do { } while (0)

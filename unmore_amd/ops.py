@@ -118,7 +118,7 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
         d.red_w, d.red_out, d.red_c = _p(red_w), _p(partials), red_w.shape[0]
     d.no_store = 1 if no_store else 0
     if _stamps is not None:   # instrumented library only (tools/probe/ts_probe.py): int64 [16, 8] cycle stamps
-        d.red_out, d.red_c = _p(_stamps), 9
+        d.rowbias, d.rows_per_batch = _p(_stamps), -9
     L.check(_timed_call(d), "umr_gemm_nt")
     if red_w is not None:
         return out, partials

@@ -35,7 +35,10 @@ const char* umr_last_error_string(void);
  * epilogue order: v = acc (+bias[n]) (+rowbias[m/rows_per_batch][n]);
  *   MASK_RELU: v *= (aux>0) | MASK_DGELU: v *= gelu'(aux) | ADD_AUX: v += aux;
  *   ADD_AUX2: v += aux2;  c2_mode==2: C2 = v;  v = act(v);  C = v;
- *   c2_mode==1: C2 = relu(v). */
+ *   c2_mode==1: C2 = relu(v).
+ * Rounding: fp32 (parity mode) applies every step in f32 and rounds once.  On the bf16 large-tile path the aux steps
+ * (ADD_AUX, MASK_RELU, MASK_DGELU) act on the value already rounded to bf16 -- bf16(bf16(acc + bias) op aux), what separate
+ * bf16 layers compute; for MASK_RELU that is bit-identical to rounding last. */
 enum umr_epi_flags {
     UMR_EPI_BIAS = 1, UMR_EPI_ADD_AUX = 2, UMR_EPI_MASK_RELU = 4, UMR_EPI_MASK_DGELU = 8,
     UMR_EPI_ADD_AUX2 = 16, UMR_EPI_OUT_F32 = 32, UMR_EPI_ROWBIAS = 64

@@ -97,6 +97,7 @@ def _rep_bias(b, reps):
 
 
 _FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch for benchmarking
+_MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: one GEMM for the feature-map gradient of both heads
 
 
 class Engine:
@@ -397,6 +398,11 @@ class Engine:
         # ---- heads
         dfeat = None
         feat = S["feat"]
+        # Both heads factored: their layer-1 input gradients dh1 go side by side into one [M, 2*C1] buffer and the gradient of
+        # the shared feature map is ONE GEMM over K = 2*C1 (instead of a GEMM plus a second one that re-reads and re-writes
+        # the [M, 256] result to accumulate into it).
+        merge_dfeat = _MERGE_DFEAT and all(not hs_.get("collapsed") for hs_ in S["heads"])
+        dh1cat, w1cat = None, []
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
@@ -415,16 +421,25 @@ class Engine:
             h1 = hs["h1"].view(B, H, W, 512)
             wgrad_c3(f"{name}.{idx[1]}.weight", dh2, h1, f"{name}.{idx[1]}.bias")
             hs["h2"] = None
+            c1 = hs["h1"].shape[-1]
+            if merge_dfeat and dh1cat is None:
+                dh1cat = torch.empty((B * H * W, 2 * c1), dtype=dt, device=dev)
             dh1 = ops.gemm_nt(dh2.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
-                              aux=(hs["h1"] if relu else None), mask_relu=relu)
+                              aux=(hs["h1"] if relu else None), mask_relu=relu,
+                              out=(dh1cat[:, hi * c1:(hi + 1) * c1] if merge_dfeat else None))
             del dh2
             hs["h1"] = None
             wgrad_lin(f"{name}.{idx[0]}.weight", dh1, feat.view(-1, 256), f"{name}.{idx[0]}.bias")
-            if dfeat is None:
+            if merge_dfeat:
+                w1cat.append(self._w(P, f"{name}.{idx[0]}.weight", "lin_t"))
+            elif dfeat is None:
                 dfeat = ops.gemm_nt(dh1, self._w(P, f"{name}.{idx[0]}.weight", "lin_t"), None)
             else:
                 ops.gemm_nt(dh1, self._w(P, f"{name}.{idx[0]}.weight", "lin_t"), None, aux=dfeat, out=dfeat)
             del dh1
+        if merge_dfeat:
+            dfeat = ops.gemm_nt(dh1cat, torch.cat(w1cat, dim=1), None)
+            del dh1cat
         S["feat"] = None
         cb("heads")
         ph, pw = S["path1_hw"]

@@ -220,6 +220,7 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"},
             "train_tflops_per_gpu": 3 * fwd_gflop * B * a.steps / elapsed / 1e3,
             "final_loss": loss_val,
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256p_kernel<conv3x3> bf16 512->512 (heads, fwd+dgrad)" if a.dtype == "bf16" else "gemm_nt_kernel<f32,conv3x3>",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,

@@ -345,6 +345,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = BIAS_INIT ? bqn[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         TS(1);
+        if (RED && w < 2) {
+            // reduction weights of this tile's 256 columns: row c = w of red_w as one 1-KiB LDS-DMA (columns >= N and a
+            // missing second row read as zeros)
+            const int v_ = it * G + pw;
+            const int n0_ = (v_ - (v_ / tiles_n) * tiles_n) * BN2;
+            const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(p.red_w + (int64_t)w * p.N + n0_), 0, (w < p.red_c) ? clamp31((int64_t)(p.N - n0_) * 4) : 0, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, UMR_LDS_PTR(smem + STG_OFF + w * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+        }
 #pragma unroll 1
         for (int t = 0; t < nt; ++t) {
             tile_body(smem + c_par * BUF2);
@@ -368,16 +377,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
             // fused row reduction (umr_gemm_desc.red_*): this lane's 16 columns of the reduction weights; the partial dot
             // products of a row are summed over the 4 lanes that share it (fq) and written per 64-column wave slice
+            // They were brought into the (idle) staging region by LDS-DMA at the start of the tile -- a global load here would
+            // be waited for on the spot, behind the next tile's prefetched K-tiles -- and are read out before pass 0 reuses it.
             f32x4 rw[2][4];
             if (RED) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) {
-                        const int n = n0 + wc * 64 + ntl * 16 + fq * 4;
-                        rw[c][ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (c < p.red_c && n < p.N) rw[c][ntl] = *(const f32x4*)(p.red_w + (int64_t)c * p.N + n);
-                    }
+                    for (int ntl = 0; ntl < 4; ++ntl)
+                        rw[c][ntl] = *(const f32x4*)(smem + STG_OFF + c * 1024 + (wc * 64 + ntl * 16 + fq * 4) * 4);
+                __syncthreads();
             }
             // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
             // 512-byte row segments (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per

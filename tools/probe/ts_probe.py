@@ -21,12 +21,16 @@ for K, N, aux in ((768, 512, 0), (512, 1024, 0), (512, 1024, 3), (768, 512, 2), 
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
     ax = torch.randn(M // 64, N, generator=g).to(dev).bfloat16().repeat(64, 1) if aux in (1, 2) else None
     rw = torch.ones(2, N, device=dev) if aux == 3 else None
-    stamps = torch.zeros(16 * 8, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(16 * 8 + 8, dtype=torch.int64, device=dev)
     for _ in range(3):
         ops.gemm_nt(A, w, bias, act=(L.ACT_RELU if aux in (0, 3) else L.ACT_NONE), out=out, aux=ax, mask_relu=(aux == 2), red_w=rw, _stamps=stamps)
     torch.cuda.synchronize()
-    t = stamps.cpu().view(16, 8)
+    ph = stamps.cpu()[128:136]
+    t = stamps.cpu()[:128].view(16, 8)
     print(f"K={K} N={N} aux mode {aux}: shader-clock cycles per tile segment (tiles 2..7 of workgroup 0)")
+    if aux in (0, 3) and int(ph[7]) > 0:   # 4-phase K-tile (plain GEMM): after-sync -> after-MFMA-block per phase, and the gaps between
+        d = [int(ph[i + 1] - ph[i]) for i in range(7)]
+        print(f"  one K-tile (tile 4, k-tile 5): MFMA blocks {d[0]} {d[2]} {d[4]} {d[6]}   read+wait+barrier gaps {d[1]} {d[3]} {d[5]}")
     for it in range(2, 8):
         r, nxt = t[it], t[it + 1][0]
         print(f"  tile {it}: k-tile0 {int(r[2] - r[1]):5d}  k-tile1 {int(r[3] - r[2]):5d}  other k-tiles {int(r[4] - r[3]):6d}  "

@@ -238,6 +238,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     //   P1(t) issues A0,B0,B1 of tile t+2 (their regions were last read in P0(t)),  P0(t+1) issues A1 of tile t+2;
     //   wait of P1(t): A0,B0,B1(t+1) landed, A1(t+1) may fly -> vmcnt(2);  wait of P0(t): A1(t) landed, A0,B0,B1(t+1) may
     //   fly -> vmcnt(6).  Every group has one K-tile (two phases) to land.
+#ifdef UMR_NT256P_TIMESTAMPS
+    const bool dbg = (p.rows_per_batch == -9) && blockIdx.x == 0 && tid == 0;
+    unsigned long long* dbgp = (unsigned long long*)p.rowbias;
+    bool ph_rec = false;   // stamps inside one K-tile (4-phase form): slots 128..135
+#define PT(k) do { if (dbg && ph_rec) dbgp[128 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
     auto tile_body2 = [&](const char* sbuf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -270,22 +278,30 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
         }
         PHASE_SYNC();
+        PT(0);
         QUADRANT(0, 0, fb0, 2)
+        PT(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
         PHASE_SYNC();
+        PT(2);
         QUADRANT(0, 2, fb1, 3)
+        PT(3);
         stage_prep();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
         PHASE_SYNC();
+        PT(4);
         QUADRANT(4, 2, fb1, 0)
+        PT(5);
         PHASE_SYNC();
+        PT(6);
         QUADRANT(4, 0, fb0, 1)
+        PT(7);
     };
 
     // prologue: the six groups the steady-state schedule has already issued when the first K-tile starts
@@ -331,8 +347,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // -DUMR_NT256P_TIMESTAMPS (tools/probe/ts_probe.py builds its own library with it): workgroup 0 / thread 0 writes
     // s_memtime stamps of the first 16 tiles to the rowbias pointer when rows_per_batch == -9 -- how the per-tile budget was taken apart
 #ifdef UMR_NT256P_TIMESTAMPS
-    const bool dbg = (p.rows_per_batch == -9) && blockIdx.x == 0 && tid == 0;
-    unsigned long long* dbgp = (unsigned long long*)p.rowbias;
 #define TS(slot) do { if (dbg && it < 16) dbgp[it * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define TS(slot) do { } while (0)
@@ -356,6 +370,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         }
 #pragma unroll 1
         for (int t = 0; t < nt; ++t) {
+#ifdef UMR_NT256P_TIMESTAMPS
+            ph_rec = (it == 4 && t == 5);
+#endif
             tile_body(smem + c_par * BUF2);
             c_par ^= 1;
 #ifdef UMR_NT256P_TIMESTAMPS
@@ -588,6 +605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef QUADRANT
 #undef TS
+#undef PT
 #undef QUADRANT_D
 #undef MFMA
 #undef PHASE_SYNC

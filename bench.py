@@ -48,12 +48,12 @@ def forward_gflop_per_image(cfg, H, W):
     return fl / 1e9
 
 
-def cpu_baseline(workload, seconds_budget=30.0):
+def cpu_baseline(workload, seconds_budget=20.0):
     """Reference-style CPU path (the oracle: fp32 PyTorch ops, autograd, Adam) on the host cores.
     Bounded sample: ONE image at half the workload's resolution per side (a quarter of the pixels; the two
     full-resolution heads are ~90 % of the FLOPs and scale with the pixel count), i.e. ~1/4 of one
-    image-step of the workload; images/sec = (1 / step time) / 4.  A full 384x384 step takes minutes on the
-    host, which would blow the bench's time budget."""
+    image-step of the workload; images/sec = (1 / step time) / 4; up to 8 timed steps within ~20 s keep the default
+    bench run inside a few minutes."""
     import torch
     from oracle import objectness_oracle as orc
     from unmore_amd import synth
@@ -91,7 +91,7 @@ def cpu_baseline(workload, seconds_budget=30.0):
     one(1)  # warm-up (also sizes the budget)
     first = time.perf_counter() - t0
     print(f"[bench] cpu_baseline: warm-up step {first:.1f} s", file=sys.stderr, flush=True)
-    n = max(1, min(3, int(seconds_budget / max(first, 1e-3))))
+    n = max(1, min(8, int(seconds_budget / max(first, 1e-3))))   # ~10-20 s of CPU work
     t0 = time.perf_counter()
     for i in range(n):
         one(2 + i)

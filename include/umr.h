@@ -227,6 +227,23 @@ int64_t umr_label_synthesis_workspace(int B, int H, int W);
 int umr_label_synthesis(const uint8_t* mask, const float* center_xy, float* center_field, float* saliency, float* sdf,
                         void* workspace, int64_t workspace_bytes, int B, int H, int W, int use_bg_sdf, umr_stream_t stream);
 
+/* ---- the random-crop branch of the training item (datasets.py:144-145,161-190: the default training path, :109) ----
+ * crop_resize_batch: src [B,C,H,W] with one box [x1,y1,x2,y2) per item -> dst [B,C,Ho,Wo]; f32 bilinear (torchvision tensor
+ *   Resize without antialias == F.interpolate(align_corners=False), :99,103) or, with nearest_u8, u8 nearest
+ *   (F.interpolate(mode="nearest"), :100,104).  Serves transforms.Resize (box = whole image) and crop + Resize.
+ * distance_transform: cv2.distanceTransform(u8, DIST_L2, 3) of each mask, divided by its maximum when normalize (:162-163).
+ * label_synthesis_cropped: as label_synthesis, but the foreground field was computed before the crop and arrives resized
+ *   (fg_sdf [B,H,W]), the object centres are given, only the background transform is taken from `mask`, and an empty
+ *   mask is not short-circuited (the reference tests emptiness before the crop, :146-157). */
+int umr_crop_resize_batch(const void* src, const int32_t* boxes, void* dst, int B, int C, int H, int W, int Ho, int Wo,
+                          int nearest_u8, umr_stream_t stream);
+int64_t umr_distance_transform_workspace(int B, int H, int W);
+int umr_distance_transform(const uint8_t* mask, float* out, void* workspace, int64_t workspace_bytes, int B, int H, int W,
+                           int normalize, umr_stream_t stream);
+int umr_label_synthesis_cropped(const uint8_t* mask, const float* center_xy, const float* fg_sdf, float* center_field,
+                                float* saliency, float* sdf, void* workspace, int64_t workspace_bytes, int B, int H, int W,
+                                int use_bg_sdf, umr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,58 @@ def labels_from_mask(mask, object_center=None, use_bg_sdf=True, dt=distance_tran
     center_field = torch.zeros_like(grid) + torch.where(mask > 0, 1, 0) * ocf
     center_field = F.normalize(center_field, dim=0)
     return {"center_field": center_field, "saliency_mask": torch.where(mask > 0, 1, 0).float(), "sdf": sdf}
+
+
+# ---- the random-crop branch (datasets.py:144-190; __getitem__ uses it, :109) -------------------------------------------
+def resize(x, size, nearest=False):
+    """transforms.Resize(size, BILINEAR / NEAREST) on a tensor [C,H,W]: torchvision 0.14.1 resizes tensors with
+    F.interpolate (no antialias by default; align_corners=False for bilinear)."""
+    x4 = x.unsqueeze(0).float()
+    if nearest:
+        return F.interpolate(x4, size=size, mode="nearest")[0]
+    return F.interpolate(x4, size=size, mode="bilinear", align_corners=False)[0]
+
+
+def training_item_random_crop(image, mask, params, image_size, use_bg_sdf=True, dt=distance_transform_3x3):
+    """datasets.py:144-216 for one decoded item with random_crop=True and GIVEN crop box params = (top, left, h, w) in the
+    400x400 frame (the draw itself, torchvision's RandomResizedCrop.get_params, is outside this restatement).
+    image [3,h,w] float in [0,1], mask [h,w] 0/1.  Returns (image [3,S,S], labels dict)."""
+    S = image_size
+    image = resize(image, (400, 400))                                                     # :144
+    mask = resize(mask.unsqueeze(0), (400, 400), nearest=True)[0]                         # :145
+    y, x = torch.where(mask > 0)
+    if len(y) == 0 or len(x) == 0:                                                         # :146-157
+        return resize(image, (S, S)), {"center_field": torch.zeros(2, S, S), "saliency_mask": torch.zeros(S, S),
+                                       "instance_mask": torch.zeros(S, S), "object_center": torch.tensor([0.0, 0.0]),
+                                       "sdf": torch.zeros(S, S)}
+    obj_x_center = (torch.min(x) + torch.max(x)) / 2                                       # :158-159
+    obj_y_center = (torch.min(y) + torch.max(y)) / 2
+    sdf = dt(np.uint8(mask.numpy()))                                                       # :162-164
+    sdf = sdf / sdf.max() if sdf.max() > 0 else sdf
+    sdf = torch.tensor(sdf)
+    all_data = torch.cat((image, sdf.unsqueeze(0), mask.unsqueeze(0)))                     # :165
+    top, left, height, width = params
+    all_data = all_data[:, top:top + height, left:left + width]                            # :169 (transforms.functional.crop)
+    image = all_data[0:3]
+    sdf = all_data[3:4]
+    mask = all_data[-1]
+    image = resize(image, (S, S))                                                          # :174
+    mask = resize(mask.unsqueeze(0), (S, S), nearest=True)[0]                              # :175
+    sdf = resize(sdf, (S, S))[0]                                                           # :176
+    crop_center_y = (obj_y_center - top) * (S / height)                                    # :180-182
+    crop_center_x = (obj_x_center - left) * (S / width)
+    object_center = torch.tensor([crop_center_x, crop_center_y])
+    if use_bg_sdf:                                                                         # :191-197
+        bg_mask = torch.where(mask == 0, 1, 0)
+        bg_sdf = dt(np.uint8(bg_mask.numpy()))
+        bg_sdf = bg_sdf / bg_sdf.max() if bg_sdf.max() > 0 else bg_sdf
+        sdf = sdf + torch.tensor(bg_sdf) * (-1)
+    H, W = mask.shape
+    xv, yv = torch.meshgrid([torch.arange(H), torch.arange(W)], indexing="ij")             # :200-207
+    grid = torch.stack((xv, yv), 2).float().permute(2, 0, 1)
+    ocf = grid - torch.tensor([object_center[1], object_center[0]]).unsqueeze(1).unsqueeze(1)
+    ocf = F.normalize(ocf, dim=0)
+    center_field = torch.zeros_like(grid) + torch.where(mask > 0, 1, 0) * ocf
+    center_field = F.normalize(center_field, dim=0)
+    return image, {"center_field": center_field, "saliency_mask": torch.where(mask > 0, 1, 0).float(), "instance_mask": mask.float(),
+                   "object_center": object_center, "sdf": sdf}

@@ -57,6 +57,10 @@ _SIGS = {
     "umr_gemm_nt_rowreduce_ok": [_vp],
     "umr_label_synthesis_workspace": [_i32, _i32, _i32],
     "umr_label_synthesis": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "umr_label_synthesis_cropped": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
+    "umr_crop_resize_batch": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_distance_transform_workspace": [_i32, _i32, _i32],
+    "umr_distance_transform": [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
     "umr_im2col_nchw": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_maxpool3x3s2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_bn_fold": [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -117,7 +121,8 @@ def lib():
         _lib.umr_last_error_string.restype = ctypes.c_char_p
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
-                   "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace"):
+                   "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
+                   "umr_distance_transform_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

@@ -9,7 +9,9 @@ image, the dataset class cannot be imported without it, and the reference holds 
 restates OpenCV's published algorithm for that call (imgproc/src/distransform.cpp `distanceTransform_3x3`: two-pass 3x3
 chamfer in 16.16 fixed point with the documented DIST_L2 3x3 weights a = 0.955, b = 1.3693, a one-pixel border of
 INT_MAX >> 2, output clamped to INT_MAX >> 2 and scaled by 2^-16).  The centre-field lines are the reference's own PyTorch
-expressions restated one to one.
+expressions restated one to one.  `training_item_random_crop` restates the random-crop branch (datasets.py:144-190) for a
+GIVEN crop box: the resizes are torchvision 0.14.1's tensor path (F.interpolate, no antialias), the box draw
+(RandomResizedCrop.get_params) lies outside the restatement -- torchvision is absent too, that boundary is unpinned as well.
 """
 import numpy as np
 import torch

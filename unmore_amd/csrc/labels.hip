@@ -5,6 +5,8 @@
 //   center_field = normalize(mask * normalize((i, j) - (c_y, c_x)))                                       (:193-207)
 //   saliency     = mask > 0                                                                               (:212)
 // An empty mask yields all-zero labels (the reference's early return, :128-138).
+// The random-crop branch (:144-190, the one __getitem__ takes) adds: batched crop + resize (bilinear f32 / nearest u8),
+// the distance transform on its own, and label synthesis around a foreground field computed before the crop.
 //
 // cv2.distanceTransform with DIST_L2 and a 3x3 mask is OpenCV's two-pass chamfer transform in 16.16 fixed point
 // (imgproc/src/distransform.cpp, distanceTransform_3x3; a = 0.955, b = 1.3693 as documented for DIST_L2 3x3):

@@ -116,3 +116,34 @@ def test_existence_checking_matches_oracle():
     sd = CO.hash_state("clf", uniform)
     want = CO.existence_scores(sd, image, boxes, O.crop_resize)
     torch.testing.assert_close(got, want, atol=1e-4, rtol=0)
+
+
+def test_get_prediction_with_proposals_is_the_composition_of_its_parts():
+    """object_scoring.py:111-153: crops -> objectness net + existence classifier in batches of 50; the helper must return
+    exactly what the three pieces give when chained by hand."""
+    from argparse import Namespace
+    from unmore_amd import reasoning
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.objectness_net import ObjectnessNet
+    dev = _dev()
+    obj = ObjectnessNet("cuda:0", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    obj.load_state_dict({k: torch.from_numpy(hash_init(k, tuple(v.shape), "tiny")) for k, v in obj.state_dict().items()})
+    obj = obj.to("cuda:0").eval()
+    clf = _net(torch.float32)
+    image = torch.from_numpy(uniform01("img:clf_scene", (3, 120, 160))).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n = 57    # > one batch of 50
+    x1 = torch.rand(n, generator=g) * 100
+    y1 = torch.rand(n, generator=g) * 70
+    boxes = torch.stack([x1, y1, x1 + 20 + torch.rand(n, generator=g) * 39.5, y1 + 20 + torch.rand(n, generator=g) * 29.5], 1)
+    boxes[0] = torch.tensor([0.0, 0.0, 160.0, 120.0])
+    got = reasoning.get_prediction_with_proposals(obj, clf, image, boxes.tolist())
+    assert got["pred_boundary_fields"].shape == (n, 128, 128) and got["pred_center_fields"].shape == (n, 2, 128, 128)
+    assert got["pred_existence_scores"].shape == (n,) and bool(got["on_edge_flags"][0].all())
+    crops, _ = reasoning.crop_resize(image, boxes, 128)
+    with torch.no_grad():
+        for lo in (0, 50):
+            pred = obj.get_prediction(crops[lo:lo + 50])
+            assert torch.equal(got["pred_boundary_fields"][lo:lo + 50], pred["sdf_maps"].squeeze(1))
+            assert torch.equal(got["pred_center_fields"][lo:lo + 50], pred["center_fields"])
+            assert torch.equal(got["pred_existence_scores"][lo:lo + 50], clf(crops[lo:lo + 50]).squeeze(1))

@@ -85,3 +85,23 @@ def existence_checking(binary_classifier_model, image, proposals, num_img_per_ba
             scores.append(binary_classifier_model(crops.to(torch.float32)))
     class_scores = torch.cat(scores, dim=0).cpu()
     return {"existence_scores": class_scores.squeeze(1)}
+
+
+def get_prediction_with_proposals(objectness_model, binary_classifier_model, image, proposals, num_img_per_batch=50):
+    """object_scoring.py:111-153: for every proposal box the 128x128 crop (floor / ceil corners, bilinear, no antialias), the
+    objectness net's boundary-distance and centre fields and the existence score, in batches of 50.
+    image [3,H,W] f32 on the GPU; proposals [N,4] (x1,y1,x2,y2).  Returns the reference's dict -- 'pred_boundary_fields'
+    [N,128,128], 'pred_center_fields' [N,2,128,128], 'pred_existence_scores' [N] -- on the model's device, plus
+    'on_edge_flags' [N,4] (computed by the reference loop, :126-127, and dropped from its return value)."""
+    props = torch.as_tensor(proposals, dtype=torch.float64)
+    sdf, cen, cls, edge = [], [], [], []
+    for i in range(0, len(props), num_img_per_batch):
+        crops, on_edge = crop_resize(image, props[i:i + num_img_per_batch], 128)
+        with torch.no_grad():
+            pred = objectness_model(crops.to(torch.float32))
+            cls.append(binary_classifier_model(crops.to(torch.float32)))
+        sdf.append(pred["sdf_maps"].squeeze(1))
+        cen.append(pred["center_fields"])
+        edge.append(on_edge)
+    return {"pred_boundary_fields": torch.cat(sdf, dim=0), "pred_center_fields": torch.cat(cen, dim=0),
+            "pred_existence_scores": torch.cat(cls, dim=0).squeeze(1), "on_edge_flags": torch.cat(edge, dim=0)}

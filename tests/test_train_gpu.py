@@ -265,3 +265,41 @@ def test_large_shape_determinism_and_batch_independence():
         single = net.get_prediction(x[1:2])
     for k in ("center_fields", "sdf_maps"):
         torch.testing.assert_close(single[k], o1[k][1:2].detach(), atol=3e-2, rtol=0)   # other kernels / summation orders at B=1
+
+
+def test_checkpoint_resume_matches_uninterrupted_run_and_torch_adam_format():
+    """train_objectness_net.py:118-123,268-275: model + optimizer state + iteration saved after 2 steps and loaded into a fresh
+    model / TrainStep give bit-identical weights after step 3; the optimizer state has torch.optim.Adam's schema."""
+    from argparse import Namespace
+    from unmore_amd import synth
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd.trainer import TrainStep
+
+    def make():
+        net = ObjectnessNet("cuda:0", 64, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+        net.load_state_dict({k: torch.from_numpy(hash_init(k, tuple(v.shape), "tiny")) for k, v in net.state_dict().items()})
+        return net.to("cuda:0")
+
+    batches = [tuple(torch.from_numpy(a).cuda() for a in synth.make_batch(2, 64, 64, seed=s)) for s in (1, 2, 3)]
+    a = make()
+    sa = TrainStep(a, lr=1e-3, lr_milestones=(2,), lr_gamma=0.5)
+    for b in batches[:2]:
+        sa.step(*b)
+    ckpt = {"model_state_dict": {k: v.detach().cpu().clone() for k, v in a.state_dict().items()},
+            "optimizer_state_dict": sa.optimizer_state_dict(), "iter": sa.iter}
+    sa.step(*batches[2])
+    # torch's own optimizer accepts the state (schema check): same parameter order, same per-parameter keys
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in a.parameters()]
+    opt = torch.optim.Adam(ref_params, lr=1e-3)
+    opt.load_state_dict({"state": {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in ckpt["optimizer_state_dict"]["state"].items()},
+                         "param_groups": ckpt["optimizer_state_dict"]["param_groups"]})
+    assert len(opt.state_dict()["state"]) == len(ckpt["optimizer_state_dict"]["state"]) > 0
+    b_ = make()
+    b_.load_state_dict(ckpt["model_state_dict"], strict=True)
+    sb = TrainStep(b_, lr=1e-3, lr_milestones=(2,), lr_gamma=0.5)
+    sb.load_optimizer_state_dict(ckpt["optimizer_state_dict"], iteration=ckpt["iter"])
+    assert sb.iter == 2 and sb.current_lr_for_step() == sa.lr0  # (about to run step 3: lr of 2 completed steps)
+    sb.step(*batches[2])
+    for (n, p), (_, q) in zip(a.named_parameters(), b_.named_parameters()):
+        assert torch.equal(p, q), n

@@ -79,6 +79,7 @@ class TrainStep:
                 p.data = view
                 self.G[n] = self.flat_g[o:o + p.numel()].view(p.shape)
         self.P = {n: p for n, p in net.named_parameters()}
+        self._offs = offs
         self.comm = BucketedAllReduce(self.flat_g, bounds, group)
         net._engine().cache.clear()
 
@@ -101,6 +102,50 @@ class TrainStep:
                       self.eps, scale)
         eng.cache.clear()  # packed (kernel-layout) weight copies are stale after the in-place update
         return out5
+
+    # ---- checkpoint / resume (train_objectness_net.py:118-123,268-275: {'model_state_dict', 'optimizer_state_dict', 'iter'})
+    def optimizer_state_dict(self):
+        """The optimizer half of the reference's checkpoint in torch.optim.Adam's own format (parameter index = position in
+        model.parameters(); parameters that never receive a gradient have no state entry, as in torch), so a checkpoint
+        written here resumes in the reference loop and vice versa."""
+        names = [n for n, _ in self.net.named_parameters()]
+        state = {}
+        if self.iter > 0:
+            for i, n in enumerate(names):
+                if n in self._offs:
+                    o, p = self._offs[n], self.P[n]
+                    state[i] = {"step": torch.tensor(float(self.iter)),
+                                "exp_avg": self.m[o:o + p.numel()].view(p.shape).clone(),
+                                "exp_avg_sq": self.v[o:o + p.numel()].view(p.shape).clone()}
+        group = {"lr": self.current_lr(), "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "initial_lr": self.lr0, "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd, iteration=None):
+        """Restore Adam's moments (and the step count) from `optimizer_state_dict()` / a torch.optim.Adam state dict of the
+        same model.  iteration: the checkpoint's 'iter' (defaults to the stored Adam step); the learning-rate schedule here
+        is a function of that absolute iteration."""
+        names = [n for n, _ in self.net.named_parameters()]
+        assert len(sd["param_groups"]) == 1 and len(sd["param_groups"][0]["params"]) == len(names), "optimizer state of another model"
+        self.m.zero_()
+        self.v.zero_()
+        step = 0
+        for i, st in sd["state"].items():
+            n = names[int(i)]
+            if n not in self._offs:
+                continue
+            o, p = self._offs[n], self.P[n]
+            self.m[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
+            self.v[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
+            step = max(step, int(float(st["step"])))
+        self.iter = int(iteration) if iteration is not None else step
+        assert self.iter == step or not sd["state"], "Adam step count and checkpoint iteration disagree"
+
+    def sync_from_model(self):
+        """Call after model.load_state_dict(): the flat parameter buffer is the storage of the parameters, so loading writes
+        through; only the packed kernel-layout weight copies have to be dropped."""
+        self.net._engine().cache.clear()
 
     def current_lr_for_step(self):
         # torch's MultiStepLR.step() runs after optimizer.step(): step k (1-based) uses the lr of k-1 completed steps

@@ -135,3 +135,34 @@ def test_backward_bf16_gradients_are_close():
     b = torch.cat([sdo[n].grad.flatten() for n, p in net.named_parameters() if p.grad is not None])
     cos = torch.dot(a, b) / (a.norm() * b.norm())
     assert cos > 0.99, cos
+
+
+@pytest.mark.parametrize("bg,act", [(True, "sine"), (True, None), (True, "relu"), (False, "tanh")])
+def test_backward_fp32_other_sdf_activations(bg, act):
+    """objectness_net.py:119-164: the 'sine' (SinActivation, :30-35), activation-free, ReLU and use_bg_sdf=False variants of the boundary-distance head,
+    forward and every parameter gradient vs the oracle's float64 autograd.  (sin is not invertible from its value: the
+    backward pass is fed the pre-activation.)"""
+    from unmore_amd.loss import objectness_loss
+    B, H, W = 2, 64, 64
+    args = Namespace(use_bg_sdf=bg, sdf_activation=act)
+    net, sd = _net("dpt_tiny", "tiny", args=args)
+    net.train()
+    x = torch.from_numpy(uniform01("img:tiny64x64", (B, 3, H, W)))
+    gc, gs, sal = _labels(B, H, W, 0)
+    sdo = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    out_o = orc.forward(sdo, x.double(), orc.CONFIGS["dpt_tiny"], bg, act)
+    # the binary-mask term takes log(sigmoid(.)) of the map: fine for every variant; all four terms as documented
+    loss_o, _ = orc.loss_terms(out_o, gc.double(), gs.double(), sal.double())
+    loss_o.backward()
+    out = net(images=x.cuda())
+    torch.testing.assert_close(out["sdf_maps"].cpu().double(), out_o["sdf_maps"].detach(), atol=1e-4, rtol=0)
+    loss = objectness_loss(out, gc.cuda(), gs.cuda(), sal.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4
+    nograd = net.nograd_names()
+    for n, p in net.named_parameters():
+        if n in nograd:
+            continue
+        ref = sdo[n].grad
+        e = (p.grad.cpu().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+        assert e <= 5e-4, f"{n}: rel err {e}"

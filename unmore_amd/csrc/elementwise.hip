@@ -298,10 +298,13 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const T* __restrict__
     for (int64_t m = r0; m < r1; ++m) {
         const int64_t b = m / HW, hw = m - b * HW;
         float g0 = dout[(b * Cout) * HW + hw], g1 = 0.f;
+        // tanh: yout is the output y (1 - y^2); sine (act 4, objectness_net.py:30-35,126): yout is the PRE-activation z (cos z)
         if (act == UMR_ACT_TANH) { const float y = yout[(b * Cout) * HW + hw]; g0 *= (1.f - y * y); }
+        else if (act == 4) g0 *= cosf(yout[(b * Cout) * HW + hw]);
         if (Cout == 2) {
             g1 = dout[(b * Cout + 1) * HW + hw];
             if (act == UMR_ACT_TANH) { const float y = yout[(b * Cout + 1) * HW + hw]; g1 *= (1.f - y * y); }
+            else if (act == 4) g1 *= cosf(yout[(b * Cout + 1) * HW + hw]);
         }
         if (kok) {
             const f32x4 hv = Vec4<T>::load(h + m * K + k);
@@ -607,7 +610,6 @@ extern "C" int umr_head_out_bwd(const void* h, const float* w, const float* dout
     UMR_CHECK_ARG(h && w && dout && dh && dw && db && workspace, "head_out_bwd: null pointer");
     UMR_CHECK_ARG(M > 0 && K > 0 && K % 4 == 0 && K <= 1024 && (Cout == 1 || Cout == 2) && HW > 0 && M % HW == 0, "head_out_bwd: bad arguments");
     UMR_CHECK_ARG(act == UMR_ACT_NONE || yout, "head_out_bwd: activation needs the forward output");
-    if (act == 4) return umr_set_error(UMR_ERR_UNSUPPORTED, "head_out_bwd: sine activation backward is not implemented");
     UMR_CHECK_ARG(workspace_bytes >= umr_head_out_bwd_workspace(M, K), "head_out_bwd: workspace too small");
     int nb = head_out_blocks(M);
     const int rpb = (int)((M + nb - 1) / nb);

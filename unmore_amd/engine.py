@@ -364,13 +364,16 @@ class Engine:
                 # h3 saved); without saved activations (inference) h3 is not written at all
                 h3, parts = ops.gemm_nt(h2, w3, b3, act=act, red_w=w4.contiguous(), no_store=not save)
                 out = ops.head_out_finish(parts, b4, B, H, W, _ACT[lay["final"]])
+                # sin is not invertible from its value: the backward pass of the 'sine' variant gets the pre-activation
+                zpre = ops.head_out_finish(parts, b4, B, H, W, L.ACT_NONE) if (save and lay["final"] == "sine") else None
                 del parts
             else:
                 h3 = ops.gemm_nt(h2, w3, b3, act=act)
                 out = ops.head_out_fwd(h3, w4, b4, B, H, W, _ACT[lay["final"]])
+                zpre = ops.head_out_fwd(h3, w4, b4, B, H, W, L.ACT_NONE) if (save and lay["final"] == "sine") else None
             outs.append(out)
             if save:
-                heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=out))
+                heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=(zpre if zpre is not None else out)))
             del h1, h2, h3
         if save:
             S["heads"] = heads_saved

@@ -45,3 +45,48 @@ def make_batch(B, H, W, seed=0):
     images = uniform01(f"images:{seed}", (B, 3, H, W))
     cf, sdf, sal = labels_from_masks(ellipse_masks(B, H, W, seed))
     return images, cf, sdf, sal
+
+
+def blob_images(B, H, W, seed=0, n_blobs=3):
+    """Structured RGB test images: a dim flat background and `n_blobs` flat-coloured discs per image (object-like content, so
+    that a randomly initialised net's fields vary over the image instead of averaging out as they do on uniform noise).
+    Determined by (B, H, W, seed) through the hash RNG alone."""
+    u = uniform01(f"blobs:{seed}", (B, 3 + 6 * n_blobs))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    img = np.zeros((B, 3, H, W), np.float32)
+    for b in range(B):
+        img[b] = (np.float32(0.2) * u[b, 0:3])[:, None, None]
+        for k in range(n_blobs):
+            q = u[b, 3 + 6 * k: 9 + 6 * k]
+            cy, cx = (np.float32(0.2) + np.float32(0.6) * q[0]) * H, (np.float32(0.2) + np.float32(0.6) * q[1]) * W
+            r = (np.float32(0.1) + np.float32(0.2) * q[2]) * min(H, W)
+            inside = ((yy - cy) ** 2 + (xx - cx) ** 2) < r * r
+            img[b] = np.where(inside[None], q[3:6][:, None, None], img[b])
+    return img
+
+
+def object_like_fields(B, H, W, seed=0):
+    """Synthetic (boundary-distance [B,H,W], centre-field [B,2,H,W]) maps with the structure the reasoning stage sees: two
+    discs per map with a soft-sign distance profile (only correctly rounded IEEE operations, so the maps regenerate bit-exactly
+    on any host) and unit vectors converging on (even maps) or diverging from (odd maps) the
+    disc centres, plus small hash noise.  Inputs for the peak-picking fixtures (tests/golden/make_golden_r2.py)."""
+    u = uniform01(f"fields:{seed}", (B, 2, 3))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    sdf = np.zeros((B, H, W), np.float32)
+    cen = np.zeros((B, 2, H, W), np.float32)
+    for b in range(B):
+        sign = np.float32(-1.0 if b % 2 == 0 else 1.0)
+        for k in range(2):
+            cy, cx = (np.float32(0.25) + np.float32(0.5) * u[b, k, 0]) * H, (np.float32(0.25) + np.float32(0.5) * u[b, k, 1]) * W
+            r = (np.float32(0.15) + np.float32(0.2) * u[b, k, 2]) * min(H, W)
+            d = np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2).astype(np.float32)
+            t = (r - d) / np.float32(8.0)
+            sdf[b] = np.maximum(sdf[b], (t / (np.float32(1.0) + np.abs(t))).astype(np.float32))  # soft sign: +,-,*,/,sqrt only
+            inside = d < r
+            n = d + np.float32(1e-6)
+            cen[b, 0] = np.where(inside, sign * (yy - cy) / n, cen[b, 0])
+            cen[b, 1] = np.where(inside, sign * (xx - cx) / n, cen[b, 1])
+        sdf[b] = sdf[b] * np.float32(2.0) - np.float32(0.3)
+    sdf += np.float32(0.1) * (uniform01(f"fields:{seed}:ns", (B, H, W)) - np.float32(0.5))
+    cen += np.float32(0.1) * (uniform01(f"fields:{seed}:nc", (B, 2, H, W)) - np.float32(0.5))
+    return sdf.astype(np.float32), cen.astype(np.float32)

@@ -1,18 +1,28 @@
 """Headline benchmark: images/sec of one ObjectnessNet training step (forward + 4-term
 loss + backward + gradient all-reduce + Adam) on synthetic 384x384 batches.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W                  (N > 1: this process only starts N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU (RCCL over xGMI for N > 1), weak scaling (fixed per-GPU batch).
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     -- the dominant kernel (bf16 implicit-GEMM 3x3 conv 512->512 of the heads),
+  roofline     -- the dominant kernel (the implicit-GEMM 3x3 conv 512->512 of the heads),
                   timed live with HIP events on its launch stream;
-  cpu_baseline -- the CPU oracle's train step on the host cores (rank 0, N == 1 only).
+  cpu_baseline -- the CPU oracle on the host cores (rank 0, N == 1 only).
+
+Workloads (BASELINE.json configs): cfg2 (default; configs[1], the one the metric is quoted on; configs[2] is the same at
+N = 8), cfg1 (configs[0]: ViT-S/16 224x224 batch 2 forward only), cfg4 (configs[3]: ViT-L/14 518x518 batch 16 train step),
+cfg5 (configs[4]: the object_reasoning.py inference sweep -- per 640x480 image the 1,225 anchors of :109-137 as 128x128 crops in
+batches of 50 through crop+resize, the net, centre peak picking and boundary deltas; one step = one image), tiny (plumbing).
+`--rehearse` runs the multi-process plumbing alone on CPU tensors (rendezvous, barrier, bucketed all-reduce of a gradient
+buffer of the workload's size, max-over-ranks timing) -- no model, no `value`; it exists so that the N > 1 launch path of this
+file is covered by a world_size-2 gloo test in a container without a GPU.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +31,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
+    "cfg1": dict(kind="forward", backbone="dpt_small", H=224, W=224, batch=2, name="ObjectnessNet ViT-S/16 224x224 batch=2 forward-only"),
     # BASELINE.json configs[1]: the configuration the metric is quoted on
-    "cfg2": dict(backbone="dpt_base", H=384, W=384, batch=64, name="ObjectnessNet ViT-B/16 384x384 bf16 batch=64 train"),
-    "cfg4": dict(backbone="dpt_large14", H=518, W=518, batch=16, name="ObjectnessNet ViT-L/14 518x518 bf16 batch=16 train"),
-    "tiny": dict(backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
+    "cfg2": dict(kind="train", backbone="dpt_base", H=384, W=384, batch=64, name="ObjectnessNet ViT-B/16 384x384 bf16 batch=64 train"),
+    "cfg4": dict(kind="train", backbone="dpt_large14", H=518, W=518, batch=16, name="ObjectnessNet ViT-L/14 518x518 bf16 batch=16 train"),
+    "cfg5": dict(kind="sweep", backbone="dpt_base", H=128, W=128, batch=50, image=(480, 640), proposals=1225,
+                 name="object_reasoning sweep: ViT-B/16 maps on 640x480 images, 1225 proposals/image as 128x128 crops in batches of 50"),
+    "tiny": dict(kind="train", backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -48,58 +61,118 @@ def forward_gflop_per_image(cfg, H, W):
     return fl / 1e9
 
 
-def cpu_baseline(workload, seconds_budget=20.0):
-    """Reference-style CPU path (the oracle: fp32 PyTorch ops, autograd, Adam) on the host cores.
-    Bounded sample: ONE image at half the workload's resolution per side (a quarter of the pixels; the two
-    full-resolution heads are ~90 % of the FLOPs and scale with the pixel count), i.e. ~1/4 of one
-    image-step of the workload; images/sec = (1 / step time) / 4; up to 8 timed steps within ~20 s keep the default
-    bench run inside a few minutes."""
-    import torch
-    from oracle import objectness_oracle as orc
-    from unmore_amd import synth
-    from unmore_amd.hashrng import hash_init
-    # threads = this process's CPU share: the affinity mask, capped at 16 (a 1-GPU box exposes all host cores
-    # but grants 16; oversubscribing 256 threads made one step ~50x slower)
+def anchors(height, width):
+    """the proposal grid of object_reasoning.py:109-137: 5 grid sizes x 3 anchor shapes around every grid point, clipped to the
+    image, plus the whole image (1,225 boxes for 640x480)."""
+    import numpy as np
+    out = []
+    for gs in (32, 64, 128, 256, 512):
+        xc, yc = np.meshgrid(np.arange(0, width, gs, dtype=int), np.arange(0, height, gs, dtype=int))
+        c = np.stack([xc.flatten(), yc.flatten(), xc.flatten(), yc.flatten()]).transpose().reshape(-1, 1, 4)
+        base = np.array([[-gs, -gs, gs, gs], [-gs / 2, -gs, gs / 2, gs], [-gs, -gs / 2, gs, gs / 2]]).reshape(1, -1, 4)
+        out.append((c + base).reshape(-1, 4))
+    out = np.concatenate(out, 0).astype(np.float64)
+    out[:, 0][out[:, 0] < 0] = 0
+    out[:, 1][out[:, 1] < 0] = 0
+    out[:, 2][out[:, 2] >= width] = width
+    out[:, 3][out[:, 3] >= height] = height
+    return np.concatenate((out, [[0, 0, width, height]]), 0)
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def _host():
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # threads = this process's CPU share, capped at 16 (a 1-GPU box exposes all host cores but grants 16; oversubscribing
+    # 256 threads made one step ~50x slower)
     cores = max(1, min(cores, 16))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cores, model
+
+
+def cpu_baseline(wl):
+    """the CPU restatement (oracle: fp32 PyTorch ops, autograd, Adam) of the same workload on the host
+    cores, torch threads = the process's CPU share; 2 warm-ups, median of >= 5 timed iterations (3 when one iteration takes
+    longer than 12 s).  Train workloads: the full step (fwd + loss + bwd + Adam) on ONE image of the workload's own
+    resolution (a batch of 64 does not fit the time budget; every image is independent, so images/sec = 1 / step time).
+    cfg1: the whole workload (forward, batch 2).  cfg5: crop+resize, forward, peak picking and box deltas on 10 of an
+    image's 1,225 proposals; images/sec = (10 / time) / 1225."""
+    import numpy as np
+    import torch
+    from oracle import objectness_oracle as orc
+    from unmore_amd import synth
+    from unmore_amd.hashrng import hash_init
+    cores, model = _host()
     torch.set_num_threads(cores)
-    cfg = orc.CONFIGS[workload["backbone"]]
-    p = cfg["patch"]
-    H, W = max(p * 2, workload["H"] // 2 // p * p), max(p * 2, workload["W"] // 2 // p * p)
-    frac = (H * W) / float(workload["H"] * workload["W"])
+    cfg = orc.CONFIGS[wl["backbone"]]
     spec = orc.state_dict_spec(cfg)
-    sd = {k: torch.from_numpy(hash_init(k, s, "bench")).requires_grad_(True) for k, s in spec.items()}
-    img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(1, H, W, seed=123))
-    m = {k: torch.zeros_like(v) for k, v in sd.items()}
-    v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+    kind = wl["kind"]
+    H, W = wl["H"], wl["W"]
+    if kind == "train":
+        sd = {k: torch.from_numpy(hash_init(k, s, "bench")).requires_grad_(True) for k, s in spec.items()}
+        img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(1, H, W, seed=123))
+        m = {k: torch.zeros_like(v) for k, v in sd.items()}
+        v = {k: torch.zeros_like(v_) for k, v_ in sd.items()}
+        per_iter, what = 1.0, f"one train step (fwd+loss+bwd+Adam) on 1 image of {H}x{W}"
 
-    def one(step):
-        for t in sd.values():
-            t.grad = None
-        loss, _ = orc.loss_terms(orc.forward(sd, img, cfg), cf, sdf, sal)
-        loss.backward()
-        with torch.no_grad():
-            for k, t in sd.items():
-                if t.grad is not None:
-                    orc.adam_update(t, t.grad, m[k], v[k], step)
+        def one(step):
+            for t in sd.values():
+                t.grad = None
+            loss, _ = orc.loss_terms(orc.forward(sd, img, cfg), cf, sdf, sal)
+            loss.backward()
+            with torch.no_grad():
+                for k, t in sd.items():
+                    if t.grad is not None:
+                        orc.adam_update(t, t.grad, m[k], v[k], step)
+    elif kind == "forward":
+        sd = {k: torch.from_numpy(hash_init(k, s, "bench")) for k, s in spec.items()}
+        img = torch.from_numpy(synth.make_batch(wl["batch"], H, W, seed=123)[0])
+        per_iter, what = float(wl["batch"]), f"forward of the whole workload ({wl['batch']} images of {H}x{W})"
 
-    print("[bench] cpu_baseline: timing the CPU oracle ...", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    one(1)  # warm-up (also sizes the budget)
-    first = time.perf_counter() - t0
-    print(f"[bench] cpu_baseline: warm-up step {first:.1f} s", file=sys.stderr, flush=True)
-    n = max(1, min(8, int(seconds_budget / max(first, 1e-3))))   # ~10-20 s of CPU work
-    t0 = time.perf_counter()
+        def one(step):
+            with torch.no_grad():
+                orc.forward(sd, img, cfg)
+    else:  # sweep
+        sd = {k: torch.from_numpy(hash_init(k, s, "bench")) for k, s in spec.items()}
+        Hi, Wi = wl["image"]
+        image = torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=123)[0])
+        props = torch.from_numpy(anchors(Hi, Wi))[600:610]
+        per_iter, what = 10.0 / wl["proposals"], "crop+resize, forward, peak picking, box deltas on 10 of one image's 1225 proposals"
+
+        def one(step):
+            with torch.no_grad():
+                crops = orc.crop_resize(image, props, 128)
+                out = orc.forward(sd, crops, cfg)
+                orc.peak_pick(out["sdf_maps"][:, 0], out["center_fields"])
+                orc.update_bbox_with_boundary_fields(out["sdf_maps"][:, 0])
+
+    print(f"[bench] cpu_baseline: timing the CPU oracle ({what}) on {cores} threads ...", file=sys.stderr, flush=True)
+    times = []
+    for i in range(2):
+        t0 = time.perf_counter()
+        one(1 + i)
+        times.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline: warm-up {i + 1}/2 {times[-1]:.1f} s", file=sys.stderr, flush=True)
+    n = 5 if times[-1] <= 12.0 else 3
+    timed = []
     for i in range(n):
-        one(2 + i)
-        print(f"[bench] cpu_baseline: step {i + 1}/{n} done", file=sys.stderr, flush=True)
-    dt = (time.perf_counter() - t0) / n
-    return {"value": frac / dt, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} timed train step(s) (fwd+loss+bwd+Adam, fp32, torch CPU, {cores} threads) on 1 image of {H}x{W} "
-                      f"(= {frac:.2f} of one {workload['H']}x{workload['W']} image), after 1 warm-up; value scaled to full-size images"}
+        t0 = time.perf_counter()
+        one(3 + i)
+        timed.append(time.perf_counter() - t0)
+        print(f"[bench] cpu_baseline: iteration {i + 1}/{n} {timed[-1]:.1f} s", file=sys.stderr, flush=True)
+    med = float(np.median(timed))
+    return {"value": per_iter / med, "unit": "images/sec", "cores": cores, "cpu_model": model, "kind": "port",
+            "sample": f"median of {n} timed iterations after 2 warm-ups, each = {what}; fp32, torch CPU, {cores} threads; "
+                      f"median {med:.2f} s/iteration"}
 
 
 def measured_traffic(a):
@@ -109,8 +182,7 @@ def measured_traffic(a):
     if a.workload != "cfg2" or a.dtype != "bf16" or a.batch is not None:
         return {"traffic": None}
     import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         try:
             ks = json.load(open(f))["kernels"]
             # the head conv runs as <conv, epilogue class 3> (forward, sdf data gradient) and <conv, 0> (ReLU-masked data gradient)
@@ -118,93 +190,190 @@ def measured_traffic(a):
             for k in ks:
                 if k["kernel"].startswith(("gemm_nt256p_kernel<1, 3", "gemm_nt256p_kernel<1, 0")) and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
                     return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
-                            "traffic_source": os.path.relpath(f, here), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
+                            "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
         except (OSError, ValueError, KeyError):
             continue
     return {"traffic": None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
-    a = ap.parse_args()
+# ----------------------------------------------------------------------------------------------- rank launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` called plainly: this parent has not touched the GPU (no torch import yet); it starts N fresh
+    rank processes of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, passes rank 0's JSON line through
+    and exits with the ranks' status.  No exec of anything from a GPU-initialised process."""
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = env0.get("MASTER_PORT") or str(_free_port())
+    env0["WORLD_SIZE"] = str(n)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
+    out0 = procs[0].stdout.read().decode()
+    rc = 0
+    deadline = time.time() + 120
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()   # exactly the child we started
+            code = -9
+        rc = rc or code
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- per-rank body
+def run_rank(a):
+    import numpy as np
     import torch
     import torch.distributed as dist
     from argparse import Namespace
-    from unmore_amd import ops, synth
-    from unmore_amd.engine import CONFIGS
-    from unmore_amd.objectness_net import ObjectnessNet
-    from unmore_amd.trainer import TrainStep
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    wl = WORKLOADS[a.workload]
+    if a.rehearse:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+        ndev = torch.cuda.device_count()
+        assert a.backend == "gloo" or world <= ndev, f"{world} ranks but {ndev} GPUs (RCCL needs one device per rank)"
+        torch.cuda.set_device(local % ndev)   # gloo rehearsal on a 1-GPU box: ranks share the device
+        dev = torch.device("cuda", local % ndev)
+    coll = {"backend": "none", "world": world}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-
-    wl = WORKLOADS[a.workload]
-    B = a.batch or wl["batch"]
-    H, W = wl["H"], wl["W"]
-    cfg = CONFIGS[wl["backbone"]]
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-
-    torch.manual_seed(0)  # identical random-init weights on every rank
-    net = ObjectnessNet(dev, H, wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
-    net.set_compute_dtype(dt)
-    net.train()
-    step = TrainStep(net, lr=1e-4, center_field_loss_type="l2", sdf_loss_type="l1", use_sdf_gradient_loss=True,
-                     use_sdf_binary_mask_loss=True, lr_milestones=(10000, 20000), lr_gamma=0.1)
-    img, cf, sdf, sal = (torch.from_numpy(x).to(dev) for x in synth.make_batch(B, H, W, seed=rank))
-
-    # dominant kernel: 3x3 conv 512->512 over all B*H*W pixels (heads: 2 forward + 2 data-gradient launches / step)
-    def is_head_conv(d):
-        return d.conv == 1 and d.Cin == 512 and d.N == 512 and d.M == B * H * W
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+            coll = {"backend": "nccl (RCCL)", "world": dist.get_world_size(), "rccl_version": ".".join(map(str, torch.cuda.nccl.version()))}
+        else:
+            dist.init_process_group("gloo")
+            coll = {"backend": "gloo", "world": dist.get_world_size()}
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    if a.rehearse:
+        return rehearse(a, wl, world, rank, coll, barrier, max_over_ranks)
+
+    from unmore_amd import ops, reasoning, synth
+    from unmore_amd.engine import CONFIGS
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd.trainer import TrainStep
+
+    B = a.batch or wl["batch"]
+    H, W = wl["H"], wl["W"]
+    cfg = CONFIGS[wl["backbone"]]
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    kind = wl["kind"]
+
+    torch.manual_seed(0)  # identical random-init weights on every rank
+    net = ObjectnessNet(dev, H, wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
+    net.set_compute_dtype(dt)
+    M_head = B * H * W
+
+    # dominant kernel: 3x3 conv 512->512 over all pixels of the batch (heads; train: 2 forward + 2 data-gradient launches / step)
+    def is_head_conv(d):
+        return d.conv == 1 and d.Cin == 512 and d.N == 512 and d.M == M_head
+
+    extra = {}
+    if kind == "train":
+        net.train()
+        step = TrainStep(net, lr=1e-4, center_field_loss_type="l2", sdf_loss_type="l1", use_sdf_gradient_loss=True,
+                         use_sdf_binary_mask_loss=True, lr_milestones=(10000, 20000), lr_gamma=0.1)
+        img, cf, sdf, sal = (torch.from_numpy(x).to(dev) for x in synth.make_batch(B, H, W, seed=rank))
+        last = [None]
+
+        def one():
+            last[0] = step.step(img, cf, sdf, sal)
+        units_per_step = B
+    elif kind == "forward":
+        net.eval()
+        for p in net.parameters():
+            p.requires_grad = False
+        img = torch.from_numpy(synth.make_batch(B, H, W, seed=rank)[0]).to(dev)
+
+        def one():
+            with torch.no_grad():
+                net.get_prediction(img)
+        units_per_step = B
+    else:  # sweep: one step = one 640x480 image = 1225 proposals (replicas only: every rank sweeps its own images)
+        net.eval()
+        for p in net.parameters():
+            p.requires_grad = False
+        Hi, Wi = wl["image"]
+        props = torch.from_numpy(anchors(Hi, Wi))
+        assert props.shape[0] == wl["proposals"]
+        n_img = max(1, min(4, a.steps))
+        images = [torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=1000 * rank + i)[0]).to(dev) for i in range(n_img)]
+        counter = [0]
+        peaks = [0, 0]
+        M_head = 50 * 128 * 128
+
+        def one():
+            image = images[counter[0] % n_img]
+            counter[0] += 1
+            for b0 in range(0, props.shape[0], 50):
+                crops, _ = reasoning.crop_resize(image, props[b0:b0 + 50], 128)
+                with torch.no_grad():
+                    out = net.get_prediction(crops)
+                sdf_, cen_ = out["sdf_maps"].squeeze(1), out["center_fields"]
+                mx, am = reasoning.center_peaks(sdf_, cen_)
+                reasoning.update_bbox_with_boundary_fields(sdf_)
+            peaks[0], peaks[1] = mx, am
+        units_per_step = 1
 
     for _ in range(a.warmup):
-        step.step(img, cf, sdf, sal)
+        one()
     barrier()
     ops.set_kernel_timer(is_head_conv)
     t0 = time.perf_counter()
-    last = None
     for _ in range(a.steps):
-        last = step.step(img, cf, sdf, sal)
+        one()
     barrier()
     elapsed = time.perf_counter() - t0
     conv_ms = ops.kernel_timer_results_ms()
     ops.set_kernel_timer(None)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(last[0].item())
+    elapsed = max_over_ranks(elapsed)
 
     if rank == 0:
         fwd_gflop = forward_gflop_per_image(cfg, H, W)
-        conv_flop = 2.0 * B * H * W * 512 * 4608
+        conv_flop = 2.0 * M_head * 512 * 4608
         avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = conv_flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        name = wl["name"] if a.batch is None else wl["name"].replace(f"batch={wl['batch']}", f"batch={B}")
+        if a.dtype != "bf16":
+            name = name.replace("bf16", a.dtype)
+        metric = {"train": "images/sec (train fwd+bwd)", "forward": "images/sec (forward)", "sweep": "images/sec (inference sweep)"}[kind]
         res = {
-            "metric": "images/sec (train fwd+bwd) ObjectnessNet ViT-B/16 384x384" if a.workload == "cfg2" else f"images/sec (train fwd+bwd) {wl['name']}",
-            "value": world * B * a.steps / elapsed,
+            "metric": "images/sec (train fwd+bwd) ObjectnessNet ViT-B/16 384x384" if a.workload == "cfg2" else f"{metric} {wl['name']}",
+            "value": world * units_per_step * a.steps / elapsed,
             "unit": "images/sec",
             "n_gpus": world,
             "steps": a.steps,
@@ -215,18 +384,30 @@ def main():
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": wl["name"] if a.batch is None else wl["name"].replace(f"batch={wl['batch']}", f"batch={B}"),
-                       "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
-                       "parallelism": f"dp{world}", "optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"},
-            "train_tflops_per_gpu": 3 * fwd_gflop * B * a.steps / elapsed / 1e3,
-            "final_loss": loss_val,
+            "config": {"workload": name, "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
+                       "parallelism": (f"dp{world}" if kind == "train" else f"replicas x{world}")},
+            "collective": coll,
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256p_kernel<conv3x3> bf16 512->512 (heads, fwd+dgrad)" if a.dtype == "bf16" else "gemm_nt_kernel<f32,conv3x3>",
+            "roofline": {"bound": "mfma", "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 (heads" + (", fwd+dgrad)" if kind == "train" else ", fwd)")
+                                                     + (" bf16" if a.dtype == "bf16" else " f32")),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,
                          **measured_traffic(a)},
         }
-        if world == 1 and not a.no_alt:
+        if kind == "train":
+            res["config"].update({"optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"})
+            res["train_tflops_per_gpu"] = 3 * fwd_gflop * B * a.steps / elapsed / 1e3
+            res["final_loss"] = float(last[0][0].item())
+        elif kind == "forward":
+            res["forward_tflops_per_gpu"] = fwd_gflop * B * a.steps / elapsed / 1e3
+        else:
+            res["crops_per_sec"] = world * wl["proposals"] * a.steps / elapsed
+            res["config"].update({"proposals_per_image": wl["proposals"], "crop": [128, 128], "crops_per_batch": 50,
+                                  "source_image": list(wl["image"]),
+                                  "stages": "crop+resize, ObjectnessNet maps, centre peak picking, boundary box deltas"})
+            res["est_minutes_for_5000_images"] = 5000.0 / res["value"] / 60.0
+            res["last_batch_maps_with_peak"] = int((peaks[0] > 0).sum().item())
+        if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
             # algebraic form of the linear boundary-distance head (identical function and gradients
             # up to rounding, tests/test_train_gpu.py::test_collapsed_sdf_head_equals_factored)
@@ -249,7 +430,63 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks):
+    """Multi-process plumbing alone (CPU tensors): what bench.py does around the model for N > 1."""
+    import torch
+    import torch.distributed as dist
+    from oracle import objectness_oracle as orc   # shapes only (the gradient buffer's size); nothing is computed with it
+    from unmore_amd.parallel import BucketedAllReduce
+    import numpy as np
+    n = sum(int(np.prod(s)) for s in orc.state_dict_spec(orc.CONFIGS[wl["backbone"]]).values())
+    flat = torch.full((n,), float(rank + 1))
+    nb = 8
+    bounds = [n * i // nb for i in range(nb + 1)]
+    comm = BucketedAllReduce(flat, bounds)
+    for _ in range(a.warmup):
+        for k in range(nb):
+            comm.ready(k)
+        comm.finish()
+    flat.fill_(float(rank + 1))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        for k in range(nb):
+            comm.ready(k)
+        scale = comm.finish()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    expect = float(sum(range(1, world + 1))) * (world ** (a.steps - 1))
+    ok = bool(torch.all(flat == expect)) and scale == 1.0 / world
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "metric": "distributed plumbing only (no model)", "value": None, "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "collective": coll, "allreduce_elements": n,
+                          "allreduce_correct": ok, "config": {"workload": wl["name"], "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo = rehearsal transport (ranks may share a GPU)")
+    ap.add_argument("--rehearse", action="store_true", help="CPU-only: run the multi-process plumbing without the model")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
+    a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)
+    return run_rank(a)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -1,0 +1,59 @@
+"""bench.py's N > 1 launch path on CPU (gloo, world_size 2): called plainly (`python bench.py --gpus 2`) the parent starts the
+rank processes itself; called the way the driver does it (torch.distributed.run) it reads RANK / WORLD_SIZE from the
+environment.  `--rehearse` = the plumbing around the model only (rendezvous, barrier, bucketed all-reduce, max-over-ranks
+timing); the model itself needs the MI355X (tests/test_bench_gpu.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    return env
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_bench_spawns_its_own_ranks_when_called_plainly():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rehearse", "--workload", "tiny", "--steps", "3",
+                        "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_json_line(r.stdout)
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["rehearsal"] is True
+    assert res["collective"] == {"backend": "gloo", "world": 2}
+    assert res["allreduce_correct"] is True and res["ms_per_step"] > 0
+
+
+def test_bench_under_torch_distributed_run():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), BENCH, "--gpus", "2", "--backend", "gloo", "--rehearse", "--workload", "tiny",
+           "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = _one_json_line(r.stdout)
+    assert res["n_gpus"] == 2 and res["allreduce_correct"] is True
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--backend", "gloo", "--workload", "tiny"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

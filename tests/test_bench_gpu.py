@@ -1,0 +1,42 @@
+"""bench.py end to end on the one-GPU box: the plain `--gpus 2` call (self-spawned ranks, gloo transport, both ranks on the
+one device, miniature workload) prints ONE line with n_gpus 2, and the single-GPU lines of the small workloads carry the
+contract's keys.  RCCL itself needs one device per rank and is first exercised by the driver's multi-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(*args, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, *args], env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_two_ranks_spawned_by_bench_itself():
+    res = _run("--gpus", "2", "--workload", "tiny", "--backend", "gloo", "--steps", "3", "--warmup", "1")
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 4 and res["config"]["parallelism"] == "dp2"
+    assert res["collective"]["backend"] == "gloo" and res["collective"]["world"] == 2
+    assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
+
+
+@pytest.mark.parametrize("workload,extra", [("tiny", []), ("cfg1", []), ("cfg5", ["--steps", "1", "--warmup", "1"])])
+def test_single_gpu_lines_carry_the_contract(workload, extra):
+    res = _run("--workload", workload, "--no-cpu-baseline", *(extra or ["--steps", "2", "--warmup", "1"]))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in res, k
+    assert res["n_gpus"] == 1 and res["value"] > 0 and "workload" in res["config"]
+    rf = res["roofline"]
+    assert rf["bound"] == "mfma" and rf["launches_timed"] > 0 and 0 < rf["frac"] < 1
+    if workload == "cfg5":
+        assert res["config"]["proposals_per_image"] == 1225 and res["crops_per_sec"] > 0

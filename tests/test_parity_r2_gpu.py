@@ -167,22 +167,36 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     print(f"loss-gradient maps: {bad_c} centre / {bad_s} sdf pixels differ from the oracle; {undecidable} L1 signs undecidable at "
           f"forward error {fwd_err:.1e}")
     assert bad_c == 0 and bad_s <= 3 * undecidable + 2
-    # (2) network backward against the oracle's VJP with identical cotangents
+    # (2) network backward against the oracle's VJP with identical cotangents.  What remains between fp32 and float64 is the
+    # other discontinuity: ReLU masks decided differently where a pre-activation is within rounding of zero (features are
+    # O(20) here).  The reference CPU path is fp32 and has the same property, so it is the yardstick: the same VJP by the
+    # oracle in fp32 on the CPU.  Bars per parameter tensor: max-norm error <= max(5e-4, 2x the CPU fp32 path's) * max|g| and
+    # relative L2 error <= max(5e-4, 2x the CPU fp32 path's).
     names = [n for n, _ in net.named_parameters()]
     ref = torch.autograd.grad([out_o["center_fields"], out_o["sdf_maps"]], [sdo[n] for n in names],
                               grad_outputs=[dpc.cpu().double(), dps.cpu().double()], allow_unused=True)
+    sd32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_32 = orc.forward(sd32, img, orc.CONFIGS["dpt_base"])
+    ref32 = torch.autograd.grad([out_32["center_fields"], out_32["sdf_maps"]], [sd32[n] for n in names],
+                                grad_outputs=[dpc.cpu(), dps.cpu()], allow_unused=True)
     torch.autograd.backward([out["center_fields"], out["sdf_maps"]], [dpc, dps])
     nograd = net.nograd_names()
-    worst, worst_n = 0.0, ""
-    for (n, p), r in zip(net.named_parameters(), ref):
+    w = dict(hip_inf=(0.0, ""), cpu_inf=(0.0, ""), hip_l2=(0.0, ""), cpu_l2=(0.0, ""))
+    for (n, p), r, r32 in zip(net.named_parameters(), ref, ref32):
         if n in nograd:
             assert p.grad is None and r is None, n
             continue
-        e = (p.grad.cpu().double() - r).abs().max().item() / (r.abs().max().item() + 1e-12)
-        if e > worst:
-            worst, worst_n = e, n
-    print(f"dpt_base fp32 worst relative gradient error {worst:.2e} ({worst_n})")
-    assert worst <= 5e-4, (worst, worst_n)
+        g = p.grad.cpu().double()
+        e = dict(hip_inf=(g - r).abs().max().item() / (r.abs().max().item() + 1e-300),
+                 cpu_inf=(r32.double() - r).abs().max().item() / (r.abs().max().item() + 1e-300),
+                 hip_l2=((g - r).norm() / (r.norm() + 1e-300)).item(), cpu_l2=((r32.double() - r).norm() / (r.norm() + 1e-300)).item())
+        for k, v in e.items():
+            if v > w[k][0]:
+                w[k] = (v, n)
+        assert e["hip_inf"] <= max(5e-4, 2 * e["cpu_inf"]), (n, e)
+        assert e["hip_l2"] <= max(5e-4, 2 * e["cpu_l2"]), (n, e)
+    print("dpt_base fp32 gradients vs float64 VJP, worst over parameters: " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
+    assert w["hip_inf"][0] <= max(5e-4, 2 * w["cpu_inf"][0])
 
 
 def test_bf16_vs_fp32_hip_at_benchmark_shape():

@@ -96,24 +96,35 @@ def test_extension_configs_match_oracle_fp32(backbone, H, W):
         np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-4, rtol=0)
 
 
-def test_inference_crops_128_bf16_and_fp32_peaks():
-    """cfg5-style call: [<=50,3,128,128] crops under no_grad (object_reasoning.py:324-326); fp32 peak indices of the
-    anti-centre score map are identical to the oracle's on the same inputs (ties reported, not hidden)."""
-    net, sd = _net("dpt_tiny", "tiny")
-    net.eval()
+def test_inference_crops_128_fp32_peaks_non_vacuous():
+    """cfg5-style call: [<=50,3,128,128] crops under no_grad (object_reasoning.py:324-326) on structured images with the
+    peak fixtures' weight edits (tests/peaks_common.py: plain hash weights on noise give all-zero score maps, i.e. a test that
+    cannot fail).  The oracle's peak chain on the HIP fields equals the chain on the oracle's own fields wherever the score
+    margin exceeds the propagated field error; every compared map must HAVE a peak."""
+    import peaks_common as pc
+    from unmore_amd.objectness_net import ObjectnessNet
+    sd = pc.edited_state_dict(orc.state_dict_spec(orc.CONFIGS["dpt_tiny"]), "tiny", 0.05, 2.0)
+    net = ObjectnessNet("cuda:0", 128, "dpt_tiny", ARGS)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0").eval()
     B = 6
-    x = torch.from_numpy(uniform01("img:crops", (B, 3, 128, 128)))
+    x = torch.from_numpy(synth.blob_images(B, 128, 128, seed=21))
     with torch.no_grad():
         out = net.get_prediction(x.cuda())
         ref = orc.forward(sd, x, orc.CONFIGS["dpt_tiny"])
+    err = max((out[k].cpu() - ref[k]).abs().max().item() for k in ("sdf_maps", "center_fields"))
+    assert err < 1e-4
     s_g, m_g, a_g = orc.peak_pick(out["sdf_maps"][:, 0].cpu(), out["center_fields"].cpu())
     s_r, m_r, a_r = orc.peak_pick(ref["sdf_maps"][:, 0], ref["center_fields"])
+    assert (m_r > 0).sum() >= B // 2, "vacuous: no score map has a peak"
+    compared = 0
     for b in range(B):
-        if a_g[b] != a_r[b]:
-            # a flipped threshold / near-tie would show here: require the two candidates to be a genuine tie
-            gap = abs(s_r[b].flatten()[a_g[b]] - s_r[b].flatten()[a_r[b]]).item()
-            assert gap < 1e-6, f"image {b}: argmax {int(a_g[b])} vs {int(a_r[b])}, score gap {gap}"
-    torch.testing.assert_close(m_g, m_r, atol=1e-4, rtol=0)
+        top2 = s_r[b].flatten().topk(2).values
+        if m_r[b] > 0 and (top2[0] - top2[1]).item() > 4 * err and torch.equal(s_g[b] != 0, s_r[b] != 0):
+            assert a_g[b] == a_r[b], f"image {b}: argmax {int(a_g[b])} vs {int(a_r[b])}"
+            compared += 1
+    assert compared >= 2
+    torch.testing.assert_close(m_g, m_r, atol=2 * err, rtol=0)
 
 
 def test_batch_filter_matches_reference_semantics():
@@ -189,6 +200,39 @@ def test_collapsed_sdf_head_equals_factored(dtype, H, W):
         a = torch.cat([p.grad.flatten() for _, p in nets["factored"][0].named_parameters() if p.grad is not None])
         b = torch.cat([p.grad.flatten() for _, p in nets["collapsed"][0].named_parameters() if p.grad is not None])
         assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
+
+
+@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64)])
+def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
+    """Default training path: the boundary-distance head's forward runs its four convolutions (identical outputs), its backward
+    takes the exact gradients of all eight factored tensors from three pixel reductions instead of layer-by-layer GEMMs
+    (engine._linear_head_backward).  Both backward forms against each other for EVERY parameter of the net (fp32: 2e-4 *
+    max|g|; the fp64-oracle bar of 5e-4 is asserted on the default path by tests/test_model_gpu.py); bf16: cosine."""
+    from unmore_amd.loss import objectness_loss
+    B = 2
+    img, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(B, H, W, seed=6))
+    res = {}
+    for mode in ("gemm", "algebraic"):
+        net, _ = _net("dpt_tiny", "tiny", dtype)
+        net.set_linear_head_backward(mode)
+        net.train()
+        out = net(images=img.cuda())
+        objectness_loss(out, cf.cuda(), sdf.cuda(), sal.cuda()).backward()
+        res[mode] = (out, {n: p.grad for n, p in net.named_parameters()})
+    assert torch.equal(res["gemm"][0]["sdf_maps"], res["algebraic"][0]["sdf_maps"])       # same forward, bit for bit
+    assert torch.equal(res["gemm"][0]["center_fields"], res["algebraic"][0]["center_fields"])
+    gg, ga = res["gemm"][1], res["algebraic"][1]
+    if dtype == torch.float32:
+        for n in gg:
+            if gg[n] is None:
+                assert ga[n] is None
+                continue
+            err = (ga[n] - gg[n]).abs().max().item() / (gg[n].abs().max().item() + 1e-12)
+            assert err < 2e-4, (n, err)
+    else:
+        a = torch.cat([g.flatten() for g in gg.values() if g is not None]).double()
+        b = torch.cat([ga[n].flatten() for n, g in gg.items() if g is not None]).double()
+        assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.995
 
 
 def test_fused_head_output_layer_matches_unfused(monkeypatch):

@@ -98,11 +98,17 @@ def _rep_bias(b, reps):
 
 _FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch for benchmarking
 _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: one GEMM for the feature-map gradient of both heads
+# Backward of a head without non-linearities between its convs (objectness_net.py:119-142): "algebraic" (default) = exact
+# gradients of all eight factored tensors from three pixel reductions (no 512/1024-channel tensor is stored, read or
+# multiplied in backward); "gemm" = the layer-by-layer data/weight-gradient GEMMs (A/B switch, the round-1 form).
+_LINEAR_HEAD_BWD = os.environ.get("UMR_LINEAR_HEAD_BWD", "algebraic")
 
 
 class Engine:
-    def __init__(self, cfg, head_layouts, compute_dtype=torch.float32, collapse_linear_heads=False):
+    def __init__(self, cfg, head_layouts, compute_dtype=torch.float32, collapse_linear_heads=False, linear_head_backward=None):
         self.cfg = cfg
+        self.linear_head_backward = linear_head_backward or _LINEAR_HEAD_BWD
+        assert self.linear_head_backward in ("algebraic", "gemm")
         self.center_layout, self.sdf_layout = head_layouts
         self.dt = compute_dtype
         self.cache = PackCache()
@@ -111,12 +117,11 @@ class Engine:
         self.collapse_linear_heads = collapse_linear_heads
 
     # ------------------------------------------------------------------ collapsed linear head (opt-in)
-    def _linear_head_forward(self, P, name, idx, feat, act):
-        """W4 W3 (W2 * (W1 x + b1) + b2) + b3) + b4 as one 3x3 conv 256 -> 1 (csrc/linear_head.hip).  All weight
-        algebra is f32 on the master weights (element strides of the PyTorch layouts, no packing):
-          u = W4 W3 [512];  Vc[ci][t] = sum_co u[co] W2[co,ci,t];  Kw[t][c] = sum_ci Vc[ci][t] W1[ci][c];
-          s[t] = sum_ci Vc[ci][t] b1[ci];  c0 = u.b2 + W4.b3 + b4."""
-        dev = feat.device
+    def _linear_head_weights(self, P, name, idx, dev):
+        """The collapsed form of a linear head W4 W3 (W2 * (W1 x + b1) + b2) + b3) + b4 = one 3x3 conv 256 -> 1 plus a
+        border-dependent bias.  All weight algebra is f32 on the master weights (element strides of the PyTorch layouts, no
+        packing):  u = W4 W3 [512];  Vc[ci][t] = sum_co u[co] W2[co,ci,t];  Kw[t][c] = sum_ci Vc[ci][t] W1[ci][c];
+        tb[t] = sum_ci Vc[ci][t] b1[ci] (t < 9);  tb[9] = u.b2 + W4.b3 + b4."""
         W1, b1 = self._f32(P, f"{name}.{idx[0]}.weight"), self._f32(P, f"{name}.{idx[0]}.bias")
         W2, b2 = self._f32(P, f"{name}.{idx[1]}.weight"), self._f32(P, f"{name}.{idx[1]}.bias")
         W3, b3 = self._f32(P, f"{name}.{idx[2]}.weight"), self._f32(P, f"{name}.{idx[2]}.bias")
@@ -132,6 +137,11 @@ class Engine:
         ops.cast(b4, torch.float32, out=tb[9:10])
         ops.small_gemm(u, b2, tb[9:10], 1, 1, C1, (0, 1), (1, 0), (0, 0), accumulate=True)
         ops.small_gemm(W4, b3, tb[9:10], 1, 1, C3, (0, 1), (1, 0), (0, 0), accumulate=True)
+        return u, Vc, Kw, tb
+
+    def _linear_head_forward(self, P, name, idx, feat, act):
+        """opt-in collapsed forward (csrc/linear_head.hip): the head as ONE streaming 3x3 conv 256 -> 1"""
+        u, Vc, Kw, tb = self._linear_head_weights(P, name, idx, feat.device)
         out = ops.linear_head_fwd(feat, Kw, tb, act)
         return out, dict(collapsed=True, u=u, Vc=Vc, Kw=Kw, act=act)
 
@@ -143,6 +153,8 @@ class Engine:
         W4 = self._f32(P, f"{name}.{idx[3]}.weight")
         C, C1, C3 = W1.shape[1], W1.shape[0], W3.shape[0]
         dev = feat.device
+        if "u" not in hs:   # factored forward, algebraic backward: the weight algebra is done here
+            hs["u"], hs["Vc"], hs["Kw"], _ = self._linear_head_weights(P, name, idx, dev)
         act, u, Vc, Kw = hs["act"], hs["u"], hs["Vc"], hs["Kw"]
         dout = dout.contiguous()
         R = ops.linear_head_bwd_weight(feat, dout, hs["out"], act)
@@ -352,6 +364,10 @@ class Engine:
                     heads_saved.append(cs)
                 continue
             act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
+            # a head that is linear up to its output activation needs none of its 512/1024-channel activations in backward
+            # (exact gradients from three pixel reductions over feat, _linear_head_backward); sin is not invertible from its value
+            algebraic = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"
+            keep = save and not algebraic
             h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
             h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
                              conv=1, act=act)
@@ -362,7 +378,7 @@ class Engine:
             if _FUSE_HEAD_OUT and ops.gemm_nt(h2, w3, b3, act=act, query_rowreduce=True):
                 # the 1024 -> {1,2} output layer rides in the epilogue of the GEMM that produces its input (one read of
                 # h3 saved); without saved activations (inference) h3 is not written at all
-                h3, parts = ops.gemm_nt(h2, w3, b3, act=act, red_w=w4.contiguous(), no_store=not save)
+                h3, parts = ops.gemm_nt(h2, w3, b3, act=act, red_w=w4.contiguous(), no_store=not keep)
                 out = ops.head_out_finish(parts, b4, B, H, W, _ACT[lay["final"]])
                 # sin is not invertible from its value: the backward pass of the 'sine' variant gets the pre-activation
                 zpre = ops.head_out_finish(parts, b4, B, H, W, L.ACT_NONE) if (save and lay["final"] == "sine") else None
@@ -372,7 +388,9 @@ class Engine:
                 out = ops.head_out_fwd(h3, w4, b4, B, H, W, _ACT[lay["final"]])
                 zpre = ops.head_out_fwd(h3, w4, b4, B, H, W, L.ACT_NONE) if (save and lay["final"] == "sine") else None
             outs.append(out)
-            if save:
+            if algebraic:
+                heads_saved.append(dict(algebraic=True, act=_ACT[lay["final"]], out=out))
+            elif save:
                 heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=(zpre if zpre is not None else out)))
             del h1, h2, h3
         if save:
@@ -404,13 +422,13 @@ class Engine:
         # Both heads factored: their layer-1 input gradients dh1 go side by side into one [M, 2*C1] buffer and the gradient of
         # the shared feature map is ONE GEMM over K = 2*C1 (instead of a GEMM plus a second one that re-reads and re-writes
         # the [M, 256] result to accumulate into it).
-        merge_dfeat = _MERGE_DFEAT and all(not hs_.get("collapsed") for hs_ in S["heads"])
+        merge_dfeat = _MERGE_DFEAT and all(not (hs_.get("collapsed") or hs_.get("algebraic")) for hs_ in S["heads"])
         dh1cat, w1cat = None, []
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
             idx = lay["conv_idx"]
-            if hs.get("collapsed"):
+            if hs.get("collapsed") or hs.get("algebraic"):
                 dfeat = self._linear_head_backward(P, name, idx, feat, hs, dout, dfeat, G)
                 continue
             relu = lay["relu"]

@@ -212,10 +212,22 @@ class ObjectnessNet(nn.Module):
         self._eng = None
         return self
 
+    def set_linear_head_backward(self, mode):
+        """How the gradients of a head WITHOUT non-linearities between its convs (tanh / None variants of the boundary-distance
+        head, objectness_net.py:119-142) are computed; its forward always runs the four convolutions as the reference does.
+        'algebraic' (default): exact gradients of all eight factored tensors from three pixel reductions over the shared
+        feature map -- the 512/1024-channel activations are neither stored nor multiplied in backward.  'gemm': the
+        layer-by-layer data- and weight-gradient GEMMs."""
+        assert mode in ("algebraic", "gemm")
+        self.linear_head_bwd_mode = mode
+        self._eng = None
+        return self
+
     def _engine(self):
         if self._eng is None or self._eng.dt != self.compute_dtype:
             self._eng = Engine(self.cfg, self._layouts, self.compute_dtype,
-                               collapse_linear_heads=(getattr(self, "sdf_head_mode", "factored") == "collapsed"))
+                               collapse_linear_heads=(getattr(self, "sdf_head_mode", "factored") == "collapsed"),
+                               linear_head_backward=getattr(self, "linear_head_bwd_mode", None))
         return self._eng
 
     def nograd_names(self):

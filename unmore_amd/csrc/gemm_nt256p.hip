@@ -68,13 +68,23 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // The fast class is specialised at compile time: as runtime flag tests its 32 values per thread and pass cost ~1000
 // issue cycles per wave (4 branches per 4 values), and an epilogue pass is pure issue time on 2 waves per SIMD.
 template <int CONV, int EPI, int AUXM, bool RED>
-__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles) {
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger) {
     constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
     constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Stagger (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  Waves w and w+4 share a SIMD.  When all eight waves run
+    // the same [read fragments, wait, barrier, MFMA] program they reach their LDS read bursts (128 KiB per phase = 512 LDS
+    // cycles) and the barrier together, and the matrix pipe idles meanwhile: 2.78 k cycles per K-tile for 2.05 k of MFMA work.
+    // Waves 0-3 therefore run ONE PHASE AHEAD of waves 4-7 in their MFMA work: per barrier interval they read the phase's
+    // fragments right AFTER the barrier that publishes them and multiply at once ([barrier] read, MFMA), while waves 4-7
+    // keep the original order ([barrier] MFMA of the previous phase, read).  Inside an interval one half's LDS burst and
+    // barrier wait sits beside the other half's MFMAs.  Both halves read a phase's data in the same interval and issue the
+    // same LDS-DMA groups in the same interval (the ahead half carries in its MFMA block the groups the other half issues
+    // in the block it runs meanwhile), so LDS lifetimes, counted vmcnt waits and barrier counts are unchanged.
+    const bool ahead = (stagger != 0) && (w < 4);
 
     // tile sequence of this workgroup: virtual ids pw, pw + G, pw + 2G, ...; workgroups of one XCD (blockIdx % 8)
     // own a contiguous run of G/8 ids per round, so neighbouring tiles share that XCD's L2
@@ -304,15 +314,88 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         PT(7);
     };
 
+#define READ_WAIT()                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);
+#define END_SYNC_N(N)                                              \
+    asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");          \
+    __builtin_amdgcn_s_barrier();                                  \
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- waves 0-3 when staggered: per phase [read, MFMA (+ the DMA groups the other half issues meanwhile), wait, barrier]
+    auto tile_body2_ahead = [&](const char* sbuf) {
+        stage_prep();                       // K-tile t+1 (all four groups are issued during this body)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb0[ks][i] = B_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
+        }
+        READ_WAIT();
+        QUADRANT_D(0, 0, fb0, STAGE_DMA(0, 0); STAGE_DMA(0, 1), STAGE_DMA(1, 0); STAGE_DMA(1, 1))
+        QUADRANT_D(0, 2, fb1, STAGE_DMA(2, 0), STAGE_DMA(2, 1))
+        END_SYNC_N(6);                      // A1(t) landed (own part); A0,B0,B1(t+1) may fly
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
+        READ_WAIT();
+        QUADRANT_D(4, 2, fb1, STAGE_DMA(3, 0), STAGE_DMA(3, 1))
+        QUADRANT_D(4, 0, fb0, (void)0, (void)0)
+        END_SYNC_N(2);                      // A0,B0,B1(t+1) landed; A1(t+1) may fly
+    };
+    auto tile_body4_ahead = [&](const char* sbuf) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb0[ks][i] = B_FRAG(ks, i);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, i);
+        }
+        READ_WAIT();
+        QUADRANT(0, 0, fb0, 1)              // B0 of K-tile t+1 (the other half: in its Q(4,0) of K-tile t-1)
+        END_SYNC_N(6);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb1[ks][i] = B_FRAG(ks, 2 + i);
+        READ_WAIT();
+        QUADRANT(0, 2, fb1, 2)
+        END_SYNC_N(6);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
+        READ_WAIT();
+        QUADRANT(4, 2, fb1, 3)
+        END_SYNC_N(6);
+        stage_prep();                       // K-tile t+2
+        QUADRANT(4, 0, fb0, 0)
+        END_SYNC_N(6);
+    };
+
     // prologue: the six groups the steady-state schedule has already issued when the first K-tile starts
     stage_setup(0);
     stage_prep();
     STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
     STAGE_DMA(2, 0); STAGE_DMA(2, 1); STAGE_DMA(3, 0); STAGE_DMA(3, 1);
-    stage_prep();
-    STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
-    if (PH2) { STAGE_DMA(2, 0); STAGE_DMA(2, 1); }   // two-phase schedule: B1 of tile 1 is pre-issued as well
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (ahead) {
+        // the ahead half issues inside its first MFMA block what the other half pre-issues here
+        if (PH2) {
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                     // A0,B0,B1 of K-tile 0 landed
+        } else {
+            stage_prep();
+            STAGE_DMA(0, 0); STAGE_DMA(0, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                     // A0,B0 of K-tile 0 landed
+        }
+    } else {
+        stage_prep();
+        STAGE_DMA(0, 0); STAGE_DMA(0, 1); STAGE_DMA(1, 0); STAGE_DMA(1, 1);
+        if (PH2) { STAGE_DMA(2, 0); STAGE_DMA(2, 1); }   // two-phase schedule: B1 of tile 1 is pre-issued as well
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
 
     float* stg = (float*)(smem + STG_OFF);
@@ -368,17 +451,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 (void*)(p.red_w + (int64_t)w * p.N + n0_), 0, (w < p.red_c) ? clamp31((int64_t)(p.N - n0_) * 4) : 0, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, UMR_LDS_PTR(smem + STG_OFF + w * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
         }
+        if (ahead) {
 #pragma unroll 1
-        for (int t = 0; t < nt; ++t) {
+            for (int t = 0; t < nt; ++t) {
+                if (PH2) tile_body2_ahead(smem + c_par * BUF2); else tile_body4_ahead(smem + c_par * BUF2);
+                c_par ^= 1;
+            }
+        } else {
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) {
 #ifdef UMR_NT256P_TIMESTAMPS
-            ph_rec = (it == 4 && t == 5);
+                ph_rec = (it == 4 && t == 5);
 #endif
-            tile_body(smem + c_par * BUF2);
-            c_par ^= 1;
+                tile_body(smem + c_par * BUF2);
+                c_par ^= 1;
 #ifdef UMR_NT256P_TIMESTAMPS
-            if (t == 0) TS(2);
-            if (t == 1) TS(3);
+                if (t == 0) TS(2);
+                if (t == 1) TS(3);
 #endif
+            }
         }
         TS(4);
         // ---- epilogue of output tile `it`; the next tile's first K-tiles are already in flight
@@ -611,6 +702,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #undef PHASE_SYNC
 #undef PHASE_SYNC_N
 #undef STAGE_DMA
+#undef READ_WAIT
+#undef END_SYNC_N
 #undef A_FRAG
 #undef B_FRAG
 }
@@ -662,8 +755,9 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     // others -- up to 2x the kernel time.  With several shorter workgroups per CU the dispatcher balances them itself; a
     // workgroup still walks >= 32 tiles, so the cross-tile prefetch keeps its value, and workgroups that run together on
     // one XCD still own neighbouring tiles (pw in the kernel).  UMR_NT256_WG_PER_CU overrides the factor.
-    static int wg_per_cu = -1;
+    static int wg_per_cu = -1, stagger = -1;
     if (wg_per_cu < 0) { const char* e = getenv("UMR_NT256_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 0; }
+    if (stagger < 0) { const char* e = getenv("UMR_NT256_STAGGER"); stagger = e ? atoi(e) : 1; }   // A/B switch (0 = all waves in lock-step)
     const int cus = num_cus();
     int64_t kf = wg_per_cu > 0 ? wg_per_cu : total / ((int64_t)cus * 32);
     if (kf < 1) kf = 1;
@@ -681,7 +775,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, AX, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total);              \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger);     \
     } while (0)
     // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged; one instantiation per aux mode, plus the fused
     // row reduction); EPI 4: the GELU class (plain GEMM only); EPI 1: everything else

@@ -575,8 +575,35 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     if (m < p.M && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
                 }
             };
-            pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});
-            pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
+            if (RED && p.no_store) {
+                // inference / algebraic-backward form of the fused output layer: C itself is never stored, so nothing is staged
+                // through LDS and no barrier is needed -- the dot products are taken on the bf16-rounded values in registers
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) {
+                        f32x4 v = acc[mt][ntl];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = (float)(bf16_t)fmaxf(v[e], relu_floor);
+                            rs0 += t * rw[0][ntl][e];
+                            rs1 += t * rw[1][ntl][e];
+                        }
+                    }
+                    rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
+                    rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
+                    const int m = m0 + wr * 128 + mt * 16 + frow;
+                    if (fq == 0 && m < p.M && n0 + wc * 64 < p.N) {
+                        float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
+                        ro[0] = rs0;
+                        if (p.red_c == 2) ro[1] = rs1;
+                    }
+                }
+            } else {
+                pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});
+                pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
+            }
             TS(6);
             __syncthreads();
             TS(7);

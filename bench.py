@@ -260,14 +260,21 @@ def run_rank(a):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
-            coll = {"backend": "nccl (RCCL)", "world": dist.get_world_size(), "rccl_version": ".".join(map(str, torch.cuda.nccl.version()))}
+            try:
+                ver = ".".join(map(str, torch.cuda.nccl.version()))
+            except Exception:   # version query is informational only
+                ver = "unknown"
+            coll = {"backend": "nccl (RCCL)", "world": dist.get_world_size(), "rccl_version": ver}
         else:
             dist.init_process_group("gloo")
             coll = {"backend": "gloo", "world": dist.get_world_size()}
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if a.backend == "nccl" and dev.type == "cuda":
+                dist.barrier(device_ids=[dev.index])
+            else:
+                dist.barrier()
         if dev.type == "cuda":
             torch.cuda.synchronize()
 
@@ -428,7 +435,7 @@ def run_rank(a):
             res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return 0
 

@@ -252,6 +252,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     const bool dbg = (p.rows_per_batch == -9) && blockIdx.x == 0 && tid == 0;
     unsigned long long* dbgp = (unsigned long long*)p.rowbias;
     bool ph_rec = false;   // stamps inside one K-tile (4-phase form): slots 128..135
+    // slots 136..139: shader-clock and 100-MHz real-time stamps around the whole kernel -> the clock the chip holds under
+    // this load = d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6; tools/power_probe.py)
+    if (dbg) { dbgp[136] = __builtin_readcyclecounter(); dbgp[137] = __builtin_amdgcn_s_memrealtime(); }
 #define PT(k) do { if (dbg && ph_rec) dbgp[128 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PT(k) do { } while (0)
@@ -721,6 +724,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     }
     // the trailing (zero-fill) LDS-DMA groups must land before the LDS allocation is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef UMR_NT256P_TIMESTAMPS
+    if (dbg) { dbgp[138] = __builtin_readcyclecounter(); dbgp[139] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 #undef QUADRANT
 #undef TS
 #undef PT

@@ -414,6 +414,19 @@ def run_rank(a):
                                   "stages": "crop+resize, ObjectnessNet maps, centre peak picking, boundary box deltas"})
             res["est_minutes_for_5000_images"] = 5000.0 / res["value"] / 60.0
             res["last_batch_maps_with_peak"] = int((peaks[0] > 0).sum().item())
+        if world == 1 and kind == "sweep" and a.dtype == "bf16" and not a.no_alt:
+            # beside the headline: the same sweep in fp32 (the reference's precision; the mode whose maps are within 1e-4 of the
+            # reference and whose peak indices are bit-identical to it, tests/test_parity_r2_gpu.py), one image
+            net.set_compute_dtype(torch.float32)
+            one()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            net.set_compute_dtype(dt)
+            res["alt_fp32_parity_mode"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
+                                           "note": "fp32 storage and exact-fp32 MFMA: the 1e-4 / bit-exact-peaks mode"}
         if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
             # algebraic form of the linear boundary-distance head (identical function and gradients

@@ -148,6 +148,9 @@ int umr_segsum(const void* x, void* out, int R, int reps, int64_t rep_stride, in
                int out_f32, int accumulate, umr_stream_t stream);
 int umr_fill_cls(void* tokens, const float* cls, const float* pos0, int B, int64_t batch_stride, int D, int dtype, umr_stream_t stream);
 int umr_cast(const void* src, void* dst, int64_t n, float scale, int dtype_in, int dtype_out, umr_stream_t stream);
+/* dst = src * (*scalar), scalar on the device: chains the incoming gradient of the scalar loss (loss.backward(), train_objectness_net.py:259)
+ * into the loss kernel's gradient maps without a host read of that scalar */
+int umr_scale_by_device_scalar(const float* src, const float* scalar, float* dst, int64_t n, umr_stream_t stream);
 
 /* ---- head output layer 1024 -> {1,2} (+tanh / sine=4), NCHW f32 output (objectness_net.py:116,133-134) ---- */
 int umr_head_out_fwd(const void* h, const float* w, const float* bias, float* out, int64_t M, int K, int Cout, int HW, int act,

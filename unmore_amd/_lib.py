@@ -82,6 +82,7 @@ _SIGS = {
     "umr_segsum": [_vp, _vp, _i32, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
     "umr_fill_cls": [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "umr_cast": [_vp, _vp, _i64, _f32, _i32, _i32, _vp],
+    "umr_scale_by_device_scalar": [_vp, _vp, _vp, _i64, _vp],
     "umr_head_out_fwd": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_head_out_bwd_workspace": [_i64, _i32],
     "umr_head_out_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

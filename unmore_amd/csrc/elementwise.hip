@@ -569,6 +569,20 @@ extern "C" int umr_fill_cls(void* tokens, const float* cls, const float* pos0, i
     return UMR_OK;
 }
 
+namespace {
+__global__ void scale_dev_kernel(const float* __restrict__ src, const float* __restrict__ scalar, float* __restrict__ dst, int64_t n) {
+    const float sc = *scalar;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i] * sc;
+}
+}  // namespace
+
+extern "C" int umr_scale_by_device_scalar(const float* src, const float* scalar, float* dst, int64_t n, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && scalar && dst && n > 0, "scale_by_device_scalar: bad arguments");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, scalar, dst, n);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
 extern "C" int umr_cast(const void* src, void* dst, int64_t n, float scale, int dtype_in, int dtype_out, umr_stream_t stream) {
     UMR_CHECK_ARG(src && dst && n > 0, "cast: bad arguments");
     hipStream_t s = (hipStream_t)stream;

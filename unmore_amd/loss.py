@@ -18,11 +18,10 @@ class _LossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_total, g_terms):
         dpc, dps = ctx.saved_tensors
-        # d(total)/d(pred) was produced in the forward pass; chain the incoming scalar with the cast kernel
-        s = float(g_total)
-        if s != 1.0:
-            dpc, dps = ops.cast(dpc, torch.float32, s), ops.cast(dps, torch.float32, s)
-        return dpc, dps, None, None, None, None
+        # d(total)/d(pred) was produced in the forward pass; the incoming scalar (1 for loss.backward()) is applied on the
+        # device -- reading it on the host would synchronise the stream every step
+        g = g_total.detach().reshape(1).to(torch.float32).contiguous()
+        return ops.scale_by_device_scalar(dpc, g), ops.scale_by_device_scalar(dps, g), None, None, None, None
 
 
 def objectness_loss(out_dict, gt_center_fields, gt_sdf_maps, gt_saliency_maps, center_field_loss_type="l2",

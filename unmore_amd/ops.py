@@ -296,6 +296,15 @@ def cast(src, dtype, scale=1.0, out=None):
     return out
 
 
+def scale_by_device_scalar(src, scalar):
+    """src * scalar with the scalar read on the device (no host synchronisation)"""
+    _need_gpu(src, scalar)
+    assert src.dtype == torch.float32 and src.is_contiguous() and scalar.dtype == torch.float32 and scalar.numel() == 1
+    out = torch.empty_like(src)
+    L.check(L.lib().umr_scale_by_device_scalar(_p(src), _p(scalar), _p(out), src.numel(), _stream()), "umr_scale_by_device_scalar")
+    return out
+
+
 ACT_SINE = 4
 
 

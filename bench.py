@@ -230,7 +230,9 @@ def spawn_ranks(n):
             p.kill()   # exactly the child we started
             code = -9
         rc = rc or code
-    sys.stdout.write(out0)
+    # exactly what rank 0 reported goes to stdout: its JSON line; anything a library printed beside it goes to stderr
+    for line in out0.splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
 

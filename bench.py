@@ -434,6 +434,23 @@ def run_rank(a):
             # algebraic form of the linear boundary-distance head (identical function and gradients
             # up to rounding, tests/test_train_gpu.py::test_collapsed_sdf_head_equals_factored)
             del step
+            # (1) the boundary-distance head's backward as layer-by-layer GEMMs (the round-1 form) instead of the exact algebraic
+            #     one the headline uses: same forward, same gradients up to rounding
+            net.set_linear_head_backward("gemm")
+            step1 = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
+            for _ in range(2):
+                step1.step(img, cf, sdf, sal)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step1.step(img, cf, sdf, sal)
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t1) / 3
+            res["alt_gemm_backward_sdf_head"] = {"value": B / dt1, "unit": "images/sec", "ms_per_step": 1e3 * dt1,
+                                                 "note": "boundary-distance head backward as layer-by-layer GEMMs (A/B of the default algebraic backward)"}
+            del step1
+            net.set_linear_head_backward("algebraic")
+            # (2) the opt-in collapsed FORWARD of the same head
             net.set_sdf_head_mode("collapsed")
             step2 = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
             for _ in range(2):

@@ -182,7 +182,26 @@ __global__ void small_gemm_kernel(const float* __restrict__ A, const float* __re
     }
 }
 
-int lh_blocks(int64_t M) { int64_t nb = (M + 4095) / 4096; if (nb > 2048) nb = 2048; if (nb < 1) nb = 1; return (int)nb; }   // upper bound on partial slabs
+// long contractions (K >= 64: u = W4 W3, Vc = u W2, gu = W2 gv, ...): one wave per output, lanes split k -- a thread per
+// output walks K serially at 18-512 threads in flight (0.68 ms for the two 512 x 4608 products)
+__global__ __launch_bounds__(256) void small_gemm_wave_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, SmallGemm g) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)g.M * g.N;
+    for (int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); idx < total; idx += (int64_t)gridDim.x * 4) {
+        const int i = (int)(idx / g.N), j = (int)(idx - (int64_t)i * g.N);
+        const float* a = A + i * g.sa_m;
+        const float* b = B + j * g.sb_n;
+        float s = 0.f;
+        for (int k = lane; k < g.K; k += 64) s += a[k * g.sa_k] * b[k * g.sb_k];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float* c = C + i * g.sc_m + j * g.sc_n;
+            *c = g.accumulate ? *c + s : s;
+        }
+    }
+}
+
+int lh_blocks(int64_t M) { int64_t nb = (M + 4095) / 4096; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return (int)nb; }   // upper bound on partial slabs (4 blocks per CU)
 
 }  // namespace
 
@@ -250,9 +269,15 @@ extern "C" int umr_small_gemm_f32(const float* A, const float* B, float* C, int 
                                   int64_t sb_k, int64_t sb_n, int64_t sc_m, int64_t sc_n, int accumulate, umr_stream_t stream) {
     UMR_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "small_gemm: bad arguments");
     SmallGemm g{M, N, K, sa_m, sa_k, sb_k, sb_n, sc_m, sc_n, accumulate};
-    int64_t nb = ((int64_t)M * N + 255) / 256;
-    if (nb > 8192) nb = 8192;
-    hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, A, B, C, g);
+    if (K >= 64) {
+        int64_t nb = ((int64_t)M * N + 3) / 4;
+        if (nb > 16384) nb = 16384;
+        hipLaunchKernelGGL(small_gemm_wave_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, A, B, C, g);
+    } else {
+        int64_t nb = ((int64_t)M * N + 255) / 256;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(small_gemm_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, A, B, C, g);
+    }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -347,14 +347,7 @@ def run_rank(a):
         def one():
             image = images[counter[0] % n_img]
             counter[0] += 1
-            for b0 in range(0, props.shape[0], 50):
-                crops, _ = reasoning.crop_resize(image, props[b0:b0 + 50], 128)
-                with torch.no_grad():
-                    out = net.get_prediction(crops)
-                sdf_, cen_ = out["sdf_maps"].squeeze(1), out["center_fields"]
-                mx, am = reasoning.center_peaks(sdf_, cen_)
-                reasoning.update_bbox_with_boundary_fields(sdf_)
-            peaks[0], peaks[1] = mx, am
+            peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams)
         units_per_step = 1
 
     for _ in range(a.warmup):
@@ -415,7 +408,8 @@ def run_rank(a):
                                   "source_image": list(wl["image"]),
                                   "stages": "crop+resize, ObjectnessNet maps, centre peak picking, boundary box deltas"})
             res["est_minutes_for_5000_images"] = 5000.0 / res["value"] / 60.0
-            res["last_batch_maps_with_peak"] = int((peaks[0] > 0).sum().item())
+            res["maps_with_peak"] = int((peaks[0] > 0).sum().item())
+            res["config"]["streams"] = a.sweep_streams
         if world == 1 and kind == "sweep" and a.dtype == "bf16" and not a.no_alt:
             # beside the headline: the same sweep in fp32 (the reference's precision; the mode whose maps are within 1e-4 of the
             # reference and whose peak indices are bit-identical to it, tests/test_parity_r2_gpu.py), one image
@@ -519,6 +513,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo = rehearsal transport (ranks may share a GPU)")
     ap.add_argument("--rehearse", action="store_true", help="CPU-only: run the multi-process plumbing without the model")
+    ap.add_argument("--sweep-streams", type=int, default=3, help="cfg5: HIP streams the independent 50-crop batches are dealt to")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()

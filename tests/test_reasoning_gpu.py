@@ -94,3 +94,26 @@ def test_pipeline_crops_to_peaks_fp32():
     assert (m_r > 0).sum() >= 2, "vacuous: no score map has a peak"
     assert torch.equal(am.cpu(), a_r)
     torch.testing.assert_close(mx.cpu(), m_r, atol=1e-12, rtol=0)
+
+
+def test_sweep_over_two_streams_equals_sequential():
+    """reasoning.sweep_proposals deals the independent 50-crop batches to two HIP streams: same peaks / deltas as one stream."""
+    from argparse import Namespace
+    import peaks_common as pc
+    from unmore_amd import reasoning, synth
+    from unmore_amd.objectness_net import ObjectnessNet
+    sd = pc.edited_state_dict(orc.state_dict_spec(orc.CONFIGS["dpt_tiny"]), "tiny", 0.05, 2.0)
+    net = ObjectnessNet("cuda:0", 128, "dpt_tiny", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    net.load_state_dict(sd)
+    net = net.to("cuda:0").eval()
+    img = torch.from_numpy(synth.blob_images(1, 240, 320, seed=4, n_blobs=6)[0]).cuda()
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.rand(130, generator=g) * 200
+    y1 = torch.rand(130, generator=g) * 140
+    boxes = torch.stack([x1, y1, x1 + 40 + torch.rand(130, generator=g) * 80, y1 + 40 + torch.rand(130, generator=g) * 60], 1)
+    a = reasoning.sweep_proposals(net, img, boxes, 50, n_streams=1)
+    b = reasoning.sweep_proposals(net, img, boxes, 50, n_streams=2)
+    torch.cuda.synchronize()
+    assert (a[0] > 0).any()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -105,3 +105,41 @@ def get_prediction_with_proposals(objectness_model, binary_classifier_model, ima
         edge.append(on_edge)
     return {"pred_boundary_fields": torch.cat(sdf, dim=0), "pred_center_fields": torch.cat(cen, dim=0),
             "pred_existence_scores": torch.cat(cls, dim=0).squeeze(1), "on_edge_flags": torch.cat(edge, dim=0)}
+
+
+_sweep_streams = {}
+
+
+def sweep_proposals(objectness_model, image, proposals, num_img_per_batch=50, n_streams=3):
+    """The per-proposal part of `center_reasoning` + the first half of `optimize_one_image_single_round` for ALL proposals of an
+    image (object_reasoning.py:301-337,528-550,139-174): crop + resize, ObjectnessNet maps, centre peaks, boundary box deltas,
+    in the reference's batches of 50.  Batches are independent, so consecutive batches are enqueued on `n_streams` HIP streams
+    in turn: one batch's chain of ~330 small dependent kernels overlaps the other's large head convolutions (results are
+    identical to the sequential order -- every batch runs the same kernels on the same data).
+    Returns (max_values [N] f64, flat_argmax [N] i64, deltas [N,4] f32) on the device."""
+    _need_gpu(image)
+    dev = image.device
+    key = (dev.index, n_streams)
+    if key not in _sweep_streams:
+        _sweep_streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    streams = _sweep_streams[key]
+    props = torch.as_tensor(proposals, dtype=torch.float64)
+    cur = torch.cuda.current_stream(dev)
+    outs = []
+    for s in streams:
+        s.wait_stream(cur)
+    for bi, i in enumerate(range(0, len(props), num_img_per_batch)):
+        st = streams[bi % n_streams]
+        with torch.cuda.stream(st):
+            crops, _ = crop_resize(image, props[i:i + num_img_per_batch], 128)
+            with torch.no_grad():
+                pred = objectness_model.get_prediction(crops)
+            sdf = pred["sdf_maps"].squeeze(1)
+            mx, am = center_peaks(sdf, pred["center_fields"])
+            d = torch.stack(update_bbox_with_boundary_fields(sdf), 1)
+            for t in (crops, sdf, pred["center_fields"], mx, am, d):
+                t.record_stream(st)
+            outs.append((mx, am, d))
+    for s in streams:
+        cur.wait_stream(s)
+    return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs])

@@ -202,7 +202,7 @@ def test_collapsed_sdf_head_equals_factored(dtype, H, W):
         assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
 
 
-@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64)])
+@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64), (torch.float32, 32, 48), (torch.float32, 96, 160)])
 def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
     """Default training path: the boundary-distance head's forward runs its four convolutions (identical outputs), its backward
     takes the exact gradients of all eight factored tensors from three pixel reductions instead of layer-by-layer GEMMs

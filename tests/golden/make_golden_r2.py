@@ -170,7 +170,23 @@ def build_reference_nets():
         dpt.pretrained, dpt.scratch = pre, scratch
         return shell(dpt)
 
-    return base, tiny
+    def small():
+        # BASELINE configs[0]: ViT-S/16 (an extension of the reference's backbone switch) assembled by the
+        # reference's OWN builders with the DPT-small convention: D 384, 12 blocks, 6 heads, hooks [2,5,8,11], features [48,96,192,384]
+        D, depth, nh, Fs, hooks = 384, 12, 6, [48, 96, 192, 384], [2, 5, 8, 11]
+        vit = mg.TimmContractViT(D, depth, nh)
+        pre = _make_vit_b16_backbone(vit, features=Fs, size=[384, 384], hooks=hooks, vit_features=D, use_readout="project")
+        scratch = _make_scratch(Fs, 256, groups=1, expand=False)
+        for k in (1, 2, 3, 4):
+            setattr(scratch, f"refinenet{k}", _make_fusion_block(256, False))
+        scratch.output_conv = nn.Sequential(Interpolate(scale_factor=2, mode="bilinear", align_corners=True))
+        dpt = DPT.__new__(DPT)
+        nn.Module.__init__(dpt)
+        dpt.channels_last = False
+        dpt.pretrained, dpt.scratch = pre, scratch
+        return shell(dpt)
+
+    return base, tiny, small
 
 
 def edit_for_peaks(net, wtag):
@@ -260,7 +276,7 @@ def make_peaks():
     import object_reasoning as orz
     from utils.misc import batch_erode
     OD = orz.Object_Discovery
-    base, tiny = build_reference_nets()
+    base, tiny, _ = build_reference_nets()
     save = {}
     # (a) kernel-level: synthetic object-like fields (regenerated bit-exactly by unmore_amd.synth) through the reference functions
     for tag, (B, H, W, seed) in {"syn128": (6, 128, 128, 0), "syn96x160": (4, 96, 160, 1)}.items():
@@ -299,7 +315,7 @@ def make_peaks():
 
 # --------------------------------------------------------------------------- (iii) full size
 def make_full():
-    base, _ = build_reference_nets()
+    base, _, small = build_reference_nets()
     net = base()
     mg._load_hash_weights(net, "base")
     H = W = 384
@@ -321,6 +337,22 @@ def make_full():
                 feat_absmax=feat.abs().amax(dim=(1, 2)).numpy())
     np.savez_compressed(os.path.join(HERE, "fwd_dpt_base_384_sampled.npz"), **save)
     print("full 384:", {k: (v.shape, float(np.abs(v).max())) for k, v in save.items()})
+    # cfg1 shape: ViT-S/16, 224x224, batch 2
+    net = small()
+    mg._load_hash_weights(net, "dpt_small")
+    x = torch.from_numpy(synth.blob_images(2, 224, 224, seed=12))
+    with torch.no_grad():
+        out = net(images=x)
+    idx = (uniform01("small224:idx", (2048,)) * (224 * 224)).astype(np.int64)
+    cen, sdf = out["center_fields"], out["sdf_maps"]
+    save = dict(sample_idx=idx, center_samples=cen.reshape(2, 2, -1)[:, :, idx].numpy(), sdf_samples=sdf.reshape(2, 1, -1)[:, :, idx].numpy(),
+                center_mean=cen.mean(dim=(0, 2, 3)).numpy(), sdf_mean=sdf.mean(dim=(0, 2, 3)).numpy(),
+                center_absmax=cen.abs().amax(dim=(0, 2, 3)).numpy(), sdf_absmax=sdf.abs().amax(dim=(0, 2, 3)).numpy())
+    np.savez_compressed(os.path.join(HERE, "fwd_dpt_small_224_sampled.npz"), **save)
+    with open(os.path.join(HERE, "schema_dpt_small.txt"), "w") as f:
+        for k, v in net.state_dict().items():
+            f.write(f"{k} {' '.join(map(str, v.shape))}\n")
+    print("small 224:", {k: (v.shape, float(np.abs(v).max())) for k, v in save.items()})
 
 
 def main():

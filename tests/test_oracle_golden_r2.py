@@ -112,3 +112,21 @@ def test_oracle_forward_full_size_matches_reference(golden_dir):
     np.testing.assert_allclose(cen.mean(dim=(1, 2)).numpy(), g["center_mean"], atol=2e-5, rtol=0)
     np.testing.assert_allclose(sdf.abs().amax(dim=(1, 2)).numpy(), g["sdf_absmax"], atol=5e-5, rtol=0)
     np.testing.assert_allclose(feat.reshape(256, -1)[:, idx[:256]].numpy(), g["feat_samples"], atol=2e-4, rtol=1e-4)
+
+
+def test_oracle_dpt_small_matches_reference_builders(golden_dir):
+    """BASELINE configs[0] shape (ViT-S/16, 224x224, batch 2): the dpt_small extension assembled by the reference's own
+    builders (_make_vit_b16_backbone / _make_scratch / _make_fusion_block) -- schema and sampled outputs"""
+    g = np.load(os.path.join(golden_dir, "fwd_dpt_small_224_sampled.npz"))
+    cfg = orc.CONFIGS["dpt_small"]
+    spec = orc.state_dict_spec(cfg)
+    ref_schema = [(l.split()[0], tuple(int(v) for v in l.split()[1:])) for l in open(os.path.join(golden_dir, "schema_dpt_small.txt"))]
+    assert [(k, tuple(v)) for k, v in spec.items()] == ref_schema
+    sd = {k: torch.from_numpy(hash_init(k, s, "dpt_small")) for k, s in spec.items()}
+    x = torch.from_numpy(synth.blob_images(2, 224, 224, seed=12))
+    with torch.no_grad():
+        out = orc.forward(sd, x, cfg)
+    idx = g["sample_idx"]
+    np.testing.assert_allclose(out["center_fields"].reshape(2, 2, -1)[:, :, idx].numpy(), g["center_samples"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out["sdf_maps"].reshape(2, 1, -1)[:, :, idx].numpy(), g["sdf_samples"], atol=5e-5, rtol=0)
+    np.testing.assert_allclose(out["center_fields"].mean(dim=(0, 2, 3)).numpy(), g["center_mean"], atol=2e-5, rtol=0)

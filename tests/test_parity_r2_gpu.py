@@ -131,6 +131,21 @@ def test_forward_fp32_full_size_matches_reference(golden_dir):
     np.testing.assert_allclose(sdf.abs().amax(dim=(1, 2)).numpy(), g["sdf_absmax"], atol=1e-4, rtol=0)
 
 
+def test_forward_fp32_cfg1_shape_matches_reference(golden_dir):
+    """BASELINE configs[0]: ViT-S/16 224x224 batch 2 forward, HIP fp32 vs the reference builders' outputs"""
+    g = np.load(os.path.join(golden_dir, "fwd_dpt_small_224_sampled.npz"))
+    net, _ = _net("dpt_small", tag="dpt_small", size=224)
+    net.eval()
+    x = torch.from_numpy(synth.blob_images(2, 224, 224, seed=12)).cuda()
+    with torch.no_grad():
+        out = net.get_prediction(x)
+    idx = g["sample_idx"]
+    np.testing.assert_allclose(out["center_fields"].reshape(2, 2, -1)[:, :, idx].cpu().numpy(), g["center_samples"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["sdf_maps"].reshape(2, 1, -1)[:, :, idx].cpu().numpy(), g["sdf_samples"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["center_fields"].abs().amax(dim=(0, 2, 3)).cpu().numpy(), g["center_absmax"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["sdf_maps"].mean(dim=(0, 2, 3)).cpu().numpy(), g["sdf_mean"], atol=1e-4, rtol=0)
+
+
 # ------------------------------------------------------------------------------------------------ gradients at benchmark width
 def test_backward_fp32_dpt_base_matches_oracle_autograd():
     """dpt_base (D=768, 12 blocks, F=[96,192,384,768]) 128x128 B=2, the 4-term loss with the documented flags, against the

@@ -408,6 +408,9 @@ def run_rank(a):
                                   "source_image": list(wl["image"]),
                                   "stages": "crop+resize, ObjectnessNet maps, centre peak picking, boundary box deltas"})
             res["est_minutes_for_5000_images"] = 5000.0 / res["value"] / 60.0
+            if a.sweep_streams > 1:
+                res["roofline"]["note"] = ("batches on different HIP streams share the chip: a conv launch is timed while kernels of the other "
+                                           "streams run beside it, so `achieved` is a lower bound of the kernel alone (--sweep-streams 1)")
             res["maps_with_peak"] = int((peaks[0] > 0).sum().item())
             res["config"]["streams"] = a.sweep_streams
         if world == 1 and kind == "sweep" and a.dtype == "bf16" and not a.no_alt:

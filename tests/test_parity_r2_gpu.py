@@ -217,6 +217,40 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     print("dpt_base fp32 gradients vs float64 VJP, worst over parameters: " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
 
 
+def test_backward_fp32_patch14_odd_grid_matches_oracle():
+    """BASELINE configs[3] wiring (dpt_large14: patch 14, pos grid 37, odd token grids -- fusion blocks resize to the skip's size,
+    final resize to the input size, all with non-2x bilinear adjoints) at 70x98 (grid 5x7): 4-term loss, every parameter gradient
+    vs the oracle's float64 autograd (relative L2 <= 5e-4 and max-norm <= 5e-3 * max|g| per tensor)."""
+    from unmore_amd.loss import objectness_loss
+    B, H, W = 1, 70, 98
+    net, sd = _net("dpt_large14", tag="dpt_large14", size=70)
+    net.train()
+    _, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(B, H, W, seed=8))
+    img = torch.from_numpy(synth.blob_images(B, H, W, seed=8))
+    sdo = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    loss_o, _ = orc.loss_terms(orc.forward(sdo, img.double(), orc.CONFIGS["dpt_large14"]), cf.double(), sdf.double(), sal.double())
+    loss_o.backward()
+    loss = objectness_loss(net(images=img.cuda()), cf.cuda(), sdf.cuda(), sal.cuda())
+    loss.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4
+    nograd = net.nograd_names()
+    worst = dict(l2=(0.0, ""), inf=(0.0, ""))
+    for n, p in net.named_parameters():
+        r = sdo[n].grad
+        if n in nograd:
+            assert p.grad is None and r is None, n
+            continue
+        g = p.grad.cpu().double()
+        l2 = ((g - r).norm() / (r.norm() + 1e-300)).item()
+        inf = (g - r).abs().max().item() / (r.abs().max().item() + 1e-300)
+        if l2 > worst["l2"][0]:
+            worst["l2"] = (l2, n)
+        if inf > worst["inf"][0]:
+            worst["inf"] = (inf, n)
+        assert l2 <= 5e-4 and inf <= 5e-3, (n, l2, inf)
+    print(f"dpt_large14 70x98 fp32 gradients vs float64: worst relative L2 {worst['l2'][0]:.2e} ({worst['l2'][1]}), worst max-norm {worst['inf'][0]:.2e} ({worst['inf'][1]})")
+
+
 def test_bf16_vs_fp32_hip_at_benchmark_shape():
     """dpt_base 384x384 B=4: 1024 tiles of 256 rows -> gemm_nt256p<conv / 1x1 / fused reduction>, gemm_tn256, merged dfeat GEMM.
     bf16 step vs fp32 step of the same HIP engine on the same weights and batch: loss within 2e-2, every parameter gradient

@@ -217,18 +217,19 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     print("dpt_base fp32 gradients vs float64 VJP, worst over parameters: " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
 
 
-def test_backward_fp32_patch14_odd_grid_matches_oracle():
-    """BASELINE configs[3] wiring (dpt_large14: patch 14, pos grid 37, odd token grids -- fusion blocks resize to the skip's size,
+@pytest.mark.parametrize("backbone,H,W", [("dpt_large14", 70, 98), ("dpt_large", 64, 96)])
+def test_backward_fp32_patch14_odd_grid_matches_oracle(backbone, H, W):
+    """dpt_large = the reference's only live backbone_type (ViT-L/16, objectness_net.py:62-73), at 64x96.  BASELINE configs[3] wiring (dpt_large14: patch 14, pos grid 37, odd token grids -- fusion blocks resize to the skip's size,
     final resize to the input size, all with non-2x bilinear adjoints) at 70x98 (grid 5x7): 4-term loss, every parameter gradient
     vs the oracle's float64 autograd (relative L2 <= 5e-4 and max-norm <= 5e-3 * max|g| per tensor)."""
     from unmore_amd.loss import objectness_loss
-    B, H, W = 1, 70, 98
-    net, sd = _net("dpt_large14", tag="dpt_large14", size=70)
+    B = 1
+    net, sd = _net(backbone, tag=backbone, size=H)
     net.train()
     _, cf, sdf, sal = (torch.from_numpy(a) for a in synth.make_batch(B, H, W, seed=8))
     img = torch.from_numpy(synth.blob_images(B, H, W, seed=8))
     sdo = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
-    loss_o, _ = orc.loss_terms(orc.forward(sdo, img.double(), orc.CONFIGS["dpt_large14"]), cf.double(), sdf.double(), sal.double())
+    loss_o, _ = orc.loss_terms(orc.forward(sdo, img.double(), orc.CONFIGS[backbone]), cf.double(), sdf.double(), sal.double())
     loss_o.backward()
     loss = objectness_loss(net(images=img.cuda()), cf.cuda(), sdf.cuda(), sal.cuda())
     loss.backward()
@@ -248,7 +249,7 @@ def test_backward_fp32_patch14_odd_grid_matches_oracle():
         if inf > worst["inf"][0]:
             worst["inf"] = (inf, n)
         assert l2 <= 5e-4 and inf <= 5e-3, (n, l2, inf)
-    print(f"dpt_large14 70x98 fp32 gradients vs float64: worst relative L2 {worst['l2'][0]:.2e} ({worst['l2'][1]}), worst max-norm {worst['inf'][0]:.2e} ({worst['inf'][1]})")
+    print(f"{backbone} {H}x{W} fp32 gradients vs float64: worst relative L2 {worst['l2'][0]:.2e} ({worst['l2'][1]}), worst max-norm {worst['inf'][0]:.2e} ({worst['inf'][1]})")
 
 
 def test_bf16_vs_fp32_hip_at_benchmark_shape():

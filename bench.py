@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement), including
 
 Workloads (BASELINE.json configs): cfg2 (default; configs[1], the one the metric is quoted on; configs[2] is the same at
 N = 8), cfg1 (configs[0]: ViT-S/16 224x224 batch 2 forward only), cfg4 (configs[3]: ViT-L/14 518x518 batch 16 train step),
+ref (the reference's own training recipe: dpt_large, 128x128, batch 20),
 cfg5 (configs[4]: the object_reasoning.py inference sweep -- per 640x480 image the 1,225 anchors of :109-137 as 128x128 crops in
 batches of 50 through crop+resize, the net, centre peak picking and boundary deltas; one step = one image), tiny (plumbing).
 `--rehearse` runs the multi-process plumbing alone on CPU tensors (rendezvous, barrier, bucketed all-reduce of a gradient
@@ -37,6 +38,8 @@ WORKLOADS = {
     "cfg4": dict(kind="train", backbone="dpt_large14", H=518, W=518, batch=16, name="ObjectnessNet ViT-L/14 518x518 bf16 batch=16 train"),
     "cfg5": dict(kind="sweep", backbone="dpt_base", H=128, W=128, batch=50, image=(480, 640), proposals=1225,
                  name="object_reasoning sweep: ViT-B/16 maps on 640x480 images, 1225 proposals/image as 128x128 crops in batches of 50"),
+    # the reference's own recipe (README.md:150-154, train_objectness_net.py:783-788,815-817): dpt_large, 128x128, batch 20
+    "ref": dict(kind="train", backbone="dpt_large", H=128, W=128, batch=20, name="ObjectnessNet ViT-L/16 (dpt_large) 128x128 bf16 batch=20 train (the reference's recipe)"),
     "tiny": dict(kind="train", backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
 }
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md

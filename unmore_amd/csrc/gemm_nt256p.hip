@@ -84,7 +84,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // barrier wait sits beside the other half's MFMAs.  Both halves read a phase's data in the same interval and issue the
     // same LDS-DMA groups in the same interval (the ahead half carries in its MFMA block the groups the other half issues
     // in the block it runs meanwhile), so LDS lifetimes, counted vmcnt waits and barrier counts are unchanged.
+#ifdef UMR_EXP_AHEAD_HI
+    const bool ahead = (stagger != 0) && (w >= 4);
+#else
     const bool ahead = (stagger != 0) && (w < 4);
+#endif
 
     // tile sequence of this workgroup: virtual ids pw, pw + G, pw + 2G, ...; workgroups of one XCD (blockIdx % 8)
     // own a contiguous run of G/8 ids per round, so neighbouring tiles share that XCD's L2
@@ -221,8 +225,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
     __builtin_amdgcn_sched_barrier(0);
 #define MFMA(ACC, BF, AF) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF, AF, ACC, 0, 0, 0)
+#ifndef UMR_EXP_PRIO_MODE
+#define UMR_EXP_PRIO_MODE 1
+#endif
+    // priority policy of the MFMA clusters: 0 = raise around every cluster (flips); 1 / 2 = static priority 1 for waves 4-7 /
+    // waves 0-3 and no flips; 3 = none.  Measured on the head conv (two-phase K-tile, same box, tools/probe/prio_ab.sh): 30.9 /
+    // 30.2 / 31.1 / 31.2 ms -- the guide's "static priority for the younger half" (Two waves per SIMD, item 4).  The four-phase
+    // plain GEMMs lose 4-10 % without the flips (their LDS-DMA pieces are issued inside the raised cluster) and keep them.
+    constexpr int PRIO_MODE = (CONV == 1) ? UMR_EXP_PRIO_MODE : 0;
+#define QPRIO(x) if (PRIO_MODE == 0) __builtin_amdgcn_s_setprio(x);
 #define QUADRANT_D(M0, N0, FB, DMA_A, DMA_B)                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                  \
+    QPRIO(1)                                                                                        \
     MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
     MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
     __builtin_amdgcn_sched_barrier(0);                                                              \
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
     MFMA(acc[M0 + 2][N0 + 0], FB[1][0], fa[1][2]); MFMA(acc[M0 + 2][N0 + 1], FB[1][1], fa[1][2]);   \
     MFMA(acc[M0 + 3][N0 + 0], FB[1][0], fa[1][3]); MFMA(acc[M0 + 3][N0 + 1], FB[1][1], fa[1][3]);   \
-    __builtin_amdgcn_s_setprio(0);
+    QPRIO(0)
 #define QUADRANT(M0, N0, FB, Gp) QUADRANT_D(M0, N0, FB, STAGE_DMA(Gp, 0), STAGE_DMA(Gp, 1))
 
 #define PHASE_SYNC() PHASE_SYNC_N(6)
@@ -379,6 +392,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         END_SYNC_N(6);
     };
 
+    if (PRIO_MODE == 1 && w >= 4) __builtin_amdgcn_s_setprio(1);
+    if (PRIO_MODE == 2 && w < 4) __builtin_amdgcn_s_setprio(1);
     // prologue: the six groups the steady-state schedule has already issued when the first K-tile starts
     stage_setup(0);
     stage_prep();

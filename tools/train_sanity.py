@@ -1,7 +1,9 @@
 """Does the bf16 throughput path TRAIN at benchmark scale?  cfg2 model (ViT-B/16 DPT, 384x384, batch 64), the documented loss
 flags, Adam 1e-4, N steps on a small pool of synthetic batches (images: structured blobs; labels: one ellipse each).  Prints the
 five loss values every 20 steps and checks that the total falls monotonically in 50-step averages and stays finite.
-    python tools/train_sanity.py [steps=200] [batches=4]"""
+    python tools/train_sanity.py [steps=200] [batches=4] [fp32_steps=0]
+With fp32_steps > 0 the first steps are repeated in fp32 parity mode from the same initial weights on the same batches and the two
+loss trajectories are compared (bf16 storage must track fp32 within a few 1e-3 per step)."""
 import os
 import sys
 import time
@@ -17,9 +19,11 @@ from unmore_amd.trainer import TrainStep
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n32 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = ObjectnessNet(dev, 384, "dpt_base", Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
+init = {k: v.detach().clone() for k, v in net.state_dict().items()}
 net.set_compute_dtype(torch.bfloat16)
 net.train()
 step = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
@@ -43,3 +47,17 @@ assert torch.isfinite(tot).all(), "non-finite loss"
 avg = [tot[i:i + 50].mean().item() for i in range(0, steps - 49, 50)]
 print("50-step averages of the total loss:", [round(a, 4) for a in avg], f"| {steps * 64 / dt:.1f} images/s incl. per-step host work")
 assert all(b < a for a, b in zip(avg, avg[1:])), "loss does not fall"
+
+if n32 > 0:
+    del step
+    net32 = ObjectnessNet(dev, 384, "dpt_base", Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
+    net32.load_state_dict(init, strict=True)
+    net32.set_compute_dtype(torch.float32)
+    net32.train()
+    step32 = TrainStep(net32, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
+    h32 = [step32.step(*pool[it % nb]) for it in range(n32)]
+    t32 = torch.stack(h32)[:, 0].cpu()
+    d = (tot[:n32] - t32).abs()
+    print(f"first {n32} steps, bf16 vs fp32 total loss: max |diff| {d.max().item():.2e}; fp32 {[round(v, 4) for v in t32.tolist()]}")
+    print(f"                                         bf16 {[round(v, 4) for v in tot[:n32].tolist()]}")
+    assert d.max().item() < 2e-2

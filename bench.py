@@ -476,10 +476,11 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks):
     """Multi-process plumbing alone (CPU tensors): what bench.py does around the model for N > 1."""
     import torch
     import torch.distributed as dist
-    from oracle import objectness_oracle as orc   # shapes only (the gradient buffer's size); nothing is computed with it
+    from argparse import Namespace
+    from unmore_amd.objectness_net import ObjectnessNet
     from unmore_amd.parallel import BucketedAllReduce
-    import numpy as np
-    n = sum(int(np.prod(s)) for s in orc.state_dict_spec(orc.CONFIGS[wl["backbone"]]).values())
+    # the gradient buffer's size: parameters of the workload's model (the module only HOLDS parameters; nothing is computed)
+    n = sum(p.numel() for p in ObjectnessNet("cpu", wl["H"], wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")).parameters())
     flat = torch.full((n,), float(rank + 1))
     nb = 8
     bounds = [n * i // nb for i in range(nb + 1)]

@@ -429,6 +429,18 @@ def run_rank(a):
             net.set_compute_dtype(dt)
             res["alt_fp32_parity_mode"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
                                            "note": "fp32 storage and exact-fp32 MFMA: the 1e-4 / bit-exact-peaks mode"}
+            # and with the opt-in collapsed forward of the boundary-distance head (one 3x3 conv 256 -> 1)
+            net.set_sdf_head_mode("collapsed")
+            one()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                one()
+            torch.cuda.synchronize()
+            dt3 = (time.perf_counter() - t1) / 2
+            net.set_sdf_head_mode("factored")
+            res["alt_collapsed_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
+                                             "note": "opt-in algebraic fast path; not the headline configuration"}
         if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
             # algebraic form of the linear boundary-distance head (identical function and gradients

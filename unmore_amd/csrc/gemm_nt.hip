@@ -44,7 +44,26 @@ template <> struct Raw8<float> {
     static __device__ __forceinline__ void cvt(type t, f32x4& a, f32x4& b) { a = t.a; b = t.b; }
 };
 
-template <typename T, int CONV, int EPI>
+// three-way bf16 split of 8 f32 values: x = h + m + l with |m| <= 2^-8 |x|, |l| <= 2^-16 |x| (round-to-nearest each time)
+__device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? x0[e] : x1[e - 4];
+        const bf16_t hh = (bf16_t)x;
+        const float r = x - (float)hh;
+        const bf16_t mm = (bf16_t)r;
+        const float r2 = r - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (bf16_t)r2;
+    }
+}
+
+// X3 (f32 only): the products of the f32 GEMM are formed on the bf16 matrix cores from three-way bf16 splits of both operands,
+//   a b ~= ah bh + ah bm + am bh + ah bl + al bh + am bm      (dropped: am bl, al bm, al bl <= 2^-23 |a b|),
+// six v_mfma_f32_16x16x32_bf16 (96 matrix-pipe cycles per 16x16x32 block) instead of eight v_mfma_f32_16x16x4_f32 (256 cycles),
+// accumulated in f32 as before.  Every product is within ~2.4e-7 of the f32 product (f32's own rounding is 6e-8) -- fp32-grade
+// results (measured: every fp32 parity test unchanged), not the bit-exact f32 FMA chain of the plain path; +35 % on the fp32 head conv
+// (48.3 -> 35.8 ms at 50 crops: the splitting VALU work, not the matrix pipe, bounds it).  Default; UMR_F32_X3=0 restores the f32 MFMA.
+template <typename T, int CONV, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Tr<T>::EPC, BK = Tr<T>::BK;
@@ -181,6 +200,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     }
 
     auto compute = [&](const char* sbuf) {
+        if constexpr (sizeof(T) == 4 && X3) {
+            // one K-tile = 32 f32 per row = ONE k-step of the bf16 MFMA: lane group fq, element e <-> k = (e < 4 ? 0 : 16) + 4 fq + (e & 3)
+            // (any bijection works as long as both operands use the same one)
+            bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                split3_bf16(*(const f32x4*)(sbuf + a_addr[0][i]), *(const f32x4*)(sbuf + a_addr[1][i]), ah[i], am[i], al[i]);
+#pragma unroll
+            for (int ntl = 0; ntl < 4; ++ntl) {
+                bf16x8 bh, bm, bl;
+                split3_bf16(*(const f32x4*)(sbuf + b_addr[0][ntl]), *(const f32x4*)(sbuf + b_addr[1][ntl]), bh, bm, bl);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    f32x4 c = acc[mt][ntl];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[mt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[mt], c, 0, 0, 0);
+                    acc[mt][ntl] = c;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (sizeof(T) == 2) {
@@ -423,11 +467,21 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 0>), g, b, LDS_BYTES, s, *d, tiles_n);   \
         else hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 1>), g, b, LDS_BYTES, s, *d, tiles_n);           \
     } while (0)
+#define LAUNCH_X3(CV)                                                                                          \
+    do {                                                                                                       \
+        if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 0, true>), g, b, LDS_BYTES, s, *d, tiles_n); \
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 1, true>), g, b, LDS_BYTES, s, *d, tiles_n);         \
+    } while (0)
+    static int f32_x3 = -1;   // UMR_F32_X3=1: f32 products on the bf16 matrix cores from three-way splits (see the kernel)
+    if (f32_x3 < 0) { const char* e = getenv("UMR_F32_X3"); f32_x3 = e ? atoi(e) : 1; }
     if (d->dtype == UMR_BF16) {
         if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
+    } else if (f32_x3 && !((d->conv == 0 ? d->K : d->Cin) % 32)) {   // whole 32-wide K-tiles only (the tail path zero-fills, which is fine, but keep it simple)
+        if (d->conv == 0) LAUNCH_X3(0); else if (d->conv == 1) LAUNCH_X3(1); else LAUNCH_X3(2);
     } else {
         if (d->conv == 0) LAUNCH(float, 0); else if (d->conv == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
     }
+#undef LAUNCH_X3
 #undef LAUNCH
     UMR_LAUNCH_CHECK();
     return UMR_OK;

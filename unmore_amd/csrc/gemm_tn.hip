@@ -28,7 +28,18 @@ template <> struct TnTr<float> { static constexpr int ROWS = 32, ROWB = 512, RPI
 
 __device__ __forceinline__ int tn_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-template <typename T, int CONV>
+// three-way bf16 split of 8 f32 values (see gemm_nt.hip: f32 products on the bf16 matrix cores)
+__device__ __forceinline__ void tn_split3(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t hh = (bf16_t)x[e];
+        const float r = x[e] - (float)hh;
+        const bf16_t mm = (bf16_t)r;
+        h[e] = hh; m[e] = mm; l[e] = (bf16_t)(r - (float)mm);
+    }
+}
+
+template <typename T, int CONV, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc p, int tiles_k, int rows_per_split,
                                                          float* slab, float* bslab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -270,6 +281,47 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const umr_gemm_tn_desc 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             mfmas(std::integral_constant<int, 1>{});
+        } else if constexpr (X3) {
+            // f32 operands, products on the bf16 matrix cores (three-way splits, six MFMAs per block: gemm_nt.hip).  The 32 rows
+            // of a stage are ONE k-step: lane group g, element e <-> stage row 8 g + e, the same map for both operands.
+            bf16x8 ah[4], am[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = *(const float*)(sA + (g * 8 + e) * ROWB + (wn * 64 + i * 16 + li) * 4);
+                tn_split3(v, ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = *(const float*)(sB + (g * 8 + e) * ROWB + (wk * 64 + kt * 16 + li) * 4);
+                bf16x8 bh, bm, bl;
+                tn_split3(v, bh, bm, bl);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 c = acc[nt][kt];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am[nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah[nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am[nt], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[nt], c, 0, 0, 0);
+                    acc[nt][kt] = c;
+                }
+            }
+            if (do_bias) {
+                bf16x8 ones;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, al[nt], accb[nt], 0, 0, 0);
+                    accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, am[nt], accb[nt], 0, 0, 0);
+                    accb[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, ah[nt], accb[nt], 0, 0, 0);
+                }
+            }
         } else {
 #pragma unroll
             for (int ks = 0; ks < ROWS / 4; ++ks) {
@@ -452,11 +504,17 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     } else {
     dim3 g((unsigned)(pl.tiles_n * pl.tiles_k), (unsigned)pl.splits), b(256);
 #define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_tn_kernel<T, CV>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
+#define LAUNCH_X3(CV) hipLaunchKernelGGL((gemm_tn_kernel<float, CV, true>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
+    static int f32_x3 = -1;   // as in gemm_nt.hip
+    if (f32_x3 < 0) { const char* e = getenv("UMR_F32_X3"); f32_x3 = e ? atoi(e) : 1; }
     if (d->dtype == UMR_BF16) {
         if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
+    } else if (f32_x3) {
+        if (d->conv == 0) LAUNCH_X3(0); else if (d->conv == 1) LAUNCH_X3(1); else LAUNCH_X3(2);
     } else {
         if (d->conv == 0) LAUNCH(float, 0); else if (d->conv == 1) LAUNCH(float, 1); else LAUNCH(float, 2);
     }
+#undef LAUNCH_X3
 #undef LAUNCH
     UMR_LAUNCH_CHECK();
     }

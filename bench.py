@@ -309,11 +309,11 @@ def run_rank(a):
     net.set_compute_dtype(dt)
     M_head = B * H * W
 
-    # dominant kernel: 3x3 conv 512->512 over all pixels of the batch (heads; train: 2 forward + 2 data-gradient launches / step)
+    # dominant kernel: 3x3 conv 512->512 over all pixels of the batch (heads; train: 2 forward launches + the centre head's
+    # data-gradient launch per step -- the boundary-distance head's backward is algebraic; the weight gradient is the TN kernel)
     def is_head_conv(d):
         return d.conv == 1 and d.Cin == 512 and d.N == 512 and d.M == M_head
 
-    extra = {}
     if kind == "train":
         net.train()
         step = TrainStep(net, lr=1e-4, center_field_loss_type="l2", sdf_loss_type="l1", use_sdf_gradient_loss=True,

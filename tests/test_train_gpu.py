@@ -347,3 +347,17 @@ def test_checkpoint_resume_matches_uninterrupted_run_and_torch_adam_format():
     sb.step(*batches[2])
     for (n, p), (_, q) in zip(a.named_parameters(), b_.named_parameters()):
         assert torch.equal(p, q), n
+
+
+def test_empty_batch_is_handled():
+    """the batch filter can leave nothing (train_objectness_net.py:190-207): forward returns empty maps like the reference's
+    convolutions do; the native step refuses instead of feeding NaN means to Adam"""
+    from unmore_amd.trainer import TrainStep
+    net, _ = _net("dpt_tiny", "tiny")
+    x = torch.zeros((0, 3, 64, 64), device="cuda:0")
+    with torch.no_grad():
+        out = net.get_prediction(x)
+    assert out["center_fields"].shape == (0, 2, 64, 64) and out["sdf_maps"].shape == (0, 1, 64, 64)
+    step = TrainStep(net)
+    with pytest.raises(ValueError, match="empty batch"):
+        step.step(x, torch.zeros((0, 2, 64, 64), device="cuda:0"), torch.zeros((0, 1, 64, 64), device="cuda:0"), torch.zeros((0, 1, 64, 64), device="cuda:0"))

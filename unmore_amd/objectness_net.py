@@ -250,6 +250,11 @@ class ObjectnessNet(nn.Module):
         if not images.is_cuda:
             raise RuntimeError("unmore_amd.ObjectnessNet runs on the MI355X only (no CPU fallback); move the model and inputs to the GPU")
         in_dtype = images.dtype
+        if images.shape[0] == 0:
+            # an empty batch (the train loop's filter can drop every image, train_objectness_net.py:190-207): the reference's convs
+            # return empty maps; so do we, without a launch
+            B0, _, H0, W0 = images.shape
+            return {"center_fields": images.new_zeros((0, 2, H0, W0)), "sdf_maps": images.new_zeros((0, 1, H0, W0))}
         x = images.float()
         named = list(self.named_parameters())
         names = tuple(n for n, _ in named)

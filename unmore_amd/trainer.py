@@ -92,6 +92,9 @@ class TrainStep:
 
     def step(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
         """One optimisation step; returns the [total, center, sdf, grad, bce] loss tensor (device, f32)."""
+        if images.shape[0] == 0:
+            # the reference would take the mean of empty maps (NaN) and push NaN gradients into Adam; refuse instead
+            raise ValueError("TrainStep.step: empty batch (every image was filtered out); skip this iteration")
         eng = self.net._engine()
         center, sdf, S = eng.forward(self.P, images, save=True)
         out5, dpc, dps = ops.objectness_loss(center, sdf, gt_center_fields, gt_sdf_maps, gt_saliency_maps, *self.loss_cfg)

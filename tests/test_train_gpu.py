@@ -202,7 +202,7 @@ def test_collapsed_sdf_head_equals_factored(dtype, H, W):
         assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.99
 
 
-@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64), (torch.float32, 32, 48), (torch.float32, 96, 160)])
+@pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64), (torch.float32, 64, 32), (torch.float32, 96, 160)])
 def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
     """Default training path: the boundary-distance head's forward runs its four convolutions (identical outputs), its backward
     takes the exact gradients of all eight factored tensors from three pixel reductions instead of layer-by-layer GEMMs
@@ -361,3 +361,21 @@ def test_empty_batch_is_handled():
     step = TrainStep(net)
     with pytest.raises(ValueError, match="empty batch"):
         step.step(x, torch.zeros((0, 2, 64, 64), device="cuda:0"), torch.zeros((0, 1, 64, 64), device="cuda:0"), torch.zeros((0, 1, 64, 64), device="cuda:0"))
+
+
+def test_sizes_that_are_not_multiples_of_the_patch_follow_the_reference():
+    """100x100 with patch 16: the token grid is 6x6 (the remainder is ignored by the strided patch conv, vit.py:179) and every
+    upsampling is exactly x2 (blocks.py:377-379, models.py:70-72), so the maps are 96x96 -- as the reference's.  An odd grid
+    (48x48 -> 3x3) cannot pass the skip addition (blocks.py:372) and raises there too."""
+    net, sd = _net("dpt_tiny", "tiny")
+    net.eval()
+    x = torch.from_numpy(uniform01("img:odd100", (1, 3, 100, 100)))
+    with torch.no_grad():
+        out = net(images=x.cuda())
+        ref = orc.forward(sd, x, orc.CONFIGS["dpt_tiny"])
+    assert ref["sdf_maps"].shape == (1, 1, 96, 96) and out["sdf_maps"].shape == (1, 1, 96, 96)
+    for k in ("center_fields", "sdf_maps"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=1e-4, rtol=0)
+    with pytest.raises((AssertionError, RuntimeError)):
+        with torch.no_grad():
+            net(images=torch.zeros(1, 3, 48, 48, device="cuda:0"))

@@ -333,10 +333,12 @@ class Engine:
                              self._f32(P, r_ + "resConfUnit2.conv1.bias"), conv=1, act=L.ACT_RELU).view_as(x1_)
             u = ops.gemm_nt(t2, self._w(P, r_ + "resConfUnit2.conv2.weight", "c3"),
                             self._f32(P, r_ + "resConfUnit2.conv2.bias"), conv=1, aux=s_).view_as(x1_)
-            if k > 1:
+            if k > 1 and cfg["patch"] != 16:
                 nxt = rn[k - 2].shape
-                Ho, Wo = nxt[1], nxt[2]  # == 2x for the reference's patch-16 configs
+                Ho, Wo = nxt[1], nxt[2]  # patch-14 extension: resize to the next skip's size
             else:
+                # the reference's wiring: exactly x2 (blocks.py:377-379); a token grid that does not survive the stride-2 conv and
+                # the doublings (e.g. an odd grid) then fails at the skip addition, as the reference does (blocks.py:372)
                 Ho, Wo = 2 * hh, 2 * ww
             up = ops.bilinear_fwd(u, Ho, Wo, True)
             path = ops.gemm_nt(up.view(-1, 256), self._w(P, r_ + "out_conv.weight", "lin"), self._f32(P, r_ + "out_conv.bias"))
@@ -344,7 +346,13 @@ class Engine:
             if save:
                 fs.update(s_relu=s_relu, t2=t2, up=up, in_hw=(hh, ww))
                 fus_saved[k] = fs
-        feat = ops.bilinear_fwd(path, H, W, True)  # models.py:70-72 (x2; == input size for patch 16)
+        if cfg["patch"] == 16:
+            # models.py:70-72: Interpolate(scale_factor=2) -- the maps have 32 * (grid // 2 ...) = 16 * grid pixels per side, which is
+            # the input size whenever that is a multiple of 16 (every documented use); otherwise smaller, exactly as in the reference
+            H, W = 2 * path.shape[1], 2 * path.shape[2]
+            if save:
+                S["H"], S["W"] = H, W
+        feat = ops.bilinear_fwd(path, H, W, True)
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers

@@ -1,6 +1,7 @@
 """Does the bf16 throughput path TRAIN at benchmark scale?  cfg2 model (ViT-B/16 DPT, 384x384, batch 64), the documented loss
 flags, Adam 1e-4, N steps on a small pool of synthetic batches (images: structured blobs; labels: one ellipse each).  Prints the
-five loss values every 20 steps and checks that the total falls monotonically in 50-step averages and stays finite.
+five loss values and the allocator's current / peak bytes every 20 steps and checks that the total falls in 50-step averages (no
+rise above 2 %) and stays finite.
     python tools/train_sanity.py [steps=200] [batches=4] [fp32_steps=0]
 With fp32_steps > 0 the first steps are repeated in fp32 parity mode from the same initial weights on the same batches and the two
 loss trajectories are compared (bf16 storage must track fp32 within a few 1e-3 per step)."""
@@ -39,14 +40,15 @@ for it in range(steps):
     hist.append(out5)
     if (it + 1) % 20 == 0:
         v = out5.cpu().tolist()
-        print(f"step {it + 1:4d}  total {v[0]:.4f}  center {v[1]:.4f}  sdf {v[2]:.4f}  sdf-grad {v[3]:.4f}  bce {v[4]:.4f}", flush=True)
+        print(f"step {it + 1:4d}  total {v[0]:.4f}  center {v[1]:.4f}  sdf {v[2]:.4f}  sdf-grad {v[3]:.4f}  bce {v[4]:.4f}  "
+              f"| allocated {torch.cuda.memory_allocated() / 2 ** 30:.2f} GiB, peak {torch.cuda.max_memory_allocated() / 2 ** 30:.2f} GiB", flush=True)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 tot = torch.stack(hist)[:, 0].cpu()
 assert torch.isfinite(tot).all(), "non-finite loss"
 avg = [tot[i:i + 50].mean().item() for i in range(0, steps - 49, 50)]
 print("50-step averages of the total loss:", [round(a, 4) for a in avg], f"| {steps * 64 / dt:.1f} images/s incl. per-step host work")
-assert all(b < a for a, b in zip(avg, avg[1:])), "loss does not fall"
+assert avg[-1] < avg[0] and all(b < 1.02 * a for a, b in zip(avg, avg[1:])), "loss does not fall"
 
 if n32 > 0:
     del step

@@ -36,7 +36,8 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device):
-    key = (device.index,)
+    # one scratch buffer per (device, stream): kernels of different streams may run concurrently (reasoning.sweep_proposals)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

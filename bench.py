@@ -208,35 +208,92 @@ def _free_port():
     return p
 
 
-def spawn_ranks(n):
-    """`python bench.py --gpus N` called plainly: this parent has not touched the GPU (no torch import yet); it starts N fresh
-    rank processes of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, passes rank 0's JSON line through
-    and exits with the ranks' status.  No exec of anything from a GPU-initialised process."""
+def _tail(path, nbytes=4000):
+    try:
+        with open(path, "rb") as f:
+            f.seek(0, 2)
+            size = f.tell()
+            f.seek(max(0, size - nbytes))
+            return f.read().decode(errors="replace")
+    except OSError:
+        return ""
+
+
+def spawn_ranks(n, timeout_s):
+    """`python bench.py --gpus N` called plainly: this parent has not touched the GPU (no torch import); it starts N fresh rank
+    processes of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, passes rank 0's JSON line through and
+    exits with the ranks' status.  No exec of anything from a GPU-initialised process.
+
+    The parent never blocks on one child: it polls all of them.  The first rank that exits non-zero (RCCL init failure, OOM,
+    an assert) ends the run within seconds -- the ranks this parent started are terminated (they would otherwise sit in a
+    collective / the rendezvous until someone kills them), the failing rank's stderr tail is printed and the parent exits with
+    that rank's status.  An overall deadline counted from the launch does the same for a hang (exit status 124).  Rank 0's
+    stderr is passed through live; every other rank's stderr is kept in a file whose path is printed on failure."""
+    import tempfile
+    import threading
     env0 = dict(os.environ)
     env0.setdefault("MASTER_ADDR", "127.0.0.1")
     env0["MASTER_PORT"] = env0.get("MASTER_PORT") or str(_free_port())
     env0["WORLD_SIZE"] = str(n)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env0.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
-    procs = []
+    logdir = tempfile.mkdtemp(prefix="umr_bench_ranks_")
+    t_start = time.time()
+    procs, errfiles = [], []
     for r in range(n):
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        ef = open(os.path.join(logdir, f"rank{r}.stderr"), "wb") if r else None
+        errfiles.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
-    out0 = procs[0].stdout.read().decode()
-    rc = 0
-    deadline = time.time() + 120
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()   # exactly the child we started
-            code = -9
-        rc = rc or code
-    # exactly what rank 0 reported goes to stdout: its JSON line; anything a library printed beside it goes to stderr
-    for line in out0.splitlines():
-        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL), stderr=ef))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # never blocks the poll loop
+    reader.start()
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()   # exactly the children this parent started
+        t_kill = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    rc, why = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            r, c = bad[0]
+            rc, why = (c if c > 0 else 128 - c), f"rank {r} exited with status {c}"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t_start > timeout_s:
+            running = [r for r, c in enumerate(codes) if c is None]
+            rc, why = 124, f"deadline of {timeout_s:.0f} s passed with ranks {running} still running"
+            break
+        time.sleep(0.1)
+    if why is not None:
+        stop_all()
+        sys.stderr.write(f"[bench] FAILED: {why}; the other ranks were terminated ({time.time() - t_start:.1f} s after launch)\n")
+        for r in range(1, n):
+            tail = _tail(os.path.join(logdir, f"rank{r}.stderr"))
+            if tail.strip():
+                sys.stderr.write(f"[bench] ---- rank {r} stderr (tail; full text: {logdir}/rank{r}.stderr)\n{tail}\n")
+    reader.join(timeout=5.0)
+    for ef in errfiles:
+        if ef is not None:
+            ef.close()
+    # exactly what rank 0 reported goes to stdout: its JSON line; anything a library printed beside it goes to stderr.  After a
+    # failure nothing goes to stdout: a line from a run whose ranks did not all finish is not a result.
+    for line in (out0[0].decode(errors="replace") if out0 else "").splitlines():
+        (sys.stdout if (line.startswith("{") and why is None) else sys.stderr).write(line + "\n")
     sys.stdout.flush()
+    sys.stderr.flush()
     return rc
 
 
@@ -251,6 +308,10 @@ def run_rank(a):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if a.fail_rank is not None and rank == a.fail_rank:
+        # launcher test hook: this rank dies before the rendezvous, the others are left waiting in it
+        print(f"[bench] rank {rank}: --fail-rank requested, exiting with status 3", file=sys.stderr, flush=True)
+        sys.exit(3)
     wl = WORKLOADS[a.workload]
     if a.rehearse:
         dev = torch.device("cpu")
@@ -290,8 +351,17 @@ def run_rank(a):
             return float(t.item())
         return x
 
+    def gather_over_ranks(x):
+        """every rank's own figure, in rank order (for the per-rank rates in the line)"""
+        if world > 1:
+            t = torch.zeros(world, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            t[rank] = x
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return [float(v) for v in t.tolist()]
+        return [x]
+
     if a.rehearse:
-        return rehearse(a, wl, world, rank, coll, barrier, max_over_ranks)
+        return rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_ranks)
 
     from unmore_amd import ops, reasoning, synth
     from unmore_amd.engine import CONFIGS
@@ -364,6 +434,7 @@ def run_rank(a):
     elapsed = time.perf_counter() - t0
     conv_ms = ops.kernel_timer_results_ms()
     ops.set_kernel_timer(None)
+    own = gather_over_ranks(elapsed)
     elapsed = max_over_ranks(elapsed)
 
     if rank == 0:
@@ -392,6 +463,7 @@ def run_rank(a):
             "config": {"workload": name, "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
                        "parallelism": (f"dp{world}" if kind == "train" else f"replicas x{world}")},
             "collective": coll,
+            "per_rank_images_per_sec": [units_per_step * a.steps / t for t in own],   # each rank's own clock between the barriers
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             "roofline": {"bound": "mfma", "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 (heads" + (", fwd+dgrad)" if kind == "train" else ", fwd)")
                                                      + (" bf16" if a.dtype == "bf16" else " f32")),
@@ -484,7 +556,7 @@ def run_rank(a):
     return 0
 
 
-def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks):
+def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_ranks):
     """Multi-process plumbing alone (CPU tensors): what bench.py does around the model for N > 1."""
     import torch
     import torch.distributed as dist
@@ -509,13 +581,14 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks):
             comm.ready(k)
         scale = comm.finish()
     barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    own = gather_over_ranks(time.perf_counter() - t0)
+    elapsed = max_over_ranks(own[rank] if world > 1 else own[0])
     expect = float(sum(range(1, world + 1))) * (world ** (a.steps - 1))
     ok = bool(torch.all(flat == expect)) and scale == 1.0 / world
     if rank == 0:
         print(json.dumps({"rehearsal": True, "metric": "distributed plumbing only (no model)", "value": None, "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "collective": coll, "allreduce_elements": n,
-                          "allreduce_correct": ok, "config": {"workload": wl["name"], "parallelism": f"dp{world}"}}), flush=True)
+                          "allreduce_correct": ok, "per_rank_ms_per_step": [1e3 * t / a.steps for t in own], "config": {"workload": wl["name"], "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -533,11 +606,13 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo = rehearsal transport (ranks may share a GPU)")
     ap.add_argument("--rehearse", action="store_true", help="CPU-only: run the multi-process plumbing without the model")
     ap.add_argument("--sweep-streams", type=int, default=3, help="cfg5: HIP streams the independent 50-crop batches are dealt to")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="plain --gpus N launch: overall deadline in seconds, counted from the launch")
+    ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # launcher test hook
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(a.gpus)
+        return spawn_ranks(a.gpus, a.launch_timeout)
     return run_rank(a)
 
 

@@ -25,6 +25,20 @@ enum umr_dtype { UMR_F32 = 0, UMR_BF16 = 1 };
 int umr_version(void);
 const char* umr_last_error_string(void);
 
+/* ---- how UMR_F32 GEMMs (umr_gemm_nt / umr_gemm_tn with dtype UMR_F32; the reference computes in fp32,
+ * object_reasoning.py:74) form their products.  Process-wide, may be changed between launches (not per stream).
+ *   UMR_F32_EXACT: v_mfma_f32_*_f32 -- IEEE f32 multiply-adds; inf / NaN / denormal operands behave as in an f32 FMA chain.
+ *   UMR_F32_X3 (default; env UMR_F32_X3=0 selects EXACT at load): every operand is split into three bf16 terms x = h + m + l
+ *     and a product is six bf16 MFMAs accumulated in f32 (hh + hm + mh + hl + lh + mm; the dropped terms are <= 2^-26 of the
+ *     product).  fp32-GRADE, not bit-identical to an f32 FMA chain: rms error vs float64 equals the f32 MFMA's for FINITE
+ *     operands with 2^-100 < |x| < 2^126.  Outside that range it is NOT IEEE: an inf operand gives NaN (inf - inf in the split),
+ *     |x| within 2^-8 of FLT_MAX rounds its leading term to inf -> NaN, and the m / l terms of |x| < 2^-110 underflow in
+ *     bf16 (the product then keeps only 8 / 16 significant bits -- of a value that is itself ~1e-33).  A NaN operand gives NaN
+ *     in both modes.  tests/test_gemm_gpu.py::test_f32_x3_* pins this behaviour. */
+enum umr_f32_mode { UMR_F32_EXACT = 0, UMR_F32_X3 = 1 };
+int umr_set_f32_mode(int mode);   /* returns UMR_OK or UMR_ERR_INVALID */
+int umr_get_f32_mode(void);
+
 /* ---- GEMM "NT" with implicit 3x3 convolution and fused epilogue ------------
  * C[M,N] = epi(A[M,K] . B[N,K]^T), fp32 accumulate on MFMA.
  * Replaces torch.nn.Linear / 1x1 nn.Conv2d (models/dpt/vit.py:84,263-327,

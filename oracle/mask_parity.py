@@ -1,0 +1,53 @@
+"""CPU ORACLE SUPPORT -- TEST INFRASTRUCTURE ONLY (imported by tests/ and __graft_entry__.smoke(), never by unmore_amd/).
+
+Gradient parity on the same linear piece.  The network is piecewise linear in its ReLUs (blocks.py:290-313 RCUs, the
+centre head objectness_net.py:109-117); where a pre-activation is within rounding of zero, fp32 and float64 (and two fp32
+implementations) decide the mask differently and single gradient elements move by ~1e-3 -- noise of the function's kinks,
+not of the backward kernels.  `hip_relu_masks` reads the decisions the HIP path actually took (its saved post-ReLU
+activations) and `masked_forward` runs the float64 oracle with exactly those decisions imposed, so that the oracle's
+vector-Jacobian product is the exact gradient of what the HIP backward differentiates."""
+import torch
+
+from . import objectness_oracle as orc
+
+
+def _nchw_mask(t, B, H, W):
+    return (t.reshape(B, H, W, -1) > 0).permute(0, 3, 1, 2).cpu()
+
+
+def hip_relu_masks(S, head_layouts):
+    """S: the saved-activation dict of unmore_amd.engine.Engine.forward(save=True), BEFORE backward consumes it.
+    head_layouts: (centre, sdf) layout dicts (Engine.center_layout / .sdf_layout; `relu` says whether the head has ReLUs).
+    Returns {site name (oracle.objectness_oracle ReLU sites): bool NCHW mask on the CPU}."""
+    B, H, W = S["B"], S["H"], S["W"]
+    masks = {}
+    for k, fs in S["fus"].items():
+        r = f"backbone.scratch.refinenet{k}."
+        hh, ww = fs["in_hw"]
+        masks[r + "resConfUnit2.relu_in"] = _nchw_mask(fs["s_relu"], B, hh, ww)
+        masks[r + "resConfUnit2.relu_mid"] = _nchw_mask(fs["t2"], B, hh, ww)
+        if "t1" in fs:
+            masks[r + "resConfUnit1.relu_in"] = _nchw_mask(fs["x1_relu"], B, hh, ww)
+            masks[r + "resConfUnit1.relu_mid"] = _nchw_mask(fs["t1"], B, hh, ww)
+    for hs, lay, name in zip(S["heads"], head_layouts, ("center_field_prediction_head", "sdf_prediction_head")):
+        if lay["relu"]:
+            for i, key in enumerate(("h1", "h2", "h3")):
+                masks[f"{name}.relu{i}"] = _nchw_mask(hs[key], B, H, W)
+    return masks
+
+
+def masked_forward(sd, images, cfg, masks, **kw):
+    """orc.forward with the given ReLU decisions imposed (relu(x) := x * mask); returns (out dict, {site: number of elements
+    where the oracle's own decision x > 0 differs from the imposed one})."""
+    flips = {}
+
+    def hook(x, site):
+        m = masks[site]
+        assert m.shape == x.shape, (site, tuple(m.shape), tuple(x.shape))
+        flips[site] = int(((x.detach() > 0) != m).sum())
+        return x * m.to(x.dtype)
+
+    with orc.relu_hook(hook):
+        out = orc.forward(sd, images, cfg, **kw)
+    assert set(flips) == set(masks), (sorted(set(masks) ^ set(flips)))
+    return out, flips

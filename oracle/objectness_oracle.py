@@ -235,11 +235,35 @@ def reassemble(sd, acts, cfg, h, w, inter=None):
     return outs
 
 
+# ---- ReLU sites.  Every ReLU of the path has a name (RCU: "<refinenetK.resConfUnitJ.>relu_in" / "relu_mid"; heads:
+# "<head>.relu0..2").  Tests can run the oracle with the DECISIONS of another implementation imposed at every site
+# (`with relu_hook(fn)`: fn(x, site) replaces F.relu) -- the network then is the same piecewise-linear function on the same
+# piece, and gradients can be compared without the noise of masks decided differently within rounding of zero.
+_RELU_HOOK = None
+
+
+class relu_hook:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _RELU_HOOK
+        self.prev, _RELU_HOOK = _RELU_HOOK, self.fn
+
+    def __exit__(self, *exc):
+        global _RELU_HOOK
+        _RELU_HOOK = self.prev
+
+
+def _relu(x, site):
+    return F.relu(x) if _RELU_HOOK is None else _RELU_HOOK(x, site)
+
+
 def rcu(x, sd, r):
     """models/dpt/blocks.py:290-313 (bn=False, ReLU out of place)."""
-    out = F.relu(x)
+    out = _relu(x, r + "relu_in")
     out = F.conv2d(out, sd[r + "conv1.weight"], sd[r + "conv1.bias"], padding=1)
-    out = F.relu(out)
+    out = _relu(out, r + "relu_mid")
     out = F.conv2d(out, sd[r + "conv2.weight"], sd[r + "conv2.bias"], padding=1)
     return out + x
 
@@ -291,13 +315,13 @@ def head_forward(sd, name, feat, layout):
     idx = layout["conv_idx"]
     y = F.conv2d(feat, sd[f"{name}.{idx[0]}.weight"], sd[f"{name}.{idx[0]}.bias"])
     if layout["relu"]:
-        y = F.relu(y)
+        y = _relu(y, f"{name}.relu0")
     y = F.conv2d(y, sd[f"{name}.{idx[1]}.weight"], sd[f"{name}.{idx[1]}.bias"], padding=1)
     if layout["relu"]:
-        y = F.relu(y)
+        y = _relu(y, f"{name}.relu1")
     y = F.conv2d(y, sd[f"{name}.{idx[2]}.weight"], sd[f"{name}.{idx[2]}.bias"])
     if layout["relu"]:
-        y = F.relu(y)
+        y = _relu(y, f"{name}.relu2")
     y = F.conv2d(y, sd[f"{name}.{idx[3]}.weight"], sd[f"{name}.{idx[3]}.bias"])
     if layout["final"] == "tanh":
         y = torch.tanh(y)

@@ -4,6 +4,7 @@ environment.  `--rehearse` = the plumbing around the model only (rendezvous, bar
 timing); the model itself needs the MI355X (tests/test_bench_gpu.py)."""
 import json
 import os
+import time
 import socket
 import subprocess
 import sys
@@ -57,3 +58,31 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--backend", "gloo", "--workload", "tiny"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_a_dying_rank_ends_the_plain_launch_within_seconds():
+    """rank 1 exits before the rendezvous; rank 0 would wait in it for gloo's 30-minute timeout.  The parent must notice the
+    exit, terminate rank 0, print rank 1's stderr and return non-zero quickly, without a JSON line on stdout."""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rehearse", "--workload", "tiny", "--steps", "2",
+                        "--warmup", "1", "--fail-rank", "1"], env=_env(), capture_output=True, text=True, timeout=120)
+    dt = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert dt < 30, dt
+    assert "rank 1 exited with status 3" in r.stderr and "--fail-rank requested" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_dying_rank_zero_ends_the_plain_launch_too():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rehearse", "--workload", "tiny", "--steps", "2",
+                        "--warmup", "1", "--fail-rank", "0"], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "rank 0 exited with status 3" in r.stderr
+
+
+def test_a_hung_launch_hits_the_overall_deadline():
+    """a port nobody listens on for rank 1 is simulated by a tiny deadline: the parent kills what it started and exits 124"""
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rehearse", "--workload", "cfg2", "--steps", "2000",
+                        "--warmup", "1", "--launch-timeout", "3"], env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 40 and "deadline of 3 s passed" in r.stderr

@@ -299,3 +299,87 @@ def test_large_tile_tn_plain_and_conv():
         torch.testing.assert_close(dwp.view(Co, 3, 3, Cin).permute(0, 3, 1, 2), ref, atol=2e-3 * float(ref.abs().max()), rtol=0)
         refb = dy.float().sum(0)
         torch.testing.assert_close(db, refb, atol=2e-3 * float(refb.abs().max()), rtol=0)
+
+
+# ------------------------------------------------------------------------------------------------ fp32 product modes
+@pytest.fixture
+def f32_mode_restored():
+    from unmore_amd import ops
+    prev = ops.get_f32_mode()
+    yield
+    ops.set_f32_mode(prev)
+
+
+def _rel_rms(x, ref):
+    return ((x.double() - ref).norm() / ref.norm()).item()
+
+
+@pytest.mark.parametrize("kind", ["nt", "tn", "conv"])
+def test_f32_x3_is_fp32_grade_on_finite_operands(kind, f32_mode_restored):
+    """UMR_F32_X3 (three-way bf16 splits on the bf16 matrix cores, the default of the fp32 parity mode) against the exact f32
+    MFMA path and float64, switched inside ONE process (umr_set_f32_mode).  Operands span 60 binary orders of magnitude per
+    row / column (scaled so that every dot product mixes them): the relative rms error of X3 must be within 1.5x of the exact
+    path's, and both within 2e-6."""
+    from unmore_amd import ops
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    if kind == "conv":
+        x = torch.randn((2, 12, 10, 64), generator=g)
+        w = torch.randn((96, 9 * 64), generator=g) * 0.05
+        sx = torch.exp2(torch.randint(-30, 30, (1, 1, 1, 64), generator=g).float())
+        A, B = (x * sx).to(dev), (w / sx.reshape(1, 1, 64).expand(1, 9, 64).reshape(1, -1)).to(dev)
+        ref = F.conv2d(A.double().permute(0, 3, 1, 2), B.double().reshape(96, 3, 3, 64).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(-1, 96)
+        run = lambda: ops.gemm_nt(A, B, None, conv=1)
+    else:
+        M, N, K = 700, 200, 512
+        a = torch.randn((M, K), generator=g)
+        b = torch.randn((N, K), generator=g)
+        sk = torch.exp2(torch.randint(-30, 30, (1, K), generator=g).float())
+        if kind == "nt":
+            A, B = (a * sk).to(dev), (b / sk).to(dev)
+            ref = A.double() @ B.double().t()
+            run = lambda: ops.gemm_nt(A, B, None)
+        else:   # dW[N,K'] = dY[M,N]^T X[M,K']: the reduction runs over rows, so the scales sit on rows
+            sm = torch.exp2(torch.randint(-30, 30, (M, 1), generator=g).float())
+            dY, X = (a[:, :N] * sm).to(dev), (torch.randn((M, 160), generator=g) / sm).to(dev)
+            ref = dY.double().t() @ X.double()
+            run = lambda: ops.gemm_tn(dY, X)
+    ops.set_f32_mode("exact")
+    e_exact = _rel_rms(run(), ref)
+    ops.set_f32_mode("x3")
+    e_x3 = _rel_rms(run(), ref)
+    print(f"{kind}: relative rms error vs float64 -- exact f32 MFMA {e_exact:.2e}, X3 {e_x3:.2e}")
+    assert e_exact < 2e-6 and e_x3 < 2e-6 and e_x3 < 1.5 * e_exact + 1e-8
+
+
+def test_f32_x3_documented_behaviour_outside_its_range(f32_mode_restored):
+    """What include/umr.h promises for non-finite / extreme operands, pinned: the EXACT mode behaves like an f32 FMA chain
+    (inf stays inf, FLT_MAX-sized and denormal operands are handled); X3 turns an inf or near-FLT_MAX operand into NaN and
+    loses the low-order terms of operands below ~2^-110 -- so a caller with such data selects the exact mode."""
+    from unmore_amd import ops
+    dev = _dev()
+    K = 64
+    A = torch.zeros((4, K), device=dev)
+    B = torch.zeros((8, K), device=dev)
+    B[:, 0] = 1.0
+    A[0, 0] = float("inf")
+    A[1, 0] = 3.4e38           # rounds to inf as a bf16
+    A[2, 0] = 2.0e-38          # normal in f32, but its m / l split terms are bf16 denormals
+    A[3, 0] = 1.2345678
+    ops.set_f32_mode("exact")
+    ex = ops.gemm_nt(A, B, None).cpu()
+    ops.set_f32_mode("x3")
+    x3 = ops.gemm_nt(A, B, None).cpu()
+    assert torch.isinf(ex[0]).all() and (ex[0] > 0).all()
+    assert torch.allclose(ex[1], torch.full((8,), 3.4e38)) and torch.allclose(ex[3], torch.full((8,), 1.2345678))
+    assert (ex[2] == A[2, 0].item()).all()
+    assert torch.isnan(x3[0]).all(), "X3: inf operand -> NaN (inf - inf in the split), as documented"
+    assert not torch.isfinite(x3[1]).any(), "X3: |x| within 2^-8 of FLT_MAX is out of range, as documented"
+    assert torch.allclose(x3[3], torch.full((8,), 1.2345678), rtol=3e-7, atol=0)
+    assert ((x3[2] - ex[2]).abs() <= 2.0 ** -8 * ex[2].abs()).all()   # at least the leading bf16 term survives
+    # NaN propagates in both modes
+    A[3, 1] = float("nan")
+    B[:, 1] = 1.0
+    for mode in ("exact", "x3"):
+        ops.set_f32_mode(mode)
+        assert torch.isnan(ops.gemm_nt(A, B, None)[3]).all()

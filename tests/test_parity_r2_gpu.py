@@ -153,8 +153,8 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     forward error the sign is decided by rounding, and ONE such pixel moves every parameter gradient by O(1/pixels) -- noise
     of the loss's discontinuity, not of the backward kernels (the fp32 CPU path shows the same).  So the chain is checked in
     two exact halves: (1) the loss kernel's gradient maps equal the oracle's except at such undecidable pixels (counted,
-    bounded); (2) the network backward, fed the SAME cotangent maps as the oracle's vector-Jacobian product, matches it to
-    5e-4 * max|g| for every parameter."""
+    bounded); (2) the network backward, fed the SAME cotangent maps as the oracle's vector-Jacobian product and compared on the SAME
+    linear piece (the HIP path's ReLU decisions imposed on the float64 oracle), matches it to 5e-4 * max|g| for every parameter."""
     from unmore_amd import ops
     B, H, W = 2, 128, 128
     net, sd = _net("dpt_base", tag="base")
@@ -182,39 +182,56 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     print(f"loss-gradient maps: {bad_c} centre / {bad_s} sdf pixels differ from the oracle; {undecidable} L1 signs undecidable at "
           f"forward error {fwd_err:.1e}")
     assert bad_c == 0 and bad_s <= 3 * undecidable + 2
-    # (2) network backward against the oracle's VJP with identical cotangents.  What remains between fp32 and float64 is the
-    # other discontinuity: ReLU masks decided differently where a pre-activation is within rounding of zero (features are
-    # O(20) here).  The reference CPU path is fp32 and has the same property, so it is the yardstick: the same VJP by the
-    # oracle in fp32 on the CPU.  Bars per parameter tensor: relative L2 error <= max(5e-4, 2x the CPU fp32 path's) -- the robust
-    # measure: a kernel bug shows as >= 1e-2 --; max-norm error <= 5e-3 * max|g| and at most 1 % of the elements off by more than
-    # 5e-4 * max|g| (a flipped mask upstream moves many elements of a weight gradient a little; the two fp32 paths flip DIFFERENT
-    # masks, so their element-wise errors are not comparable 1:1 -- both are printed).
-    names = [n for n, _ in net.named_parameters()]
-    ref = torch.autograd.grad([out_o["center_fields"], out_o["sdf_maps"]], [sdo[n] for n in names],
-                              grad_outputs=[dpc.cpu().double(), dps.cpu().double()], allow_unused=True)
+    # (2) network backward against the oracle's VJP with identical cotangents AND identical ReLU decisions.  What remains
+    # between fp32 and float64 once the L1 signs are shared is the other discontinuity: ReLU masks decided differently where a
+    # pre-activation is within rounding of zero.  Round 2 hypothesised that this explains a max-norm error of 1.7e-3 and widened
+    # the bar to 5e-3; here the hypothesis is a measurement: the float64 oracle is run with the HIP path's own decisions
+    # imposed at every ReLU site (oracle/mask_parity.py: relu(x) := x * mask_hip), so its VJP is the exact gradient of the
+    # function the HIP backward differentiates, and the ORIGINAL bar holds for every parameter tensor:
+    # max|g_hip - g_ref| <= 5e-4 * max|g_ref| (and relative L2 <= 5e-4).  The un-masked float64 VJP and the reference-style CPU
+    # fp32 VJP are printed beside it (they differ from BOTH by the flipped masks, counted per site).
+    del out
+    from oracle import mask_parity
+    eng = net._engine()
+    P = {n: p.detach() for n, p in net.named_parameters()}
+    names = list(P)
+    c_hip, s_hip, S = eng.forward(P, img.cuda(), save=True)
+    masks = mask_parity.hip_relu_masks(S, (eng.center_layout, eng.sdf_layout))
+    nograd = net.nograd_names()
+    G = {n: torch.zeros_like(P[n]) for n in names if n not in nograd}
+    eng.backward(P, S, dpc, dps, G)
+    torch.cuda.synchronize()
+    out_m, flips = mask_parity.masked_forward(sdo, img.double(), orc.CONFIGS["dpt_base"], masks)
+    assert (out_m["center_fields"].detach() - c_hip.cpu().double()).abs().max().item() < 1e-4
+    cot = [dpc.cpu().double(), dps.cpu().double()]
+    ref_m = torch.autograd.grad([out_m["center_fields"], out_m["sdf_maps"]], [sdo[n] for n in names], grad_outputs=cot, allow_unused=True)
+    ref_u = torch.autograd.grad([out_o["center_fields"], out_o["sdf_maps"]], [sdo[n] for n in names], grad_outputs=cot, allow_unused=True)
     sd32 = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     out_32 = orc.forward(sd32, img, orc.CONFIGS["dpt_base"])
     ref32 = torch.autograd.grad([out_32["center_fields"], out_32["sdf_maps"]], [sd32[n] for n in names],
                                 grad_outputs=[dpc.cpu(), dps.cpu()], allow_unused=True)
-    torch.autograd.backward([out["center_fields"], out["sdf_maps"]], [dpc, dps])
-    nograd = net.nograd_names()
-    w = dict(hip_inf=(0.0, ""), cpu_inf=(0.0, ""), hip_l2=(0.0, ""), cpu_l2=(0.0, ""), hip_out=(0.0, ""), cpu_out=(0.0, ""))
-    for (n, p), r, r32 in zip(net.named_parameters(), ref, ref32):
+    n_flip = sum(flips.values())
+    n_sites = sum(m.numel() for m in masks.values())
+    print(f"ReLU decisions: {n_flip} of {n_sites} differ between the HIP fp32 path and the float64 oracle; per site: "
+          + ", ".join(f"{k.replace('backbone.scratch.', '')} {v}" for k, v in sorted(flips.items()) if v))
+    w = dict(masked_inf=(0.0, ""), masked_l2=(0.0, ""), unmasked_inf=(0.0, ""), unmasked_l2=(0.0, ""), cpu32_inf=(0.0, ""), cpu32_l2=(0.0, ""))
+    fails = []
+    for n, rm, ru, r32 in zip(names, ref_m, ref_u, ref32):
         if n in nograd:
-            assert p.grad is None and r is None, n
+            assert rm is None and ru is None, n
             continue
-        g = p.grad.cpu().double()
-        gmax = r.abs().max().item() + 1e-300
-        e = dict(hip_inf=(g - r).abs().max().item() / gmax, cpu_inf=(r32.double() - r).abs().max().item() / gmax,
-                 hip_l2=((g - r).norm() / (r.norm() + 1e-300)).item(), cpu_l2=((r32.double() - r).norm() / (r.norm() + 1e-300)).item(),
-                 # share of elements off by more than 5e-4 * max|g| (a flipped ReLU mask moves single elements, not the tensor)
-                 hip_out=((g - r).abs() > 5e-4 * gmax).double().mean().item(), cpu_out=((r32.double() - r).abs() > 5e-4 * gmax).double().mean().item())
+        g = G[n].cpu().double()
+        gmax, gnorm = rm.abs().max().item() + 1e-300, rm.norm().item() + 1e-300
+        e = dict(masked_inf=(g - rm).abs().max().item() / gmax, masked_l2=(g - rm).norm().item() / gnorm,
+                 unmasked_inf=(g - ru).abs().max().item() / gmax, unmasked_l2=(g - ru).norm().item() / gnorm,
+                 cpu32_inf=(r32.double() - ru).abs().max().item() / gmax, cpu32_l2=(r32.double() - ru).norm().item() / gnorm)
         for k, v in e.items():
             if v > w[k][0]:
                 w[k] = (v, n)
-        assert e["hip_l2"] <= max(5e-4, 2 * e["cpu_l2"]), (n, e)
-        assert e["hip_out"] <= 1e-2 and e["hip_inf"] <= 5e-3, (n, e)
-    print("dpt_base fp32 gradients vs float64 VJP, worst over parameters: " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
+        if e["masked_inf"] > 5e-4 or e["masked_l2"] > 5e-4:
+            fails.append((n, e))
+    print("dpt_base fp32 gradients, worst over parameters (max-norm / max|g|, relative L2): " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
+    assert not fails, fails[:5]
 
 
 @pytest.mark.parametrize("backbone,H,W", [("dpt_large14", 70, 98), ("dpt_large", 64, 96)])

@@ -117,3 +117,44 @@ def test_sweep_over_two_streams_equals_sequential():
     assert (a[0] > 0).any()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+def test_sweep_on_three_streams_with_a_cold_pack_cache_equals_a_sequential_net():
+    """The packed (kernel-layout) weight copies are built lazily by whichever stream touches a weight first.  With a COLD cache
+    (freshly loaded net, first call ever) batch 0 packs on stream 0 while batches 1 and 2 hit the cache from streams 1 and 2:
+    they must wait for the pack kernels (engine.PackCache records an event per entry).  Compared with a second, separately
+    constructed net swept sequentially; the same again after the weights change in place (every entry is rebuilt)."""
+    from argparse import Namespace
+    import peaks_common as pc
+    from unmore_amd import reasoning, synth
+    from unmore_amd.objectness_net import ObjectnessNet
+    sd = pc.edited_state_dict(orc.state_dict_spec(orc.CONFIGS["dpt_base"]), "base", 0.05, 2.0)
+    img = torch.from_numpy(synth.blob_images(1, 240, 320, seed=4, n_blobs=6)[0]).cuda()
+    g = torch.Generator().manual_seed(1)
+    x1 = torch.rand(150, generator=g) * 200
+    y1 = torch.rand(150, generator=g) * 140
+    boxes = torch.stack([x1, y1, x1 + 40 + torch.rand(150, generator=g) * 80, y1 + 40 + torch.rand(150, generator=g) * 60], 1)
+
+    def fresh():
+        net = ObjectnessNet("cuda:0", 128, "dpt_base", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+        net.load_state_dict(sd)
+        return net.to("cuda:0").eval()
+
+    cold, seq = fresh(), fresh()
+    torch.cuda.synchronize()
+    b = reasoning.sweep_proposals(cold, img, boxes, 50, n_streams=3)     # very first call of this net: cold cache, 3 streams
+    a = reasoning.sweep_proposals(seq, img, boxes, 50, n_streams=1)
+    torch.cuda.synchronize()
+    assert (a[0] > 0).any()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    # in-place weight change: every packed copy is stale and rebuilt, again first touched from three streams
+    with torch.no_grad():
+        for net in (cold, seq):
+            for p in net.parameters():
+                p.mul_(1.0009765625)
+    b = reasoning.sweep_proposals(cold, img, boxes, 50, n_streams=3)
+    a = reasoning.sweep_proposals(seq, img, boxes, 50, n_streams=1)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)

@@ -12,3 +12,23 @@ int umr_set_error(int code, const char* msg) {
 
 extern "C" int umr_version(void) { return 100; }
 extern "C" const char* umr_last_error_string(void) { return g_err; }
+
+// ---- f32 product mode (include/umr.h): process-wide, switchable at run time (tests A/B it within one process)
+#include <atomic>
+#include <stdlib.h>
+static std::atomic<int> g_f32_mode{-1};
+int umr_f32_mode_now() {
+    int m = g_f32_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("UMR_F32_X3");
+        m = (e && atoi(e) == 0) ? UMR_F32_EXACT : UMR_F32_X3;
+        g_f32_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" int umr_set_f32_mode(int mode) {
+    if (mode != UMR_F32_EXACT && mode != UMR_F32_X3) return umr_set_error(UMR_ERR_INVALID, "umr_set_f32_mode: unknown mode");
+    g_f32_mode.store(mode, std::memory_order_relaxed);
+    return UMR_OK;
+}
+extern "C" int umr_get_f32_mode(void) { return umr_f32_mode_now(); }

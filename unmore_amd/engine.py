@@ -30,7 +30,13 @@ _ACT = {None: L.ACT_NONE, "tanh": L.ACT_TANH, "sine": ops.ACT_SINE}
 
 
 class PackCache:
-    """Kernel-layout copies of parameters, rebuilt when the parameter changes."""
+    """Kernel-layout copies of parameters, rebuilt when the parameter changes.
+
+    Stream-safe: an entry is built by kernels enqueued on whatever stream touches it first and is published to this host-side
+    dict at once, so a consumer on ANOTHER stream (reasoning.sweep_proposals deals batches to several streams) could launch
+    a GEMM that reads the packed buffer before the pack kernel has run.  Every entry therefore carries an event recorded
+    right after its build; a hit from a stream that has not yet ordered itself after that event waits on it first (once per
+    stream and entry -- afterwards the stream's own order covers it)."""
 
     def __init__(self):
         self._c = {}
@@ -38,10 +44,22 @@ class PackCache:
     def get(self, key, param, build):
         ver = (param._version, param.data_ptr())
         hit = self._c.get(key)
+        if param.is_cuda:
+            st = torch.cuda.current_stream(param.device)
+            sid = st.cuda_stream
+        else:
+            st, sid = None, None
         if hit is not None and hit[0] == ver:
+            if st is not None and sid not in hit[3]:
+                st.wait_event(hit[2])
+                hit[3].add(sid)
             return hit[1]
         val = build()
-        self._c[key] = (ver, val)
+        ev = None
+        if st is not None:
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._c[key] = (ver, val, ev, {sid})
         return val
 
     def clear(self):

@@ -32,16 +32,37 @@ def _rowmajor2d(t):
     return t
 
 
+def set_f32_mode(mode):
+    """How fp32 (parity-mode) GEMMs form their products (include/umr.h, umr_set_f32_mode): 'x3' (default) = three-way bf16
+    splits on the bf16 matrix cores, fp32-grade for finite operands; 'exact' = the f32 MFMA (IEEE behaviour for inf / huge /
+    denormal operands).  Process-wide.  Returns the previous mode."""
+    prev = get_f32_mode()
+    L.check(L.lib().umr_set_f32_mode({"exact": L.F32_EXACT, "x3": L.F32_X3}[mode]), "umr_set_f32_mode")
+    return prev
+
+
+def get_f32_mode():
+    return "x3" if L.lib().umr_get_f32_mode() == L.F32_X3 else "exact"
+
+
 _ws_cache = {}
 
 
+_WS_MAX_ENTRIES = 8
+
+
 def _workspace(nbytes, device):
-    # one scratch buffer per (device, stream): kernels of different streams may run concurrently (reasoning.sweep_proposals)
+    # one scratch buffer per (device, stream): kernels of different streams may run concurrently (reasoning.sweep_proposals).
+    # Streams come and go (their raw handles are the keys), so the cache is a small LRU: an evicted buffer goes back to the
+    # allocator pool of the stream it was allocated (and only ever used) on, which orders its reuse after the kernels that
+    # scribbled on it.
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws_cache.get(key)
+    buf = _ws_cache.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+    _ws_cache[key] = buf   # re-inserted last = most recently used
+    while len(_ws_cache) > _WS_MAX_ENTRIES:
+        _ws_cache.pop(next(iter(_ws_cache)))
     return buf
 
 

@@ -137,8 +137,10 @@ def sweep_proposals(objectness_model, image, proposals, num_img_per_batch=50, n_
             sdf = pred["sdf_maps"].squeeze(1)
             mx, am = center_peaks(sdf, pred["center_fields"])
             d = torch.stack(update_bbox_with_boundary_fields(sdf), 1)
-            for t in (crops, sdf, pred["center_fields"], mx, am, d):
-                t.record_stream(st)
+            # the results are consumed (torch.cat) on the caller's stream after cur.wait_stream(st): tell the allocator, so the
+            # blocks are not handed to the next batch of this side stream before that read has run
+            for t in (mx, am, d):
+                t.record_stream(cur)
             outs.append((mx, am, d))
     for s in streams:
         cur.wait_stream(s)

@@ -154,7 +154,7 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     of the loss's discontinuity, not of the backward kernels (the fp32 CPU path shows the same).  So the chain is checked in
     two exact halves: (1) the loss kernel's gradient maps equal the oracle's except at such undecidable pixels (counted,
     bounded); (2) the network backward, fed the SAME cotangent maps as the oracle's vector-Jacobian product and compared on the SAME
-    linear piece (the HIP path's ReLU decisions imposed on the float64 oracle), matches it to 5e-4 * max|g| for every parameter."""
+    linear piece (the HIP path's ReLU decisions imposed on the float64 oracle), matches it to 5e-5 * max|g| for every parameter."""
     from unmore_amd import ops
     B, H, W = 2, 128, 128
     net, sd = _net("dpt_base", tag="base")
@@ -187,8 +187,9 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     # pre-activation is within rounding of zero.  Round 2 hypothesised that this explains a max-norm error of 1.7e-3 and widened
     # the bar to 5e-3; here the hypothesis is a measurement: the float64 oracle is run with the HIP path's own decisions
     # imposed at every ReLU site (oracle/mask_parity.py: relu(x) := x * mask_hip), so its VJP is the exact gradient of the
-    # function the HIP backward differentiates, and the ORIGINAL bar holds for every parameter tensor:
-    # max|g_hip - g_ref| <= 5e-4 * max|g_ref| (and relative L2 <= 5e-4).  The un-masked float64 VJP and the reference-style CPU
+    # function the HIP backward differentiates.  Measured: 3.9e-6 * max|g| worst max-norm, 2.3e-6 worst relative L2 (40 of 70 M
+    # decisions differ from float64's own; the un-masked comparison sits at 4e-4, the CPU fp32 path at 3.9e-4).  Bar per
+    # parameter tensor: max|g_hip - g_ref| <= 5e-5 * max|g_ref| and relative L2 <= 5e-5 -- ten times TIGHTER than round 1's bar.  The un-masked float64 VJP and the reference-style CPU
     # fp32 VJP are printed beside it (they differ from BOTH by the flipped masks, counted per site).
     del out
     from oracle import mask_parity
@@ -228,7 +229,7 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
         for k, v in e.items():
             if v > w[k][0]:
                 w[k] = (v, n)
-        if e["masked_inf"] > 5e-4 or e["masked_l2"] > 5e-4:
+        if e["masked_inf"] > 5e-5 or e["masked_l2"] > 5e-5:
             fails.append((n, e))
     print("dpt_base fp32 gradients, worst over parameters (max-norm / max|g|, relative L2): " + "; ".join(f"{k} {v:.2e} ({n})" for k, (v, n) in w.items()))
     assert not fails, fails[:5]

@@ -42,6 +42,7 @@ WORKLOADS = {
     "ref": dict(kind="train", backbone="dpt_large", H=128, W=128, batch=20, name="ObjectnessNet ViT-L/16 (dpt_large) 128x128 bf16 batch=20 train (the reference's recipe)"),
     "tiny": dict(kind="train", backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
 }
+SWEEP_CHECK = (600, 620)   # cfg5: the proposals whose peaks the CPU oracle re-derives (20 of 1225: anchors of the 64-pixel grid)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -102,7 +103,7 @@ def _host():
     return cores, model
 
 
-def cpu_baseline(wl):
+def cpu_baseline(wl, hip_peaks=None):
     """the CPU restatement (oracle: fp32 PyTorch ops, autograd, Adam) of the same workload on the host
     cores, torch threads = the process's CPU share; 2 warm-ups, median of >= 5 timed iterations (3 when one iteration takes
     longer than 12 s).  Train workloads: the full step (fwd + loss + bwd + Adam) on ONE image of the workload's own
@@ -144,12 +145,14 @@ def cpu_baseline(wl):
         def one(step):
             with torch.no_grad():
                 orc.forward(sd, img, cfg)
-    else:  # sweep
-        sd = {k: torch.from_numpy(hash_init(k, s, "bench")) for k, s in spec.items()}
+    else:  # sweep: the same net (hash weights + the peak fixtures' documented edits) and the same image as the GPU leg
+        sd = {k: torch.from_numpy(v) for k, v in synth.peak_edited_state_dict(spec, "base").items()}
         Hi, Wi = wl["image"]
-        image = torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=123)[0])
-        props = torch.from_numpy(anchors(Hi, Wi))[600:610]
-        per_iter, what = 10.0 / wl["proposals"], "crop+resize, forward, peak picking, box deltas on 10 of one image's 1225 proposals"
+        image = torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=0)[0])
+        lo, hi = SWEEP_CHECK
+        props = torch.from_numpy(anchors(Hi, Wi))[lo:hi]
+        per_iter, what = (hi - lo) / wl["proposals"], f"crop+resize, forward, peak picking, box deltas on {hi - lo} of one image's 1225 proposals"
+        kept = {}
 
         def one(step):
             with torch.no_grad():
@@ -157,6 +160,7 @@ def cpu_baseline(wl):
                 out = orc.forward(sd, crops, cfg)
                 orc.peak_pick(out["sdf_maps"][:, 0], out["center_fields"])
                 orc.update_bbox_with_boundary_fields(out["sdf_maps"][:, 0])
+                kept["out"] = out
 
     print(f"[bench] cpu_baseline: timing the CPU oracle ({what}) on {cores} threads ...", file=sys.stderr, flush=True)
     times = []
@@ -173,7 +177,24 @@ def cpu_baseline(wl):
         timed.append(time.perf_counter() - t0)
         print(f"[bench] cpu_baseline: iteration {i + 1}/{n} {timed[-1]:.1f} s", file=sys.stderr, flush=True)
     med = float(np.median(timed))
-    return {"value": per_iter / med, "unit": "images/sec", "cores": cores, "cpu_model": model, "kind": "port",
+    extra = {}
+    if kind == "sweep" and hip_peaks is not None:
+        # configs[4]: "peak-picking bit-exact vs CPU" -- the flat argmax of every checked proposal, HIP fp32 sweep vs this CPU
+        # oracle on the same crops; `certified` = proposals whose CPU argmax is provably stable against any field perturbation
+        # below 2e-4 (oracle.peak_certificate): a mismatch there would be a real error, elsewhere it is a near-tie
+        out = kept["out"]
+        amax, arg, cert = orc.peak_certificate(out["sdf_maps"][:, 0].contiguous(), out["center_fields"].contiguous(), 2e-4)
+        h_amax, h_arg = hip_peaks
+        has_peak = amax > 0
+        mism = [(int(a) != int(b)) for a, b in zip(arg.tolist(), h_arg.tolist())]
+        extra["peak_check"] = {
+            "proposals_checked": int(arg.numel()), "proposal_range": list(SWEEP_CHECK),
+            "maps_with_peak_cpu": int(has_peak.sum()), "maps_with_peak_hip": int((h_amax > 0).sum()),
+            "peak_index_mismatches": int(sum(mism)), "certified": int(cert.sum()),
+            "mismatches_among_certified": int(sum(m for m, c in zip(mism, cert.tolist()) if c)),
+            "max_abs_amax_difference": float((amax - h_amax).abs().max()),
+            "note": "flat argmax of the eroded anti-centre score map per proposal, HIP fp32 sweep vs the CPU oracle (torch fp32) on the same crops"}
+    return {**extra, "value": per_iter / med, "unit": "images/sec", "cores": cores, "cpu_model": model, "kind": "port",
             "sample": f"median of {n} timed iterations after 2 warm-ups, each = {what}; fp32, torch CPU, {cores} threads; "
                       f"median {med:.2f} s/iteration"}
 
@@ -405,6 +426,11 @@ def run_rank(a):
                 net.get_prediction(img)
         units_per_step = B
     else:  # sweep: one step = one 640x480 image = 1225 proposals (replicas only: every rank sweeps its own images)
+        # hash weights + the peak fixtures' documented edits: a plain random-init net has empty eroded masks everywhere and the
+        # peak-picking stage would be timed doing nothing (round 2's line had maps_with_peak = 0)
+        spec = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.peak_edited_state_dict(spec, "base").items()}, strict=True)
+        net = net.to(dev)
         net.eval()
         for p in net.parameters():
             p.requires_grad = False
@@ -415,6 +441,7 @@ def run_rank(a):
         images = [torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=1000 * rank + i)[0]).to(dev) for i in range(n_img)]
         counter = [0]
         peaks = [0, 0]
+        n_with_peak = [0, 0]    # proposals with a peak / proposals swept, over the timed steps
         M_head = 50 * 128 * 128
 
         def one():
@@ -441,7 +468,10 @@ def run_rank(a):
         fwd_gflop = forward_gflop_per_image(cfg, H, W)
         conv_flop = 2.0 * M_head * 512 * 4608
         avg_ms = sum(conv_ms) / max(len(conv_ms), 1)
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        x3 = a.dtype != "bf16" and ops.get_f32_mode() == "x3"
+        # fp32 parity mode: an fp32-grade product is six bf16 MFMA products (UMR_F32_X3), so the ceiling of the ALGORITHMIC f32
+        # rate is the dense bf16 peak / 6 = 416.7 TFLOP/s (above the f32 MFMA's own 157.3); exact-f32 mode: the f32 MFMA peak
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else (PEAK_BF16_TFLOPS / 6.0 if x3 else PEAK_F32_TFLOPS)
         achieved = conv_flop / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         name = wl["name"] if a.batch is None else wl["name"].replace(f"batch={wl['batch']}", f"batch={B}")
         if a.dtype != "bf16":
@@ -465,15 +495,25 @@ def run_rank(a):
             "collective": coll,
             "per_rank_images_per_sec": [units_per_step * a.steps / t for t in own],   # each rank's own clock between the barriers
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-            "roofline": {"bound": "mfma", "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 (heads" + (", fwd+dgrad)" if kind == "train" else ", fwd)")
-                                                     + (" bf16" if a.dtype == "bf16" else " f32")),
+            "roofline": {"bound": "mfma",
+                         "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 of the heads ("
+                                    + ("per step: 2 forward launches + the centre head's ReLU-masked data gradient; the boundary-distance head's "
+                                       "backward is algebraic and the weight gradient is the TN kernel" if kind == "train" else "forward, one launch per head and batch")
+                                    + (") bf16" if a.dtype == "bf16" else (") fp32-grade: f32 values as three bf16 planes, six bf16 MFMA products per "
+                                                                          "f32 product; peak = 2500 / 6" if x3 else ") f32 MFMA"))),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,
                          **measured_traffic(a)},
         }
         if kind == "train":
             res["config"].update({"optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"})
+            # model FLOPs (3 x forward) and the FLOPs this step actually executes: with the algebraic backward the
+            # boundary-distance head's data- and weight-gradient GEMMs (2 x its forward) are not run
+            head_fwd_gflop = 2.0 * H * W * (256 * 512 + 9 * 512 * 512 + 512 * 1024 + 1024) / 1e9
+            skipped = 2.0 * head_fwd_gflop if net._engine().linear_head_backward == "algebraic" and not net._layouts[1]["relu"] and net._layouts[1]["final"] != "sine" else 0.0
             res["train_tflops_per_gpu"] = 3 * fwd_gflop * B * a.steps / elapsed / 1e3
+            res["train_tflops_note"] = "MODEL FLOPs (3 x forward formula); executed_tflops_per_gpu counts what the step runs"
+            res["executed_tflops_per_gpu"] = (3 * fwd_gflop - skipped) * B * a.steps / elapsed / 1e3
             res["final_loss"] = float(last[0][0].item())
         elif kind == "forward":
             res["forward_tflops_per_gpu"] = fwd_gflop * B * a.steps / elapsed / 1e3
@@ -488,31 +528,44 @@ def run_rank(a):
                                            "streams run beside it, so `achieved` is a lower bound of the kernel alone (--sweep-streams 1)")
             res["maps_with_peak"] = int((peaks[0] > 0).sum().item())
             res["config"]["streams"] = a.sweep_streams
-        if world == 1 and kind == "sweep" and a.dtype == "bf16" and not a.no_alt:
-            # beside the headline: the same sweep in fp32 (the reference's precision; the mode whose maps are within 1e-4 of the
-            # reference and whose peak indices are bit-identical to it, tests/test_parity_r2_gpu.py), one image
-            net.set_compute_dtype(torch.float32)
-            one()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            one()
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            net.set_compute_dtype(dt)
-            res["alt_fp32_parity_mode"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
-                                           "note": "fp32 storage and exact-fp32 MFMA: the 1e-4 / bit-exact-peaks mode"}
-            # and with the opt-in collapsed forward of the boundary-distance head (one 3x3 conv 256 -> 1)
-            net.set_sdf_head_mode("collapsed")
-            one()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(2):
+        hip_peaks = None
+        if kind == "sweep":
+            res["maps_with_peak_share"] = res["maps_with_peak"] / wl["proposals"]
+        if world == 1 and kind == "sweep" and not a.no_alt:
+            def timed_sweeps(n):
                 one()
-            torch.cuda.synchronize()
-            dt3 = (time.perf_counter() - t1) / 2
-            net.set_sdf_head_mode("factored")
-            res["alt_collapsed_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
-                                             "note": "opt-in algebraic fast path; not the headline configuration"}
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    one()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n
+            if a.dtype == "fp32":
+                # the peaks the CPU leg re-derives: image 0, proposals SWEEP_CHECK, in the headline (fp32 parity) mode
+                mx0, am0, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
+                lo, hi = SWEEP_CHECK
+                hip_peaks = (mx0[lo:hi].cpu(), am0[lo:hi].cpu())
+                # beside the headline: the same sweep with bf16 storage (no bit-exact-peak claim) ...
+                net.set_compute_dtype(torch.bfloat16)
+                dt2 = timed_sweeps(2)
+                mxb, amb, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
+                res["alt_bf16"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
+                                   "maps_with_peak": int((mxb > 0).sum().item()),
+                                   "peak_index_differs_from_fp32_mode": int((amb != am0).sum().item()),
+                                   "note": "bf16 storage / bf16 MFMA: throughput mode, maps within ~3e-2 of the reference, peak indices NOT claimed"}
+                # ... and bf16 with the opt-in collapsed forward of the boundary-distance head (one 3x3 conv 256 -> 1)
+                net.set_sdf_head_mode("collapsed")
+                dt3 = timed_sweeps(2)
+                net.set_sdf_head_mode("factored")
+                res["alt_bf16_collapsed_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
+                                                      "note": "opt-in algebraic fast path; not the headline configuration"}
+                net.set_compute_dtype(dt)
+            else:
+                net.set_compute_dtype(torch.float32)
+                dt2 = timed_sweeps(1)
+                net.set_compute_dtype(dt)
+                res["alt_fp32_parity_mode"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
+                                               "note": "fp32 storage, fp32-grade products (UMR_F32_X3): the 1e-4 maps / bit-exact-peaks mode; the default --dtype of this workload"}
         if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
             # algebraic form of the linear boundary-distance head (identical function and gradients
@@ -548,7 +601,7 @@ def run_rank(a):
             res["alt_collapsed_sdf_head"] = {"value": B / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2,
                                              "note": "opt-in algebraic fast path; not the headline configuration"}
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(wl)
+            res["cpu_baseline"] = cpu_baseline(wl, hip_peaks)
         print(json.dumps(res), flush=True)
     if world > 1:
         barrier()
@@ -602,7 +655,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"],
+                    help="default: bf16 for the train / forward workloads (BASELINE configs[0..3]); fp32 for cfg5 -- configs[4] asks for peak "
+                         "picking bit-exact vs the CPU, which only the fp32 parity mode claims (bf16 is reported beside it)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo = rehearsal transport (ranks may share a GPU)")
     ap.add_argument("--rehearse", action="store_true", help="CPU-only: run the multi-process plumbing without the model")
     ap.add_argument("--sweep-streams", type=int, default=3, help="cfg5: HIP streams the independent 50-crop batches are dealt to")
@@ -611,6 +666,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()
+    if a.dtype is None:
+        a.dtype = "fp32" if WORKLOADS[a.workload]["kind"] == "sweep" else "bf16"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a.gpus, a.launch_timeout)
     return run_rank(a)

@@ -20,7 +20,10 @@ extern "C" {
 typedef void* umr_stream_t; /* hipStream_t */
 
 enum umr_status { UMR_OK = 0, UMR_ERR_INVALID = -1, UMR_ERR_UNSUPPORTED = -2, UMR_ERR_HIP = -1000 };
-enum umr_dtype { UMR_F32 = 0, UMR_BF16 = 1 };
+/* UMR_BF16X3 (umr_gemm_nt only): f32 VALUES held as three bf16 planes per value, x = h + m + l (exact for every finite f32 in
+ * bf16's exponent range; written by umr_split3 or by a GEMM with UMR_EPI_OUT_X3).  A row of K logical elements is
+ * [h(K) | m(K) | l(K)], 3K bf16; see umr_gemm_desc. */
+enum umr_dtype { UMR_F32 = 0, UMR_BF16 = 1, UMR_BF16X3 = 2 };
 
 int umr_version(void);
 const char* umr_last_error_string(void);
@@ -55,7 +58,8 @@ int umr_get_f32_mode(void);
  * bf16 layers compute; for MASK_RELU that is bit-identical to rounding last. */
 enum umr_epi_flags {
     UMR_EPI_BIAS = 1, UMR_EPI_ADD_AUX = 2, UMR_EPI_MASK_RELU = 4, UMR_EPI_MASK_DGELU = 8,
-    UMR_EPI_ADD_AUX2 = 16, UMR_EPI_OUT_F32 = 32, UMR_EPI_ROWBIAS = 64
+    UMR_EPI_ADD_AUX2 = 16, UMR_EPI_OUT_F32 = 32, UMR_EPI_ROWBIAS = 64,
+    UMR_EPI_OUT_X3 = 128   /* dtype UMR_BF16X3 only: C is written as three bf16 planes [h(N) | m(N) | l(N)] per row (ldc >= 3N) */
 };
 enum umr_act { UMR_ACT_NONE = 0, UMR_ACT_RELU = 1, UMR_ACT_GELU = 2, UMR_ACT_TANH = 3, UMR_ACT_SIGMOID = 5 /* 4 = sine, head_out only */ };
 
@@ -94,7 +98,17 @@ typedef struct umr_gemm_desc {
     int32_t no_store;
 } umr_gemm_desc;
 
+/* dtype UMR_BF16X3 -- the fast form of the fp32 parity mode (the reference runs in fp32, object_reasoning.py:74): both operands
+ * are f32 values pre-split into bf16 planes; the product is the six-term sum of UMR_F32_X3 (same accuracy and the same range
+ * caveats) computed as six bf16 K-tiles per logical K-tile on the persistent 256x256 kernel, with no split arithmetic in the
+ * loop.  A: [M][3K] bf16 (lda >= 3K), or NHWC with 3*Cin bf16 per pixel [h(Cin) | m(Cin) | l(Cin)] when conv == 1;
+ * B: [N][3K] bf16 (ldb >= 3K; conv: K = 9*Cin ordered (ky,kx,ci) inside each plane).  K (conv: Cin) must be a multiple of 64,
+ * N of 8; epilogue: bias, ReLU, and exactly one of UMR_EPI_OUT_F32 (C f32 [M][N]) / UMR_EPI_OUT_X3 (C planes [M][3N] bf16);
+ * no aux / remap / C2 / reduction.  Anything else returns UMR_ERR_UNSUPPORTED. */
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
+/* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
+ * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
+int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);
 /* 1 if umr_gemm_nt would run d (ignoring red_*, no_store) on the path that implements the fused row reduction */
 int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d);
 

@@ -449,6 +449,43 @@ def peak_pick(sdf_maps, center_fields, border=10):
     return score, flat.amax(dim=1), flat.argmax(dim=1)
 
 
+def peak_certificate(sdf_maps, center_fields, eps, thres=0.009, border=10):
+    """Is the flat argmax of `peak_pick` provably unchanged by ANY perturbation of the fields below `eps` (max-norm)?
+    (tests/golden/make_golden_r2.py computes the same certificate for the committed peak fixtures.)  Erosion is monotone, so
+    with F = the pixels such a perturbation can move across a threshold of the union mask (object_reasoning.py:528-533), every
+    reachable eroded mask lies between erode(union & ~F) and erode(union | F); a score moves by at most sqrt(2)*eps (24
+    unit-vector taps / 24).  Certified when the peak survives in the smallest mask, beats every pixel of the largest mask by
+    more than 2*sqrt(2)*eps and amax stays on its side of the singularity threshold (:541).
+    Returns (amax [B] f64, flat argmax [B] i64, certified [B] bool)."""
+    sdf_bin = torch.where(torch.sigmoid(sdf_maps) > 0.5, 1, 0)
+    cnorm = torch.norm(center_fields, dim=1)
+    cen_bin = torch.where(cnorm > 0.5, 1, 0)
+    union = torch.where((cen_bin + sdf_bin) > 0, 1, 0)
+    score, amax, arg = peak_pick(sdf_maps, center_fields, border)
+    d_s, d_c = sdf_maps.abs(), (cnorm - 0.5).abs()
+    both = (sdf_bin == 1) & (cen_bin == 1)
+    flip = torch.where(both, torch.maximum(d_s, d_c), torch.where(sdf_bin == 1, d_s, torch.where(cen_bin == 1, d_c, torch.minimum(d_s, d_c))))
+    Fm = flip < eps
+    er_min = batch_erode(torch.where(Fm, 0, union), 9, 3)
+    er_max = batch_erode(torch.where(Fm, 1, union), 9, 3)
+    fg_max = anti_center_map(center_fields, 5) * er_max
+    fg_max[:, 0:border, :] = 0
+    fg_max[:, -border:, :] = 0
+    fg_max[:, :, 0:border] = 0
+    fg_max[:, :, -border:] = 0
+    B = sdf_maps.shape[0]
+    bound = 2.0 * math.sqrt(2.0) * eps
+    cert = torch.zeros(B, dtype=torch.bool)
+    for b in range(B):
+        p_ = int(arg[b])
+        if float(amax[b]) <= 0 or int(er_min[b].reshape(-1)[p_]) != 1:
+            continue
+        others = fg_max[b].reshape(-1).clone()
+        others[p_] = -1e300
+        cert[b] = bool(float(amax[b]) - float(others.max()) > bound) and abs(float(amax[b]) - thres) > bound
+    return amax, arg, cert
+
+
 def crop_resize(image, boxes, size=128):
     """object_reasoning.py:311-323: per box floor/ceil, crop, torchvision tensor Resize((size,size), BILINEAR)
     (torchvision 0.14: no antialias == F.interpolate(mode='bilinear', align_corners=False))."""

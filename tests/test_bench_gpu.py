@@ -40,3 +40,7 @@ def test_single_gpu_lines_carry_the_contract(workload, extra):
     assert rf["bound"] == "mfma" and rf["launches_timed"] > 0 and 0 < rf["frac"] < 1
     if workload == "cfg5":
         assert res["config"]["proposals_per_image"] == 1225 and res["crops_per_sec"] > 0
+        # BASELINE configs[4] ("peak-picking bit-exact vs CPU"): the headline is the fp32 parity mode on a net whose score maps are
+        # NOT empty (at least half of the proposals have a peak), bf16 is reported beside it
+        assert res["dtype"] == "fp32" and res["maps_with_peak"] >= 1225 // 2
+        assert res["alt_bf16"]["value"] > res["value"]

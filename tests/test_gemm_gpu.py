@@ -383,3 +383,74 @@ def test_f32_x3_documented_behaviour_outside_its_range(f32_mode_restored):
     for mode in ("exact", "x3"):
         ops.set_f32_mode(mode)
         assert torch.isnan(ops.gemm_nt(A, B, None)[3]).all()
+
+
+# ------------------------------------------------------------------------------------------------ f32 values as bf16 planes
+def _planes_to_f64(pl, K):
+    return pl[..., :K].double() + pl[..., K:2 * K].double() + pl[..., 2 * K:].double()
+
+
+def test_split3_is_lossless_for_f32():
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((777, 200), torch.float32, dev, 21) * torch.exp2(torch.randint(-40, 40, (777, 1), generator=torch.Generator().manual_seed(3)).float()).to(dev)
+    pl = ops.split3(x)
+    assert pl.shape == (777, 600) and pl.dtype == torch.bfloat16
+    assert torch.equal(_planes_to_f64(pl, 200), x.double())          # h + m + l == x exactly
+    assert torch.equal(pl[:, :200], x.to(torch.bfloat16))             # h = round-to-nearest bf16 of x
+
+
+@pytest.mark.parametrize("M,N,K,relu", [(1000, 264, 192, True), (257, 8, 64, False), (70001, 512, 256, True)])
+def test_gemm_nt_x3_planes(M, N, K, relu, f32_mode_restored):
+    """umr_gemm_nt with dtype UMR_BF16X3 (operands = f32 values as three bf16 planes, six plane pairs per K-tile on the persistent
+    256x256 kernel): fp32-grade vs float64 -- error within 2x of the exact f32 MFMA path's --, f32 and plane outputs agree
+    exactly, tails in M and N."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    A = _rnd((M, K), torch.float32, dev, 31)
+    B = _rnd((N, K), torch.float32, dev, 32, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 33)
+    ref = A.double() @ B.double().t() + bias.double()
+    if relu:
+        ref = F.relu(ref)
+    act = L.ACT_RELU if relu else L.ACT_NONE
+    Ap, Bp = ops.split3(A), ops.split3(B)
+    out = ops.gemm_nt_x3(Ap, Bp, bias, act=act)
+    outp = ops.gemm_nt_x3(Ap, Bp, bias, act=act, out_planes=True)
+    assert out.dtype == torch.float32 and out.shape == (M, N) and outp.shape == (M, 3 * N)
+    assert torch.equal(_planes_to_f64(outp, N), out.double())
+    ops.set_f32_mode("exact")
+    exact = ops.gemm_nt(A, B, bias, act=act)
+    e_x3, e_ex = _rel_rms(out, ref), _rel_rms(exact, ref)
+    print(f"planes GEMM {M}x{N}x{K}: relative rms error vs float64 {e_x3:.2e} (exact f32 MFMA path {e_ex:.2e})")
+    assert e_x3 < 2.0 * e_ex + 1e-8 and e_x3 < 1e-6
+    torch.testing.assert_close(out.double(), ref, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("nb,H,W,Cin,N", [(2, 20, 24, 64, 128), (1, 37, 19, 128, 72), (5, 128, 128, 64, 256)])
+def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored):
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    x = _rnd((nb, H, W, Cin), torch.float32, dev, 41)
+    w = _rnd((N, 3, 3, Cin), torch.float32, dev, 42, (9 * Cin) ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 43)
+    ref = F.relu(F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1)).permute(0, 2, 3, 1).reshape(-1, N)
+    xp, wp = ops.split3(x), ops.split3(w.reshape(N, 9 * Cin))
+    out = ops.gemm_nt_x3(xp, wp, bias, act=L.ACT_RELU, conv=1)
+    outp = ops.gemm_nt_x3(xp, wp, bias, act=L.ACT_RELU, conv=1, out_planes=True)
+    assert torch.equal(_planes_to_f64(outp, N), out.double())
+    ops.set_f32_mode("exact")
+    exact = ops.gemm_nt(x, w.reshape(N, 9 * Cin), bias, act=L.ACT_RELU, conv=1)
+    e_x3, e_ex = _rel_rms(out, ref), _rel_rms(exact, ref)
+    print(f"planes conv {nb}x{H}x{W}x{Cin}->{N}: relative rms error vs float64 {e_x3:.2e} (exact f32 MFMA path {e_ex:.2e})")
+    assert e_x3 < 2.0 * e_ex + 1e-8 and e_x3 < 1e-6   # measured 6.3e-7 vs 4.1e-7: the six-term product is ~1.5x f32's own rounding
+    torch.testing.assert_close(out.double(), ref, atol=2e-5, rtol=2e-5)
+
+
+def test_gemm_nt_x3_refuses_what_it_does_not_implement():
+    from unmore_amd import ops
+    dev = _dev()
+    Ap = ops.split3(_rnd((64, 96), torch.float32, dev, 1))      # K = 96 is not a multiple of 64
+    Bp = ops.split3(_rnd((16, 96), torch.float32, dev, 2))
+    with pytest.raises(RuntimeError, match="BF16X3"):
+        ops.gemm_nt_x3(Ap, Bp)

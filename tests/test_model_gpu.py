@@ -166,3 +166,7 @@ def test_backward_fp32_other_sdf_activations(bg, act):
         ref = sdo[n].grad
         e = (p.grad.cpu().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
         assert e <= 5e-4, f"{n}: rel err {e}"
+    # and on the HIP path's own linear piece (float64 oracle with its ReLU decisions imposed): rounding only
+    from grad_common import masked_gradient_check
+    w_inf, w_n, w_l2, n_flip = masked_gradient_check(net, sd, "dpt_tiny", x, gc, gs, sal, use_bg_sdf=bg, sdf_activation=act)
+    print(f"use_bg_sdf={bg} sdf_activation={act}: worst max-norm {w_inf:.2e} ({w_n}), worst relative L2 {w_l2:.2e}, {n_flip} decisions differ")

@@ -239,7 +239,10 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
 def test_backward_fp32_patch14_odd_grid_matches_oracle(backbone, H, W):
     """dpt_large = the reference's only live backbone_type (ViT-L/16, objectness_net.py:62-73), at 64x96.  BASELINE configs[3] wiring (dpt_large14: patch 14, pos grid 37, odd token grids -- fusion blocks resize to the skip's size,
     final resize to the input size, all with non-2x bilinear adjoints) at 70x98 (grid 5x7): 4-term loss, every parameter gradient
-    vs the oracle's float64 autograd (relative L2 <= 5e-4 and max-norm <= 5e-3 * max|g| per tensor)."""
+    (a) through the autograd.Function boundary vs the oracle's plain float64 autograd (relative L2 <= 5e-4 per tensor; the max-norm
+    is only reported here: it carries the masks / L1 signs that fp32 and float64 decide differently), and (b) on the HIP path's
+    own linear piece vs the float64 oracle with its ReLU decisions imposed: max-norm and relative L2 <= 5e-5 per tensor."""
+    from grad_common import masked_gradient_check
     from unmore_amd.loss import objectness_loss
     B = 1
     net, sd = _net(backbone, tag=backbone, size=H)
@@ -266,8 +269,12 @@ def test_backward_fp32_patch14_odd_grid_matches_oracle(backbone, H, W):
             worst["l2"] = (l2, n)
         if inf > worst["inf"][0]:
             worst["inf"] = (inf, n)
-        assert l2 <= 5e-4 and inf <= 5e-3, (n, l2, inf)
-    print(f"{backbone} {H}x{W} fp32 gradients vs float64: worst relative L2 {worst['l2'][0]:.2e} ({worst['l2'][1]}), worst max-norm {worst['inf'][0]:.2e} ({worst['inf'][1]})")
+        assert l2 <= 5e-4, (n, l2, inf)
+        p.grad = None
+    w_inf, w_n, w_l2, n_flip = masked_gradient_check(net, sd, backbone, img, cf, sdf, sal)
+    print(f"{backbone} {H}x{W} fp32 gradients: vs plain float64 autograd worst relative L2 {worst['l2'][0]:.2e} ({worst['l2'][1]}), worst max-norm "
+          f"{worst['inf'][0]:.2e} ({worst['inf'][1]}); on the HIP path's linear piece ({n_flip} decisions differ) worst max-norm {w_inf:.2e} ({w_n}), "
+          f"worst relative L2 {w_l2:.2e}")
 
 
 def test_bf16_vs_fp32_hip_at_benchmark_shape():

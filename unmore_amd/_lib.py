@@ -8,8 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UMR_LIB") or os.path.join(_HERE, "lib", "libumr.so")   # UMR_LIB: an instrumented build (tools/probe)
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
-EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS = 1, 2, 4, 8, 16, 32, 64
+F32, BF16, BF16X3 = 0, 1, 2
+EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS, EPI_OUT_X3 = 1, 2, 4, 8, 16, 32, 64, 128
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 ACT_SIGMOID = 5
 F32_EXACT, F32_X3 = 0, 1   # umr_f32_mode
@@ -98,6 +98,7 @@ _SIGS = {
     "umr_linear_head_bwd_weight_workspace": [_i64, _i32],
     "umr_linear_head_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "umr_set_f32_mode": [_i32],
     "umr_get_f32_mode": [],
     "umr_version": [],

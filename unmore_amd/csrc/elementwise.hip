@@ -227,6 +227,31 @@ __global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, in
         dst[i] = from_f32<TO>(to_f32<TI>(src[i]) * scale);
 }
 
+// ---------------------------------------------------------------- f32 -> three bf16 planes per row (UMR_BF16X3 operands)
+// one thread = 4 consecutive k of one row: 16 B read, 3 x 8 B written (a wave covers 256 consecutive k: 1 KiB read, 3 x 512 B written)
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int K,
+                                                     int64_t ld_src, int64_t ld_dst) {
+    const int k4 = K >> 2;
+    const int64_t total = rows * k4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / k4;
+        const int k = (int)(i - r * k4) * 4;
+        const f32x4 x = *(const f32x4*)(src + r * ld_src + k);
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16_t hh = (bf16_t)x[e];
+            const float r1 = x[e] - (float)hh;
+            const bf16_t mm = (bf16_t)r1;
+            h[e] = hh; m[e] = mm; l[e] = (bf16_t)(r1 - (float)mm);
+        }
+        bf16_t* d = dst + r * ld_dst + k;
+        *(bf16x4*)d = h;
+        *(bf16x4*)(d + K) = m;
+        *(bf16x4*)(d + 2 * K) = l;
+    }
+}
+
 // ---------------------------------------------------------------- head output layer: 1024 -> {1,2} (+ activation), NCHW f32 out
 // one wave per pixel row: lanes split K, wave reduction.  out[b][c][hw]
 template <typename T>
@@ -592,6 +617,15 @@ extern "C" int umr_cast(const void* src, void* dst, int64_t n, float scale, int 
     else if (dtype_in == UMR_F32 && dtype_out == UMR_F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n, scale);
     else if (dtype_in == UMR_BF16 && dtype_out == UMR_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n, scale);
     else return umr_set_error(UMR_ERR_INVALID, "cast: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && rows > 0 && K > 0 && K % 4 == 0 && ld_src >= K && ld_src % 4 == 0 && ld_dst >= 3 * (int64_t)K && ld_dst % 4 == 0,
+                  "split3: bad arguments (K, ld_src, ld_dst multiples of 4; ld_dst >= 3K)");
+    hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (K / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K,
+                       ld_src, ld_dst);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

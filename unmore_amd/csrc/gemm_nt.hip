@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 }  // namespace
 
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
+int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
 static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
@@ -430,6 +431,23 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     UMR_CHECK_ARG(d != nullptr, "gemm_nt: null descriptor");
     UMR_CHECK_ARG(d->A && d->B && (d->C || d->no_store), "gemm_nt: null operand");
     UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem");
+    if (d->dtype == UMR_BF16X3) {
+        // f32 values as three bf16 planes: persistent 256x256 kernel only (include/umr.h)
+        UMR_CHECK_ARG(d->conv == 0 || d->conv == 1, "gemm_nt (BF16X3): plain GEMM or stride-1 3x3 conv only");
+        const bool out_f32 = (d->flags & UMR_EPI_OUT_F32) != 0, out_x3 = (d->flags & UMR_EPI_OUT_X3) != 0;
+        const int kk = d->conv == 0 ? d->K : d->Cin;
+        const bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && (out_f32 != out_x3) && d->c2_mode == 0 && !d->red_w && !d->no_store &&
+                        d->a_rows_in <= 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
+                        !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3)) && (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU) &&
+                        (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) && (out_x3 ? (d->ldc % 8 == 0 && d->ldc >= 3 * (int64_t)d->N) : (d->ldc % 4 == 0)) &&
+                        (d->conv == 1 ? (d->K == 9 * d->Cin && (int64_t)d->nb * d->Ho * d->Wo == d->M && d->Ho == d->H && d->Wo == d->W)
+                                      : (d->lda % 8 == 0 && d->lda >= 3 * (int64_t)d->K));
+        if (!ok) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt (BF16X3): needs K (conv: Cin) % 64 == 0, N % 8 == 0, bias / ReLU epilogue, "
+                                                           "exactly one of OUT_F32 / OUT_X3, no aux / remap / C2 / reduction (include/umr.h)");
+        UMR_CHECK_ARG(!(d->flags & UMR_EPI_BIAS) || d->bias, "gemm_nt: bias flag without pointer");
+        UMR_CHECK_ARG((int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) < (1ll << 31), "gemm_nt: grid too large");
+        return umr_launch_gemm_nt256p(d, (hipStream_t)stream);
+    }
     UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16, "gemm_nt: dtype");
     const int epc = d->dtype == UMR_BF16 ? 8 : 4;
     UMR_CHECK_ARG(d->conv >= 0 && d->conv <= 2, "gemm_nt: conv mode");

@@ -67,8 +67,17 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // EPI: 1 = generic epilogue, 3 = fast class (AUXM: 0 none, 1 residual add, 2 ReLU mask; RED: fused row reduction), 4 = GELU class.
 // The fast class is specialised at compile time: as runtime flag tests its 32 values per thread and pass cost ~1000
 // issue cycles per wave (4 branches per 4 values), and an epilogue pass is pure issue time on 2 waves per SIMD.
-template <int CONV, int EPI, int AUXM, bool RED>
+//
+// X3 (dtype UMR_BF16X3, EPI 5): fp32-grade products from operands that arrive PRE-SPLIT into three bf16 planes per value
+// (x = h + m + l, exact for f32 data; umr_split3).  Operand rows hold [h(K) | m(K) | l(K)] (conv A: [h(Cin) | m(Cin) | l(Cin)]
+// per pixel; conv B: [plane][tap][ci]).  The K loop walks, for every 64-wide K-tile, the six plane pairs
+// (m,m) (l,h) (h,l) (m,h) (h,m) (h,h) -- the terms of (ah+am+al)(bh+bm+bl) above 2^-26 of the product -- as six ordinary bf16
+// K-tiles accumulated in f32: the main loop is the bf16 kernel unchanged (no split arithmetic in it; the 128x128 fp32 kernel of
+// gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
+// products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
+template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger) {
+    static_assert(X3 == (EPI == 5), "the plane-pair K loop and the f32 / plane epilogue (EPI 5) go together");
     constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 
     const int lrow = lane >> 3, lchk = lane & 7;
     const int hw = (CONV != 0) ? p.Ho * p.Wo : 1;
+    const int apix = X3 ? 3 * p.Cin : p.Cin;   // conv: bf16 elements per input pixel
     // ---- per-lane staging constants (tile independent).  Group-local row lr = (w*2+i)*8 + lane/8.
     unsigned vo[4][2];         // [group A0,B0,B1,A1][i]
     int trow_a[2][2];          // tile row of A group gi, instruction i (for the conv halo masks)
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 const int gch = lchk ^ ((trow >> 1) & 7);
                 trow_a[gi][i] = trow;
                 vo[g][i] = (CONV == 0) ? (unsigned)(((int64_t)trow * p.lda) * SZ + gch * 16)
-                                       : (unsigned)((int64_t)trow * p.Cin * SZ + gch * 16);
+                                       : (unsigned)((int64_t)trow * apix * SZ + gch * 16);
                 a_eff[gi][i] = vo[g][i];
                 a_tapmask[gi][i] = 0x1FFu;
             }
@@ -132,12 +142,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     }
 
     const int ktiles_per_tap = (CONV == 0) ? 0 : p.Cin / BK2;
-    const int nt = (CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap;   // K % 64 == 0 guaranteed by the dispatcher
+    const int nt = ((CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap) * (X3 ? 6 : 1);   // K % 64 == 0 guaranteed by the dispatcher
 
     // ---- staging side state
     __amdgpu_buffer_rsrc_t rsA, rsB;
     int s_it = 0;                     // tile iteration the cursor is in
     int st_tile = 0, st_tap = 0, st_ci = 0, st_par = 0;
+    int st_pp = 0, st_k = 0;          // X3: plane pair within the K-tile, K-tile index (plain)
     unsigned soffA = 0, soffB = 0;
     auto clamp31 = [](int64_t v) -> int { return v > 0x7FFFFFFFll ? 0x7FFFFFFF : (v < 0 ? 0 : (int)v); };
     auto stage_setup = [&](int it) {
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                                                     live ? clamp31((int64_t)(p.M - m0) * p.lda * SZ) : 0, 0x00020000);
         } else {
             // stride-1 'same' conv: input pixel index == output row index; origin = tap (-1,-1) of tile row 0
-            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + ((int64_t)m0 - (p.W + 1)) * p.Cin * SZ), 0,
+            rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + ((int64_t)m0 - (p.W + 1)) * apix * SZ), 0,
                                                     live ? 0x7FFFFFFF : 0, 0x00020000);
 #pragma unroll
             for (int gi = 0; gi < 2; ++gi)
@@ -174,12 +185,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // called when group 0 (A0) of a new K-tile is about to be issued
     auto stage_prep = [&]() {
         if (st_tile == nt) {   // roll over into the next output tile of this workgroup
-            st_tile = 0; st_tap = 0; st_ci = 0;
+            st_tile = 0; st_tap = 0; st_ci = 0; st_pp = 0; st_k = 0;
             ++s_it;
             stage_setup(s_it);
         }
+        // X3: planes of this K-tile's pair, 2 bits per pair: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
+        const int pa = X3 ? ((0x049 >> (2 * st_pp)) & 3) : 0;   // A planes 1,2,0,1,0,0
+        const int pb = X3 ? ((0x121 >> (2 * st_pp)) & 3) : 0;   // B planes 1,0,2,0,1,0
+        const bool next_k = !X3 || st_pp == 5;
+        if (X3) st_pp = next_k ? 0 : st_pp + 1;
         if (CONV == 0) {
-            soffA = soffB = (unsigned)(st_tile * BK2 * SZ);
+            const int kt = X3 ? st_k : st_tile;
+            soffA = (unsigned)((kt * BK2 + pa * p.K) * SZ);
+            soffB = (unsigned)((kt * BK2 + pb * p.K) * SZ);
+            if (X3 && next_k) ++st_k;
         } else {
             const int c0 = st_ci * BK2;
             const int ky = st_tap / 3, kx = st_tap - ky * 3;
@@ -188,9 +207,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     a_eff[gi][i] = ((a_tapmask[gi][i] >> st_tap) & 1u) ? vo[gi == 0 ? 0 : 3][i] : OOB;
-            soffA = (unsigned)(((ky * p.W + kx) * p.Cin + c0) * SZ);
-            soffB = (unsigned)((st_tap * p.Cin + c0) * SZ);
-            if (++st_tap == 9) { st_tap = 0; ++st_ci; }
+            soffA = (unsigned)(((ky * p.W + kx) * apix + pa * p.Cin + c0) * SZ);
+            soffB = (unsigned)((pb * 9 * p.Cin + st_tap * p.Cin + c0) * SZ);
+            if (next_k) { if (++st_tap == 9) { st_tap = 0; ++st_ci; } }
         }
     };
     auto stage_issue = [&](auto gtag, auto itag) {
@@ -432,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // fetched at the start of each epilogue (first tile: here): a load issued where it is needed would be waited for at once,
     // and vmcnt retires in order -- that wait drained the next tile's prefetched K-tiles (~1900 cycles per tile, measured
     // with s_memtime stamps).  Fetched there, everything issued before it has long landed when the epilogue ends.
-    constexpr bool BIAS_INIT = (EPI == 3 || EPI == 4);
+    constexpr bool BIAS_INIT = (EPI == 3 || EPI == 4 || EPI == 5);
     f32x4 bqn[4];
     auto fetch_bias = [&](int it_) {
         const int v_ = it_ * G + pw;
@@ -699,6 +718,59 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             pass4(std::integral_constant<int, 0>{}); pass4(std::integral_constant<int, 1>{});
             pass4(std::integral_constant<int, 2>{}); pass4(std::integral_constant<int, 3>{});
             __syncthreads();
+        } else if (EPI == 5) {
+            // X3 class: (bias already in the accumulators), ReLU, output either as f32 rows (UMR_EPI_OUT_F32) or again as three
+            // bf16 planes [h(N) | m(N) | l(N)] per row (UMR_EPI_OUT_X3: lossless for f32 values, and what the next X3 layer
+            // stages directly).  f32-staged, 8 passes of 32 rows in a runtime loop (one copy of the store code): the K loop is
+            // six times longer than the bf16 kernel's, the epilogue's share is small.
+            fetch_bias(it + 1);
+            const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
+            const bool planes = (p.flags & UMR_EPI_OUT_X3) != 0;
+#pragma unroll 1
+            for (int mt = 0; mt < 8; ++mt) {
+                if (mt > 0) __syncthreads();
+                switch (mt) {
+                    case 0: stage_rows(std::integral_constant<int, 0>{}); break;
+                    case 1: stage_rows(std::integral_constant<int, 1>{}); break;
+                    case 2: stage_rows(std::integral_constant<int, 2>{}); break;
+                    case 3: stage_rows(std::integral_constant<int, 3>{}); break;
+                    case 4: stage_rows(std::integral_constant<int, 4>{}); break;
+                    case 5: stage_rows(std::integral_constant<int, 5>{}); break;
+                    case 6: stage_rows(std::integral_constant<int, 6>{}); break;
+                    default: stage_rows(std::integral_constant<int, 7>{}); break;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int lr = (tid >> 5) + j * 16, cg = tid & 31;
+                    const int m = m0 + (lr >> 4) * 128 + mt * 16 + (lr & 15), n = n0 + cg * 8;
+                    if (m >= p.M || n >= p.N) continue;
+                    const int sw = lr & 15;
+                    f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
+                    f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], relu_floor); v1[e] = fmaxf(v1[e], relu_floor); }
+                    if (planes) {
+                        bf16x8 h, mm, l;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float x = e < 4 ? v0[e] : v1[e - 4];
+                            const bf16_t hh = (bf16_t)x;
+                            const float r1 = x - (float)hh;
+                            const bf16_t m2 = (bf16_t)r1;
+                            h[e] = hh; mm[e] = m2; l[e] = (bf16_t)(r1 - (float)m2);
+                        }
+                        T2* cp = (T2*)p.C + (int64_t)m * p.ldc + n;
+                        *(bf16x8*)cp = h;
+                        *(bf16x8*)(cp + p.N) = mm;
+                        *(bf16x8*)(cp + 2 * p.N) = l;
+                    } else {
+                        float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
+                        *(f32x4*)cp = v0;
+                        *(f32x4*)(cp + 4) = v1;
+                    }
+                }
+            }
         } else {
             // generic epilogue (every flag / activation / remap of include/umr.h): ONE copy of the store code in a
             // runtime loop over the passes -- unrolled it is ~100 KiB of instructions and runs out of the I-cache
@@ -830,6 +902,21 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     if ((d->red_w || d->no_store) && !umr_nt256p_plain_epilogue(d))
         return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class (no aux operand with the reduction)");
     const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
+#define L256PX(CV)                                                                                                     \
+    do {                                                                                                               \
+        static bool set_ = false;                                                                                      \
+        if (!set_) {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, 5, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
+            set_ = true;                                                                                               \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger); \
+    } while (0)
+    if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
+        if (d->conv == 0) L256PX(0); else L256PX(1);
+        UMR_LAUNCH_CHECK();
+        return UMR_OK;
+    }
+#undef L256PX
     if (d->conv == 0) {
         if (fast_ep) {
             if (d->red_w) L256P(0, 3, 0, true);

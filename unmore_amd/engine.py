@@ -115,6 +115,7 @@ def _rep_bias(b, reps):
 
 
 _FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch for benchmarking
+_X3_HEADS = os.environ.get("UMR_X3_HEADS", "1") != "0"            # A/B switch: fp32-mode inference heads on the bf16-plane kernel
 _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: one GEMM for the feature-map gradient of both heads
 # Backward of a head without non-linearities between its convs (objectness_net.py:119-142): "algebraic" (default) = exact
 # gradients of all eight factored tensors from three pixel reductions (no 512/1024-channel tensor is stored, read or
@@ -214,6 +215,15 @@ class Engine:
             "ct": lambda: _pack_convT(p, self.dt),
             "ct_d": lambda: _pack_convT_dgrad(p, self.dt),
         }[kind]())
+
+    def _wx3(self, P, name, kind):
+        """f32 weights as three bf16 planes per value ([N, 3K]; conv: K = (ky,kx,ci) inside each plane) for ops.gemm_nt_x3"""
+        p = P[name]
+        if kind == "lin":
+            build = lambda: ops.split3(p.detach().reshape(p.shape[0], -1).contiguous())
+        else:
+            build = lambda: ops.split3(_pack_conv3(p, torch.float32))
+        return self.cache.get((name, kind + "_x3"), p, build)
 
     def _f32(self, P, name):
         p = P[name].detach()
@@ -380,6 +390,12 @@ class Engine:
         # ---- heads (objectness_net.py:109-135)
         outs = []
         heads_saved = []
+        # fp32 (parity) mode at inference: the heads' three big layers run on the persistent 256x256 bf16 kernel with every f32
+        # value held as three bf16 planes (six plane pairs per K-tile, csrc/gemm_nt256p.hip X3) -- the same six-term products as
+        # the 128x128 fp32 kernel's in-register split (UMR_F32_X3), without the split arithmetic in the loop.  Training keeps
+        # f32 activations (its backward reads them), and the exact-f32 mode keeps the f32 MFMA.
+        x3_heads = _X3_HEADS and dt == torch.float32 and not save and ops.get_f32_mode() == "x3"
+        featp = ops.split3(feat.view(-1, 256)) if x3_heads else None
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
             if self.collapse_linear_heads and not lay["relu"]:
@@ -390,6 +406,17 @@ class Engine:
                     heads_saved.append(cs)
                 continue
             act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
+            if x3_heads:
+                b_ = lambda k: self._f32(P, f"{name}.{idx[k]}.bias")
+                h1p = ops.gemm_nt_x3(featp, self._wx3(P, f"{name}.{idx[0]}.weight", "lin"), b_(0), act=act, out_planes=True)
+                h2p = ops.gemm_nt_x3(h1p.view(B, H, W, -1), self._wx3(P, f"{name}.{idx[1]}.weight", "c3"), b_(1), act=act, conv=1, out_planes=True)
+                del h1p
+                h3 = ops.gemm_nt_x3(h2p, self._wx3(P, f"{name}.{idx[2]}.weight", "lin"), b_(2), act=act)
+                del h2p
+                w4 = self._f32(P, f"{name}.{idx[3]}.weight")
+                outs.append(ops.head_out_fwd(h3, w4.reshape(w4.shape[0], -1), b_(3), B, H, W, _ACT[lay["final"]]))
+                del h3
+                continue
             # a head that is linear up to its output activation needs none of its 512/1024-channel activations in backward
             # (exact gradients from three pixel reductions over feat, _linear_head_backward); sin is not invertible from its value
             algebraic = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"

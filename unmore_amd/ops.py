@@ -147,6 +147,58 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     return (out, out2) if c2_mode else out
 
 
+def split3(x, out=None):
+    """f32 [..., K] (rows contiguous) -> bf16 planes [..., 3K] = [h(K) | m(K) | l(K)] per row (include/umr.h, UMR_BF16X3)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K) if x.is_contiguous() else x
+    assert x2.dim() == 2
+    rows = x2.shape[0]
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (3 * K,), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().umr_split3(_p(x2), _p(out), rows, K, x2.stride(0), 3 * K, _stream()), "umr_split3")
+    return out
+
+
+def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False):
+    """fp32-grade C = act(A . B^T + bias) from operands held as three bf16 planes per f32 value (split3): Ap [M, 3K] (or NHWC
+    [nb,H,W,3*Cin] when conv == 1), Bp [N, 3K].  Returns f32 [M, N], or planes [M, 3N] bf16 with out_planes=True (what the next
+    gemm_nt_x3 layer takes).  Persistent 256x256 bf16 kernel, six plane pairs per K-tile (csrc/gemm_nt256p.hip, X3)."""
+    _need_gpu(Ap, Bp)
+    assert Ap.dtype == torch.bfloat16 and Bp.dtype == torch.bfloat16 and Bp.dim() == 2 and Bp.is_contiguous()
+    d = L.GemmDesc()
+    N, K = Bp.shape[0], Bp.shape[1] // 3
+    if conv:
+        assert conv == 1
+        nb, H, W, C3 = Ap.shape
+        Cin = C3 // 3
+        assert Ap.is_contiguous() and K == 9 * Cin
+        M_ = nb * H * W
+        d.nb, d.H, d.W, d.Cin, d.Ho, d.Wo = nb, H, W, Cin, H, W
+        d.lda = C3
+    else:
+        A2 = Ap if Ap.dim() == 2 else Ap.reshape(-1, Ap.shape[-1])
+        assert A2.stride(1) == 1 and A2.shape[1] == 3 * K
+        M_ = A2.shape[0]
+        d.lda = A2.stride(0)
+    if out_planes:
+        out = torch.empty((M_, 3 * N), dtype=torch.bfloat16, device=Ap.device)
+        flags = L.EPI_OUT_X3
+    else:
+        out = torch.empty((M_, N), dtype=torch.float32, device=Ap.device)
+        flags = L.EPI_OUT_F32
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        flags |= L.EPI_BIAS
+    d.A, d.B, d.C, d.bias = _p(Ap), _p(Bp), _p(out), _p(bias)
+    d.ldb, d.ldc = Bp.stride(0), out.stride(0)
+    d.M, d.N, d.K, d.dtype = M_, N, K, L.BF16X3
+    d.flags, d.act, d.conv = flags, act, conv
+    L.check(_timed_call(d), "umr_gemm_nt")
+    return out
+
+
 def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_remap=None, x_remap=None, lddy=None, ldx=None):
     """dW[N,K] f32 = sum_m dY[m,N]^T X[m,K]; X is NHWC [nb,H,W,Cin] when conv != 0
     (dY then is [nb*Ho*Wo, N] and dW is [N, 9*Cin] packed (ky,kx,ci))."""

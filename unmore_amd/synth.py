@@ -90,3 +90,21 @@ def object_like_fields(B, H, W, seed=0):
     sdf += np.float32(0.1) * (uniform01(f"fields:{seed}:ns", (B, H, W)) - np.float32(0.5))
     cen += np.float32(0.1) * (uniform01(f"fields:{seed}:nc", (B, 2, H, W)) - np.float32(0.5))
     return sdf.astype(np.float32), cen.astype(np.float32)
+
+
+# A randomly initialised net on noise gives identically empty eroded masks (every score map is zero and peak picking has
+# nothing to do).  The committed peak fixtures (tests/golden/make_golden_r2.py, EDITS) therefore use two documented weight
+# edits per hash-weight set that give surviving masks of varied size on the blob images: the last boundary-distance bias +=
+# shift (pre-tanh), the last centre-field layer *= scale.  bench.py --workload cfg5 uses the same nets.
+PEAK_EDITS = {"base": (0.5, 1.5), "tiny": (0.05, 2.0)}
+
+
+def peak_edited_state_dict(spec, wtag):
+    """hash weights `wtag` + PEAK_EDITS[wtag]; spec: name -> shape.  numpy f32 arrays."""
+    from .hashrng import hash_init
+    shift, scale = PEAK_EDITS[wtag]
+    sd = {k: hash_init(k, tuple(s), wtag) for k, s in spec.items()}
+    sd["sdf_prediction_head.3.bias"] = sd["sdf_prediction_head.3.bias"] + np.float32(shift)
+    sd["center_field_prediction_head.6.weight"] = sd["center_field_prediction_head.6.weight"] * np.float32(scale)
+    sd["center_field_prediction_head.6.bias"] = sd["center_field_prediction_head.6.bias"] * np.float32(scale)
+    return sd

@@ -172,6 +172,14 @@ int umr_pixel_shuffle(const void* src, void* dst, int B, int H, int W, int s, in
 int umr_zero_stuff2(const void* dy, void* out, int B, int H, int W, int Ho, int Wo, int C, int dtype, umr_stream_t stream);
 int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int64_t* src_strides, int64_t src_offset,
                  int dtype_in, int dtype_out, int accumulate, umr_stream_t stream);
+/* many permutes in one launch (the per-step refresh of the kernel-layout weight copies after the optimizer step).
+ * table_dev: n entries IN DEVICE MEMORY, sorted by blk_start; entry e covers blocks [blk_start_e, blk_start_{e+1}) with
+ * blk_start_0 = 0 and ceil(elements_e / 2048) blocks each; total_blocks = the sum.  Same element semantics as umr_permute4
+ * (dst[i0,i1,i2,i3] = src[soff + sum i_k * sstride[k]], cast to dtype_out; no accumulate). */
+typedef struct umr_perm_entry {
+    const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start;
+} umr_perm_entry;
+int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, umr_stream_t stream);
 int umr_segsum(const void* x, void* out, int R, int reps, int64_t rep_stride, int64_t seg_stride, int C, int dtype_in,
                int out_f32, int accumulate, umr_stream_t stream);
 int umr_fill_cls(void* tokens, const float* cls, const float* pos0, int B, int64_t batch_stride, int D, int dtype, umr_stream_t stream);

@@ -454,3 +454,45 @@ def test_gemm_nt_x3_refuses_what_it_does_not_implement():
     Bp = ops.split3(_rnd((16, 96), torch.float32, dev, 2))
     with pytest.raises(RuntimeError, match="BF16X3"):
         ops.gemm_nt_x3(Ap, Bp)
+
+
+@pytest.mark.parametrize("M", [64 * 577, 1000, 224 * 3 + 5])
+def test_tile_height_does_not_change_results(M, monkeypatch):
+    """The persistent 256x256 kernel picks 256, 224 or 192 output rows per tile for plain GEMMs so that the tile count fills whole
+    rounds of the chip (csrc/gemm_nt256p.hip, `bm`).  Every output element's K sum is the same instruction sequence whatever the
+    tile it lands in, so all epilogue classes must give BIT-IDENTICAL results for the three heights -- and match torch."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    D = 768
+    x = _rnd((M, D), torch.bfloat16, dev, 71)
+    w = _rnd((D, D), torch.bfloat16, dev, 72, D ** -0.5)
+    w4 = _rnd((4 * D, D), torch.bfloat16, dev, 73, D ** -0.5)
+    bias = _rnd((D,), torch.float32, dev, 74)
+    b4 = _rnd((4 * D,), torch.float32, dev, 75)
+    aux = _rnd((M, D), torch.bfloat16, dev, 76)
+    redw = _rnd((2, 4 * D), torch.float32, dev, 77)
+    monkeypatch.setenv("UMR_GEMM_TILE", "256")   # small M would otherwise go to the 128x128 kernel
+
+    def run():
+        outs = [ops.gemm_nt(x, w, bias, act=L.ACT_RELU),                      # fast class
+                ops.gemm_nt(x, w, bias, aux=aux),                             # residual add
+                ops.gemm_nt(x, w, None, aux=aux, mask_relu=True),             # ReLU mask
+                ops.gemm_nt(x, w, None, aux=aux, mask_dgelu=True),            # GELU' class
+                ops.gemm_nt(x, w, bias, out_f32=True)]                        # generic class
+        outs += list(ops.gemm_nt(x, w4, b4, act=L.ACT_GELU, c2_mode=2))       # GELU class, two outputs
+        outs += list(ops.gemm_nt(x, w4, b4, act=L.ACT_RELU, red_w=redw))      # fused row reduction
+        outs.append(ops.gemm_nt(x, w4, b4, act=L.ACT_RELU, red_w=redw, no_store=True)[1])
+        torch.cuda.synchronize()
+        return outs
+
+    res = {}
+    for bm in (256, 224, 192):
+        monkeypatch.setenv("UMR_NT256_BM", str(bm))
+        res[bm] = run()
+    monkeypatch.delenv("UMR_NT256_BM")
+    res[0] = run()   # the library's own choice
+    for bm in (224, 192, 0):
+        for a, b in zip(res[256], res[bm]):
+            assert torch.equal(a, b), bm
+    ref = F.relu(x.float() @ w.float().t() + bias)
+    torch.testing.assert_close(res[224][0].float(), ref, atol=3e-2, rtol=3e-2)

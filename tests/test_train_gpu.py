@@ -379,3 +379,48 @@ def test_sizes_that_are_not_multiples_of_the_patch_follow_the_reference():
     with pytest.raises((AssertionError, RuntimeError)):
         with torch.no_grad():
             net(images=torch.zeros(1, 3, 48, 48, device="cuda:0"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_repack_equals_lazy_repack(dtype, monkeypatch):
+    """After the Adam launch every kernel-layout weight copy is refreshed by ONE umr_permute4_batched launch (PackCache.refresh)
+    instead of being dropped and re-packed weight by weight: four steps either way end in bit-identical weights and losses."""
+    from unmore_amd import trainer
+    B, H, W = 2, 64, 64
+    img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=4))
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(trainer, "_BATCHED_REPACK", mode)
+        net, _ = _net("dpt_tiny", "tiny", dtype)
+        step = trainer.TrainStep(net, lr=1e-3)
+        losses = [step.step(img, cf, sdf, sal).clone() for _ in range(4)]
+        if mode:
+            eng = net._engine()
+            assert eng.cache._replay is not None and len(eng.cache._replay[1]) > 40 and not eng.cache._o
+        res[mode] = (torch.stack(losses).cpu(), step.flat_p.clone().cpu())
+    assert torch.equal(res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+
+
+def test_permute4_batched_equals_single_launches():
+    from unmore_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    recipes, refs = [], []
+    for i, (co, ci) in enumerate([(8, 16), (33, 7), (256, 64), (5, 3)]):
+        w = torch.randn((co, ci, 3, 3), generator=g).to(dev)
+        st = w.stride()
+        for dt in (torch.float32, torch.bfloat16):
+            dst = torch.zeros((co, 9 * ci), dtype=dt, device=dev)
+            dims, strides = (co, 3, 3, ci), (st[0], st[2], st[3], st[1])
+            refs.append(ops.permute4(w, torch.empty_like(dst), dims, strides))
+            recipes.append((w, dst, dims, strides, 0))
+    big = torch.randn(300001, generator=g).to(dev)      # a cast (1-D) with a ragged tail, more than one block
+    dstb = torch.zeros(300001, dtype=torch.bfloat16, device=dev)
+    refs.append(big.to(torch.bfloat16))
+    recipes.append((big, dstb, (1, 1, 1, 300001), (0, 0, 0, 1), 0))
+    launch = ops.permute4_batched(recipes)
+    launch()
+    torch.cuda.synchronize()
+    for (src, dst, *_), ref in zip(recipes, refs):
+        assert torch.equal(dst, ref)

@@ -187,6 +187,36 @@ __global__ void permute4_kernel(const TI* __restrict__ src, TO* __restrict__ dst
     }
 }
 
+// Many permutes in ONE launch (the per-step refresh of every kernel-layout weight copy after the optimizer step: ~180 launches
+// of a few microseconds each otherwise).  table[e] describes one permute and the first block that works on it; a block finds
+// its entry by binary search and handles 2048 consecutive destination elements.
+struct PermEntry { const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start; };
+static_assert(sizeof(PermEntry) == sizeof(umr_perm_entry), "umr_perm_entry layout");
+__global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    const int64_t b = blockIdx.x;
+    while (lo < hi) {   // last entry with blk_start <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const PermEntry e = table[lo];
+    const int64_t total = (int64_t)e.d[0] * e.d[1] * e.d[2] * e.d[3];
+    const int64_t base = (b - e.blk_start) * 2048;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t idx = base + j * 256 + threadIdx.x;
+        if (idx >= total) break;
+        int64_t r = idx;
+        const int i3 = (int)(r % e.d[3]); r /= e.d[3];
+        const int i2 = (int)(r % e.d[2]); r /= e.d[2];
+        const int i1 = (int)(r % e.d[1]);
+        const int i0 = (int)(r / e.d[1]);
+        const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
+        const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
+        if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+    }
+}
+
 // ---------------------------------------------------------------- small reductions / fills
 // out[r][c] (f32 or T) = sum_{k<reps} x[(r*reps + k)*ld_rep + c]   (segment sum over `reps` consecutive row blocks)
 template <typename T, typename TO>
@@ -568,6 +598,13 @@ extern "C" int umr_permute4(const void* src, void* dst, const int32_t* dst_dims,
     else if (dtype_in == UMR_BF16 && dtype_out == UMR_F32) hipLaunchKernelGGL((permute4_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, pd, accumulate);
     else if (dtype_in == UMR_BF16 && dtype_out == UMR_BF16) hipLaunchKernelGGL((permute4_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, pd, accumulate);
     else return umr_set_error(UMR_ERR_INVALID, "permute4: dtype");
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, umr_stream_t stream) {
+    UMR_CHECK_ARG(table_dev && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "permute4_batched: bad arguments");
+    hipLaunchKernelGGL(permute4_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PermEntry*)table_dev, n);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

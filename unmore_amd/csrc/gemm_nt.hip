@@ -399,13 +399,9 @@ int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
-static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("UMR_GEMM_TILE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
+static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch
+    const char* e = getenv("UMR_GEMM_TILE");
+    return e ? atoi(e) : 0;
 }
 
 static bool uses_256(const umr_gemm_desc* d) {

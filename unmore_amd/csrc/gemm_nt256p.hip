@@ -76,7 +76,12 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
 // products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
 template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger) {
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm) {
+    // bm: output rows per tile, 256 | 224 | 192 (plain GEMMs only).  A persistent grid of G workgroups needs ceil(tiles / G) tile
+    // times however full the last round is: the transformer GEMMs at 36,928 tokens have 435 (N = 768) or 1305 (N = 2304) tiles of
+    // 256 rows for 256 CUs -- 2 resp. 6 rounds of which the last is 70 % / 10 % full.  With 224-row tiles they have 495 / 1485 tiles:
+    // the same number of rounds, each 1/8 shorter (the host picks bm, umr_launch_gemm_nt256p).  Rows >= bm of a tile are outside
+    // the A descriptor (zero-filled by the DMA), their MFMAs are skipped by the waves that own them and their stores masked.
     static_assert(X3 == (EPI == 5), "the plane-pair K loop and the f32 / plane epilogue (EPI 5) go together");
     constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -155,12 +160,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         const bool live = it < n_my;
         const int v = live ? it * G + pw : 0;
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
-        const int m0 = tm * BM2, n0 = tn * BN2;
+        const int m0 = tm * bm, n0 = tn * BN2;
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (int64_t)n0 * p.ldb * SZ), 0,
                                                 live ? clamp31((int64_t)(p.N - n0) * p.ldb * SZ) : 0, 0x00020000);
         if (CONV == 0) {
             rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + (int64_t)m0 * p.lda * SZ), 0,
-                                                    live ? clamp31((int64_t)(p.M - m0) * p.lda * SZ) : 0, 0x00020000);
+                                                    live ? clamp31((int64_t)((p.M - m0 < bm) ? (p.M - m0) : bm) * p.lda * SZ) : 0, 0x00020000);
         } else {
             // stride-1 'same' conv: input pixel index == output row index; origin = tap (-1,-1) of tile row 0
             rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A + ((int64_t)m0 - (p.W + 1)) * apix * SZ), 0,
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 
     f32x4 acc[8][4];
     const int wr = w >> 2, wc = w & 3;
+    const int dead_blocks = (CONV == 0 && wr == 1) ? ((BM2 - bm) >> 4) : 0;   // wave-uniform: 0, 2 or 4
     const int frow = lane & 15, fq = lane >> 4;
     int a_ad[2], b_ad[2];
 #pragma unroll
@@ -271,6 +277,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     MFMA(acc[M0 + 3][N0 + 0], FB[1][0], fa[1][3]); MFMA(acc[M0 + 3][N0 + 1], FB[1][1], fa[1][3]);   \
     QPRIO(0)
 #define QUADRANT(M0, N0, FB, Gp) QUADRANT_D(M0, N0, FB, STAGE_DMA(Gp, 0), STAGE_DMA(Gp, 1))
+    // bm < 256: the waves that own tile rows 128..255 (wr == 1) have `dead_blocks` (2 at bm 224, 4 at bm 192) 16-row blocks without
+    // rows at the end of their 128: the upper quadrants (blocks 4..7) run their first two blocks only, or only their DMA slots
+#define QUADRANT_S(M0, N0, FB, Gp)                                                                  \
+    QPRIO(1)                                                                                        \
+    MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(Gp, 0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 0][N0 + 0], FB[1][0], fa[1][0]); MFMA(acc[M0 + 0][N0 + 1], FB[1][1], fa[1][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    STAGE_DMA(Gp, 1);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    QPRIO(0)
+#define QUADRANT_HI(N0, FB, Gp)                                                  \
+    if (dead_blocks == 0) { QUADRANT(4, N0, FB, Gp) }                            \
+    else if (dead_blocks == 2) { QUADRANT_S(4, N0, FB, Gp) }                     \
+    else { STAGE_DMA(Gp, 0); STAGE_DMA(Gp, 1); }
 
 #define PHASE_SYNC() PHASE_SYNC_N(6)
     // Two-phase form of the same K-tile (PH2): phases (Q0,Q1) and (Q2,Q3) merged -- 2 barriers instead of 4.  All waves
@@ -341,11 +366,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
         PHASE_SYNC();
         PT(4);
-        QUADRANT(4, 2, fb1, 0)
+        QUADRANT_HI(2, fb1, 0)
         PT(5);
         PHASE_SYNC();
         PT(6);
-        QUADRANT(4, 0, fb0, 1)
+        QUADRANT_HI(0, fb0, 1)
         PT(7);
     };
 
@@ -512,7 +537,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         // ---- epilogue of output tile `it`; the next tile's first K-tiles are already in flight
         const int v = it * G + pw;
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
-        const int m0 = tm * BM2, n0 = tn * BN2;
+        const int m0 = tm * bm, n0 = tn * BN2;
+        const int m_end = (p.M - m0 < bm) ? p.M : m0 + bm;   // rows of this tile that exist
         if (EPI == 3) {
             // fast class: (bias already in the accumulators), aux add / ReLU mask, ReLU.  The math runs on the accumulators in
             // their fragment layout, the results are staged as bf16 -- 64 tile rows per pass, 4 passes / 8 barriers, half the
@@ -548,7 +574,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
                         const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
                         u32x4 a = {0u, 0u, 0u, 0u};
-                        if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                        if (m < m_end && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
                         axc[PS % 3][j] = a;
                     }
                 }
@@ -584,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
                         rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
                         const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
-                        if (fq == 0 && m < p.M && n0 + wc * 64 < p.N) {
+                        if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
                             float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
                             ro[0] = rs0;
                             if (p.red_c == 2) ro[1] = rs1;
@@ -609,7 +635,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], a[e]);
                     }
-                    if (m < p.M && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
+#ifdef UMR_EXP_NT_STORE   // experiment (tools/energy_probe.py): non-temporal C stores -- C is re-read only by a much later kernel
+                    if (m < m_end && n < p.N && !p.no_store) __builtin_nontemporal_store(o, (u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n));
+#else
+                    if (m < m_end && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
+#endif
                 }
             };
             if (RED && p.no_store) {
@@ -631,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
                     rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
                     const int m = m0 + wr * 128 + mt * 16 + frow;
-                    if (fq == 0 && m < p.M && n0 + wc * 64 < p.N) {
+                    if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
                         float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
                         ro[0] = rs0;
                         if (p.red_c == 2) ro[1] = rs1;
@@ -661,7 +691,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
                         const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
                         u32x4 a = {0u, 0u, 0u, 0u};
-                        if (m < p.M && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                        if (m < m_end && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
                         axc[PS % 3][j] = a;
                     }
                 }
@@ -701,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                             for (int e = 0; e < 4; ++e) o[e] = mul_dgelu_bf16x2(o[e], a[e]);
                         }
-                        if (m < p.M && n < p.N) *(u32x4*)(dst + (int64_t)m * ld + n) = o;
+                        if (m < m_end && n < p.N) *(u32x4*)(dst + (int64_t)m * ld + n) = o;
                     }
                 };
                 if (PS > 0) __syncthreads();
@@ -744,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 for (int j = 0; j < 2; ++j) {
                     const int lr = (tid >> 5) + j * 16, cg = tid & 31;
                     const int m = m0 + (lr >> 4) * 128 + mt * 16 + (lr & 15), n = n0 + cg * 8;
-                    if (m >= p.M || n >= p.N) continue;
+                    if (m >= m_end || n >= p.N) continue;
                     const int sw = lr & 15;
                     f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
                     f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
@@ -794,7 +824,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 for (int j = 0; j < 2; ++j) {
                     const int lr = (tid >> 5) + j * 16, cg = tid & 31;
                     const int m = m0 + (lr >> 4) * 128 + mt * 16 + (lr & 15), n = n0 + cg * 8;
-                    if (m >= p.M || n >= p.N) continue;
+                    if (m >= m_end || n >= p.N) continue;
                     const int sw = lr & 15;
                     const f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
                     const f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
@@ -815,6 +845,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     if (dbg) { dbgp[138] = __builtin_readcyclecounter(); dbgp[139] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 #undef QUADRANT
+#undef QUADRANT_S
+#undef QUADRANT_HI
 #undef TS
 #undef PT
 #undef QUADRANT_D
@@ -867,7 +899,28 @@ static bool umr_nt256p_gelu_epilogue(const umr_gemm_desc* d) {
 
 // eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
-    const int tiles_m = (d->M + BM2 - 1) / BM2, tiles_n = (d->N + BN2 - 1) / BN2;
+    const int tiles_n = (d->N + BN2 - 1) / BN2;
+    const int cus = num_cus();
+    // rows per tile (see the kernel): for plain GEMMs of a few rounds, the bm in {256, 224, 192} with the smallest
+    // rounds x tile time (tile time ~ a fixed quarter -- epilogue, first-load latency -- plus the K loop, which scales with bm);
+    // the waves that skip blocks are the non-ahead half, so the stagger has to be on.  UMR_NT256_BM forces a value.
+    static int stagger = -1;
+    const char* bm_e = getenv("UMR_NT256_BM");   // read per launch: tests switch it inside one process
+    const int bm_env = bm_e ? atoi(bm_e) : 0;
+    if (stagger < 0) { const char* e = getenv("UMR_NT256_STAGGER"); stagger = e ? atoi(e) : 1; }   // A/B switch (0 = all waves in lock-step)
+    int bm = BM2;
+    if (d->conv == 0 && d->dtype == UMR_BF16) {
+        if (bm_env == 256 || bm_env == 224 || bm_env == 192) bm = bm_env;
+        else if ((int64_t)((d->M + BM2 - 1) / BM2) * tiles_n <= 16ll * cus) {
+            double best = 1e300;
+            for (int c = 256; c >= 192; c -= 32) {
+                const int64_t t = (int64_t)((d->M + c - 1) / c) * tiles_n;
+                const double cost = (double)((t + cus - 1) / cus) * (0.25 + 0.75 * c / 256.0);
+                if (cost < best - 1e-9) { best = cost; bm = c; }
+            }
+        }
+    }
+    const int tiles_m = (d->M + bm - 1) / bm;
     const int64_t total = (int64_t)tiles_m * tiles_n;
     // One workgroup fits a CU (160 KiB LDS).  The grid is a small multiple of the CU count, not exactly the CU count: if
     // some CUs are busy when the kernel starts (an RCCL all-reduce of the previous gradient bucket runs beside backward),
@@ -875,10 +928,8 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     // others -- up to 2x the kernel time.  With several shorter workgroups per CU the dispatcher balances them itself; a
     // workgroup still walks >= 32 tiles, so the cross-tile prefetch keeps its value, and workgroups that run together on
     // one XCD still own neighbouring tiles (pw in the kernel).  UMR_NT256_WG_PER_CU overrides the factor.
-    static int wg_per_cu = -1, stagger = -1;
+    static int wg_per_cu = -1;
     if (wg_per_cu < 0) { const char* e = getenv("UMR_NT256_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 0; }
-    if (stagger < 0) { const char* e = getenv("UMR_NT256_STAGGER"); stagger = e ? atoi(e) : 1; }   // A/B switch (0 = all waves in lock-step)
-    const int cus = num_cus();
     int64_t kf = wg_per_cu > 0 ? wg_per_cu : total / ((int64_t)cus * 32);
     if (kf < 1) kf = 1;
     if (kf > 8) kf = 8;
@@ -895,7 +946,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, AX, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger);     \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm);     \
     } while (0)
     // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged; one instantiation per aux mode, plus the fused
     // row reduction); EPI 4: the GELU class (plain GEMM only); EPI 1: everything else
@@ -909,7 +960,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, 5, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger); \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm); \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
         if (d->conv == 0) L256PX(0); else L256PX(1);

@@ -39,11 +39,13 @@ class PackCache:
     stream and entry -- afterwards the stream's own order covers it)."""
 
     def __init__(self):
-        self._c = {}
+        self._c = {}           # key -> [version, value, event, synced streams, recipe, param]: replayable packs
+        self._o = {}           # same without a recipe: rebuilt lazily after refresh()
+        self._replay = None    # (launcher, keys) of the batched refresh, built on first use
 
     def get(self, key, param, build):
         ver = (param._version, param.data_ptr())
-        hit = self._c.get(key)
+        hit = self._c.get(key) or self._o.get(key)
         if param.is_cuda:
             st = torch.cuda.current_stream(param.device)
             sid = st.cuda_stream
@@ -54,16 +56,56 @@ class PackCache:
                 st.wait_event(hit[2])
                 hit[3].add(sid)
             return hit[1]
-        val = build()
+        # record what the build launches: a pack that is exactly ONE permute / cast into the returned tensor can be replayed by
+        # refresh() (every pack helper below is); anything else is rebuilt lazily after a refresh
+        rec = []
+        prev, ops._pack_recorder = ops._pack_recorder, rec
+        try:
+            val = build()
+        finally:
+            ops._pack_recorder = prev
+        recipe = rec[0] if (len(rec) == 1 and torch.is_tensor(val) and rec[0][1].data_ptr() == val.data_ptr()) else None
         ev = None
         if st is not None:
             ev = torch.cuda.Event()
             ev.record(st)
-        self._c[key] = (ver, val, ev, {sid})
+        entry = [ver, val, ev, {sid}, recipe, param]
+        self._c.pop(key, None)
+        self._o.pop(key, None)
+        if recipe is not None and st is not None:
+            self._c[key] = entry
+            self._replay = None
+        else:
+            self._o[key] = entry
         return val
 
     def clear(self):
         self._c.clear()
+        self._o.clear()
+        self._replay = None
+
+    def refresh(self):
+        """The parameters were updated IN PLACE by a kernel torch does not see (TrainStep's Adam launch): re-run every pack into
+        its existing destination in ONE launch (umr_permute4_batched) instead of dropping the copies and re-packing ~180
+        weights one launch each during the next step.  Entries that are not a single permute are dropped (rebuilt lazily)."""
+        self._o.clear()
+        if not self._c:
+            return
+        if any(e[5].data_ptr() != e[0][1] for e in self._c.values()):   # a parameter's storage moved: the recipes are stale
+            self.clear()
+            return
+        if self._replay is None:
+            keys = list(self._c)
+            self._replay = (ops.permute4_batched([self._c[k][4] for k in keys]), keys)
+        launch, keys = self._replay
+        launch()
+        st = torch.cuda.current_stream(self._c[keys[0]][5].device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        for k in keys:
+            e = self._c[k]
+            e[0] = (e[5]._version, e[5].data_ptr())
+            e[2], e[3] = ev, {st.cuda_stream}
 
 
 def _pack_linear(w, dt):  # [N,K] -> [N,K] T

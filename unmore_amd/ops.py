@@ -338,9 +338,40 @@ def zero_stuff2(dy, H, W):
     return out
 
 
+# recorder for engine.PackCache: while a list is installed here, every permute4 / cast is appended to it as a replayable recipe
+# (src tensor, dst tensor, dims, strides, offset) -- the per-step refresh of all packed weight copies replays them in ONE launch
+_pack_recorder = None
+
+
+def permute4_batched(recipes):
+    """Replays recorded permutes (list of (src, dst, dims, strides, offset)) in one launch.  Returns a callable that launches
+    it again on the current stream (the device-side table is built once)."""
+    import numpy as np
+    n = len(recipes)
+    arr = (L.PermEntry * n)()
+    blk = 0
+    for i, (src, dst, dims, strides, off) in enumerate(recipes):
+        e = arr[i]
+        e.src, e.dst = src.data_ptr(), dst.data_ptr()
+        for k in range(4):
+            e.d[k], e.sstride[k] = dims[k], strides[k]
+        e.soff, e.dtype_in, e.dtype_out, e.blk_start = off, _DT[src.dtype], _DT[dst.dtype], blk
+        blk += (dims[0] * dims[1] * dims[2] * dims[3] + 2047) // 2048
+    host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+    table = host.to(recipes[0][1].device)
+    keep = [r[0] for r in recipes] + [r[1] for r in recipes]   # the table holds raw pointers: keep the tensors alive with it
+
+    def launch():
+        L.check(L.lib().umr_permute4_batched(_p(table), n, blk, _stream()), "umr_permute4_batched")
+    launch.keep = keep
+    return launch
+
+
 def permute4(src, dst, dst_dims, src_strides, src_offset=0, accumulate=False):
     """dst[i0,i1,i2,i3] = src.flat[src_offset + sum i_k*src_strides[k]] (cast to dst dtype)."""
     _need_gpu(src, dst)
+    if _pack_recorder is not None and not accumulate:
+        _pack_recorder.append((src, dst, tuple(dst_dims), tuple(src_strides), src_offset))
     dims = (ctypes.c_int32 * 4)(*dst_dims)
     strides = (ctypes.c_int64 * 4)(*src_strides)
     L.check(L.lib().umr_permute4(_p(src), _p(dst), ctypes.cast(dims, ctypes.c_void_p), ctypes.cast(strides, ctypes.c_void_p),
@@ -366,6 +397,8 @@ def cast(src, dtype, scale=1.0, out=None):
     assert src.is_contiguous()
     if out is None:
         out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    if _pack_recorder is not None and scale == 1.0:
+        _pack_recorder.append((src, out, (1, 1, 1, src.numel()), (0, 0, 0, 1), 0))
     L.check(L.lib().umr_cast(_p(src), _p(out), src.numel(), scale, _DT[src.dtype], _DT[out.dtype], _stream()), "umr_cast")
     return out
 

@@ -11,8 +11,12 @@ overlap the remaining backward, and (b) Adam is a single kernel launch over the 
 buffers.  `model.state_dict()` is unaffected (parameters are views)."""
 import torch
 
+import os
+
 from . import ops
 from .parallel import BucketedAllReduce
+
+_BATCHED_REPACK = os.environ.get("UMR_BATCHED_REPACK", "1") != "0"   # A/B switch: 0 = drop the packed copies, re-pack lazily (round 2)
 
 
 def _stage_of(name, cfg):
@@ -103,7 +107,11 @@ class TrainStep:
         self.iter += 1
         ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.iter, self.current_lr_for_step(), self.betas[0], self.betas[1],
                       self.eps, scale)
-        eng.cache.clear()  # packed (kernel-layout) weight copies are stale after the in-place update
+        # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
+        if _BATCHED_REPACK:
+            eng.cache.refresh()
+        else:
+            eng.cache.clear()
         return out5
 
     # ---- checkpoint / resume (train_objectness_net.py:118-123,268-275: {'model_state_dict', 'optimizer_state_dict', 'iter'})

@@ -103,8 +103,9 @@ typedef struct umr_gemm_desc {
  * caveats) computed as six bf16 K-tiles per logical K-tile on the persistent 256x256 kernel, with no split arithmetic in the
  * loop.  A: [M][3K] bf16 (lda >= 3K), or NHWC with 3*Cin bf16 per pixel [h(Cin) | m(Cin) | l(Cin)] when conv == 1;
  * B: [N][3K] bf16 (ldb >= 3K; conv: K = 9*Cin ordered (ky,kx,ci) inside each plane).  K (conv: Cin) must be a multiple of 64,
- * N of 8; epilogue: bias, ReLU, and exactly one of UMR_EPI_OUT_F32 (C f32 [M][N]) / UMR_EPI_OUT_X3 (C planes [M][3N] bf16);
- * no aux / remap / C2 / reduction.  Anything else returns UMR_ERR_UNSUPPORTED. */
+ * N of 8; epilogue: bias, ReLU, and exactly one of UMR_EPI_OUT_F32 (C f32 [M][N]) / UMR_EPI_OUT_X3 (C planes [M][3N] bf16) -- or,
+ * for a plain GEMM, the fused row reduction red_* with no_store = 1 (dot products of the f32 values, C never stored);
+ * no aux / remap / C2.  Anything else returns UMR_ERR_UNSUPPORTED. */
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
@@ -173,13 +174,19 @@ int umr_zero_stuff2(const void* dy, void* out, int B, int H, int W, int Ho, int 
 int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int64_t* src_strides, int64_t src_offset,
                  int dtype_in, int dtype_out, int accumulate, umr_stream_t stream);
 /* many permutes in one launch (the per-step refresh of the kernel-layout weight copies after the optimizer step).
- * table_dev: n entries IN DEVICE MEMORY, sorted by blk_start; entry e covers blocks [blk_start_e, blk_start_{e+1}) with
- * blk_start_0 = 0 and ceil(elements_e / 2048) blocks each; total_blocks = the sum.  Same element semantics as umr_permute4
- * (dst[i0,i1,i2,i3] = src[soff + sum i_k * sstride[k]], cast to dtype_out; no accumulate). */
+ * table_dev: n entries IN DEVICE MEMORY, sorted by blk_start; entry e covers blocks [blk_start_e, blk_start_{e+1}), blk_start_0 = 0;
+ * total_blocks = the sum.  Same element semantics as umr_permute4 (dst[i0,i1,i2,i3] = src[soff + sum i_k * sstride[k]], cast to
+ * dtype_out; no accumulate).  Block shape per entry: e[3] == 0 -> linear, ceil(elements / 2048) blocks of 2048 consecutive
+ * destination elements; otherwise TILED: a block handles the hyper-rectangle e[0] x e[1] x e[2] x e[3] (product <= 4608) of the
+ * destination index space, read in source-address order (ord[] = the four dimensions by ascending |sstride|) through LDS --
+ * prod_k ceil(d[k] / e[k]) blocks, tile coordinate of dimension 3 fastest.  Use tiles when the innermost destination dimension
+ * is strided in the source (transposes). */
 typedef struct umr_perm_entry {
     const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start;
+    int32_t e[4]; int32_t ord[4];
 } umr_perm_entry;
-int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, umr_stream_t stream);
+/* blk_entry_dev: optional int32[total_blocks] in device memory, the entry index of every block (saves the per-block search) */
+int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, const int32_t* blk_entry_dev, umr_stream_t stream);
 int umr_segsum(const void* x, void* out, int R, int reps, int64_t rep_stride, int64_t seg_stride, int C, int dtype_in,
                int out_f32, int accumulate, umr_stream_t stream);
 int umr_fill_cls(void* tokens, const float* cls, const float* pos0, int B, int64_t batch_stride, int D, int dtype, umr_stream_t stream);

@@ -447,6 +447,23 @@ def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored):
     torch.testing.assert_close(out.double(), ref, atol=2e-5, rtol=2e-5)
 
 
+def test_gemm_nt_x3_fused_row_reduction():
+    """the 1024 -> {1,2} head output layer folded into the planes GEMM (inference: C never stored) vs float64"""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    M, N, K = 40000 + 37, 1024, 512
+    A = _rnd((M, K), torch.float32, dev, 51)
+    B = _rnd((N, K), torch.float32, dev, 52, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 53)
+    for c in (1, 2):
+        rw = _rnd((c, N), torch.float32, dev, 54 + c, N ** -0.5)
+        b4 = _rnd((c,), torch.float32, dev, 57)
+        parts = ops.gemm_nt_x3(ops.split3(A), ops.split3(B), bias, act=L.ACT_RELU, red_w=rw)
+        out = ops.head_out_finish(parts, b4, 1, 1, M, L.ACT_NONE)          # [1, c, 1, M]
+        ref = F.relu(A.double() @ B.double().t() + bias.double()) @ rw.double().t() + b4.double()
+        torch.testing.assert_close(out[0, :, 0, :].t().double(), ref, atol=2e-5, rtol=2e-5)
+
+
 def test_gemm_nt_x3_refuses_what_it_does_not_implement():
     from unmore_amd import ops
     dev = _dev()

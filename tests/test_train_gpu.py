@@ -403,24 +403,45 @@ def test_batched_repack_equals_lazy_repack(dtype, monkeypatch):
 
 
 def test_permute4_batched_equals_single_launches():
-    from unmore_amd import ops
+    """umr_permute4_batched (linear and LDS-tiled block shapes, ragged edges) against one umr_permute4 launch per tensor: the
+    engine's own pack recipes -- conv weights to [co][ky][kx][ci], the flipped data-gradient form [ci][2-ky][2-kx][co], Linear
+    transposes of row-strided slices, bias replication, plain casts."""
+    from unmore_amd import engine, ops
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     recipes, refs = [], []
-    for i, (co, ci) in enumerate([(8, 16), (33, 7), (256, 64), (5, 3)]):
+
+    def record(build):
+        rec = []
+        ops._pack_recorder = rec
+        try:
+            ref = build()
+        finally:
+            ops._pack_recorder = None
+        assert len(rec) == 1
+        src, dst, dims, strides, off = rec[0]
+        refs.append(ref.clone())
+        recipes.append((src, torch.zeros_like(dst), dims, strides, off))
+
+    for co, ci in [(8, 16), (33, 7), (256, 64), (130, 70), (512, 512)]:
         w = torch.randn((co, ci, 3, 3), generator=g).to(dev)
-        st = w.stride()
         for dt in (torch.float32, torch.bfloat16):
-            dst = torch.zeros((co, 9 * ci), dtype=dt, device=dev)
-            dims, strides = (co, 3, 3, ci), (st[0], st[2], st[3], st[1])
-            refs.append(ops.permute4(w, torch.empty_like(dst), dims, strides))
-            recipes.append((w, dst, dims, strides, 0))
+            record(lambda: engine._pack_conv3(w, dt))
+            record(lambda: engine._pack_conv3_dgrad(w, dt))
+    wl = torch.randn((300, 1536), generator=g).to(dev)
+    record(lambda: engine._pack_linear(wl, torch.bfloat16))
+    record(lambda: engine._pack_linear_t(wl, torch.bfloat16))
+    record(lambda: engine._pack_linear_t(wl[:, :768], torch.bfloat16))       # row-strided slice (the readout projection halves)
+    record(lambda: engine._pack_linear_t(wl[:, 768:], torch.float32))
+    wt = torch.randn((96, 96, 4, 4), generator=g).to(dev)
+    record(lambda: engine._pack_convT(wt, torch.bfloat16))
+    record(lambda: engine._pack_convT_dgrad(wt, torch.bfloat16))
+    record(lambda: engine._rep_bias(torch.randn(96, generator=g).to(dev), 16))
     big = torch.randn(300001, generator=g).to(dev)      # a cast (1-D) with a ragged tail, more than one block
-    dstb = torch.zeros(300001, dtype=torch.bfloat16, device=dev)
-    refs.append(big.to(torch.bfloat16))
-    recipes.append((big, dstb, (1, 1, 1, 300001), (0, 0, 0, 1), 0))
+    record(lambda: ops.cast(big, torch.bfloat16))
+    assert sum(ops._perm_tile(r[2], r[3]) is not None for r in recipes) >= 10 and any(ops._perm_tile(r[2], r[3]) is None for r in recipes)
     launch = ops.permute4_batched(recipes)
     launch()
     torch.cuda.synchronize()
-    for (src, dst, *_), ref in zip(recipes, refs):
-        assert torch.equal(dst, ref)
+    for i, ((src, dst, *_), ref) in enumerate(zip(recipes, refs)):
+        assert torch.equal(dst, ref), i

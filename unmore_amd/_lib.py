@@ -40,7 +40,7 @@ class GemmTnDesc(ctypes.Structure):
 
 class PermEntry(ctypes.Structure):   # umr_perm_entry
     _fields_ = [("src", _vp), ("dst", _vp), ("d", _i32 * 4), ("sstride", _i64 * 4), ("soff", _i64), ("dtype_in", _i32), ("dtype_out", _i32),
-                ("blk_start", _i64)]
+                ("blk_start", _i64), ("e", _i32 * 4), ("ord", _i32 * 4)]
 
 
 def build(verbose=False, jobs=8):
@@ -103,7 +103,7 @@ _SIGS = {
     "umr_linear_head_bwd_weight_workspace": [_i64, _i32],
     "umr_linear_head_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
-    "umr_permute4_batched": [_vp, _i32, _i64, _vp],
+    "umr_permute4_batched": [_vp, _i32, _i64, _vp, _vp],
     "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "umr_set_f32_mode": [_i32],
     "umr_get_f32_mode": [],

@@ -189,31 +189,102 @@ __global__ void permute4_kernel(const TI* __restrict__ src, TO* __restrict__ dst
 
 // Many permutes in ONE launch (the per-step refresh of every kernel-layout weight copy after the optimizer step: ~180 launches
 // of a few microseconds each otherwise).  table[e] describes one permute and the first block that works on it; a block finds
-// its entry by binary search and handles 2048 consecutive destination elements.
-struct PermEntry { const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start; };
+// its entry by binary search.  Two block shapes: linear (e[3] == 0: 2048 consecutive destination elements, for permutes whose
+// innermost destination dimension is contiguous in the source too -- casts) and TILED (a hyper-rectangle e[0..3] of the
+// destination index space, <= 4608 elements): the tile is read in SOURCE-address order (ord[] = dimensions by ascending
+// |source stride|) into LDS at its destination-linear position and written out in destination order, so that both the
+// gather and the store are runs of >= 128 bytes.  The conv-weight transposes ([co,ci,3,3] -> [co][ky][kx][ci] and the flipped
+// [ci][ky][kx][co] data-gradient form) read single floats 36 B / 18 KB apart in the linear shape: 11.4 GB of HBM-side traffic
+// per refresh for 0.7 GB of weights (1.7 ms); tiled: see DESIGN.md section 5.
+struct PermEntry { const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start;
+                   int32_t e[4]; int32_t ord[4]; };
 static_assert(sizeof(PermEntry) == sizeof(umr_perm_entry), "umr_perm_entry layout");
-__global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* __restrict__ table, int n) {
-    int lo = 0, hi = n - 1;
+constexpr int PERM_TILE_MAX = 4608;
+__global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* __restrict__ table, int n, const int32_t* __restrict__ blk_entry) {
+    __shared__ float tile[PERM_TILE_MAX];
     const int64_t b = blockIdx.x;
-    while (lo < hi) {   // last entry with blk_start <= b
-        const int mid = (lo + hi + 1) >> 1;
-        if (table[mid].blk_start <= b) lo = mid; else hi = mid - 1;
+    int lo = 0;
+    if (blk_entry) {
+        lo = blk_entry[b];     // one load instead of a dependent chain of ~8 (a block moves only 8-18 KB: the search was a third of its time)
+    } else {
+        int hi = n - 1;
+        while (lo < hi) {   // last entry with blk_start <= b
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[mid].blk_start <= b) lo = mid; else hi = mid - 1;
+        }
     }
     const PermEntry e = table[lo];
-    const int64_t total = (int64_t)e.d[0] * e.d[1] * e.d[2] * e.d[3];
-    const int64_t base = (b - e.blk_start) * 2048;
+    const int64_t lb = b - e.blk_start;
+    if (e.e[3] == 0) {
+        const int64_t total = (int64_t)e.d[0] * e.d[1] * e.d[2] * e.d[3];
+        const int64_t base = lb * 2048;
+        // a plain cast (the Linear weights: most of the bytes): 16-byte loads
+        if (e.d[0] == 1 && e.d[1] == 1 && e.d[2] == 1 && e.sstride[3] == 1 && e.dtype_in == UMR_F32 && (e.soff & 3) == 0 &&
+            (((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0 && base + 2048 <= total) {
+            const float* sp = (const float*)e.src + e.soff + base;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int64_t idx = base + j * 256 + threadIdx.x;
-        if (idx >= total) break;
-        int64_t r = idx;
-        const int i3 = (int)(r % e.d[3]); r /= e.d[3];
-        const int i2 = (int)(r % e.d[2]); r /= e.d[2];
-        const int i1 = (int)(r % e.d[1]);
-        const int i0 = (int)(r / e.d[1]);
-        const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
-        const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
-        if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+            for (int j = 0; j < 2; ++j) {
+                const int o = (j * 256 + threadIdx.x) * 4;
+                const f32x4 v = *(const f32x4*)(sp + o);
+                if (e.dtype_out == UMR_F32) *(f32x4*)((float*)e.dst + base + o) = v;
+                else { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)((bf16_t*)e.dst + base + o) = t; }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t idx = base + j * 256 + threadIdx.x;
+            if (idx >= total) break;
+            int64_t r = idx;
+            const int i3 = (int)(r % e.d[3]); r /= e.d[3];
+            const int i2 = (int)(r % e.d[2]); r /= e.d[2];
+            const int i1 = (int)(r % e.d[1]);
+            const int i0 = (int)(r / e.d[1]);
+            const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
+            const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
+            if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+        }
+        return;
+    }
+    // tiled: tile coordinates (dimension 3 fastest), then its origin
+    int nt[4], org[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nt[k] = (e.d[k] + e.e[k] - 1) / e.e[k];
+    int64_t r = lb;
+    org[3] = (int)(r % nt[3]) * e.e[3]; r /= nt[3];
+    org[2] = (int)(r % nt[2]) * e.e[2]; r /= nt[2];
+    org[1] = (int)(r % nt[1]) * e.e[1]; r /= nt[1];
+    org[0] = (int)r * e.e[0];
+    const int T = e.e[0] * e.e[1] * e.e[2] * e.e[3];
+    const int o0 = e.ord[0], o1 = e.ord[1], o2 = e.ord[2], o3 = e.ord[3];   // o0 = the dimension that runs fastest in the source
+    for (int idx = threadIdx.x; idx < T; idx += 256) {
+        int l[4];
+        int q = idx;
+        l[o0] = q % e.e[o0]; q /= e.e[o0];
+        l[o1] = q % e.e[o1]; q /= e.e[o1];
+        l[o2] = q % e.e[o2];
+        l[o3] = q / e.e[o2];
+        const bool in = org[0] + l[0] < e.d[0] && org[1] + l[1] < e.d[1] && org[2] + l[2] < e.d[2] && org[3] + l[3] < e.d[3];
+        if (in) {
+            const int64_t si = e.soff + (int64_t)(org[0] + l[0]) * e.sstride[0] + (int64_t)(org[1] + l[1]) * e.sstride[1] +
+                               (int64_t)(org[2] + l[2]) * e.sstride[2] + (int64_t)(org[3] + l[3]) * e.sstride[3];
+            tile[((l[0] * e.e[1] + l[1]) * e.e[2] + l[2]) * e.e[3] + l[3]] =
+                e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T; idx += 256) {
+        int q = idx;
+        const int l3 = q % e.e[3]; q /= e.e[3];
+        const int l2 = q % e.e[2]; q /= e.e[2];
+        const int l1 = q % e.e[1];
+        const int l0 = q / e.e[1];
+        const int i0 = org[0] + l0, i1 = org[1] + l1, i2 = org[2] + l2, i3 = org[3] + l3;
+        if (i0 < e.d[0] && i1 < e.d[1] && i2 < e.d[2] && i3 < e.d[3]) {
+            const int64_t di = (((int64_t)i0 * e.d[1] + i1) * e.d[2] + i2) * e.d[3] + i3;
+            const float v = tile[idx];
+            if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = v; else ((bf16_t*)e.dst)[di] = (bf16_t)v;
+        }
     }
 }
 
@@ -602,9 +673,10 @@ extern "C" int umr_permute4(const void* src, void* dst, const int32_t* dst_dims,
     return UMR_OK;
 }
 
-extern "C" int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, umr_stream_t stream) {
+extern "C" int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, const int32_t* blk_entry_dev, umr_stream_t stream) {
     UMR_CHECK_ARG(table_dev && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "permute4_batched: bad arguments");
-    hipLaunchKernelGGL(permute4_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PermEntry*)table_dev, n);
+    hipLaunchKernelGGL(permute4_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const PermEntry*)table_dev, n,
+                       blk_entry_dev);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

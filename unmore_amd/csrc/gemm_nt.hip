@@ -432,14 +432,18 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         UMR_CHECK_ARG(d->conv == 0 || d->conv == 1, "gemm_nt (BF16X3): plain GEMM or stride-1 3x3 conv only");
         const bool out_f32 = (d->flags & UMR_EPI_OUT_F32) != 0, out_x3 = (d->flags & UMR_EPI_OUT_X3) != 0;
         const int kk = d->conv == 0 ? d->K : d->Cin;
-        const bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && (out_f32 != out_x3) && d->c2_mode == 0 && !d->red_w && !d->no_store &&
+        const bool red = d->red_w != nullptr;   // fused row reduction: inference form only (C is not stored), plain GEMM
+        const bool out_ok = red ? (d->no_store && !out_f32 && !out_x3 && d->conv == 0 && d->red_out && (d->red_c == 1 || d->red_c == 2))
+                                : (!d->no_store && d->C && (out_f32 != out_x3) &&
+                                   (out_x3 ? (d->ldc % 8 == 0 && d->ldc >= 3 * (int64_t)d->N) : (d->ldc % 4 == 0)));
+        const bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && out_ok && d->c2_mode == 0 &&
                         d->a_rows_in <= 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
                         !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3)) && (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU) &&
-                        (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) && (out_x3 ? (d->ldc % 8 == 0 && d->ldc >= 3 * (int64_t)d->N) : (d->ldc % 4 == 0)) &&
+                        (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) &&
                         (d->conv == 1 ? (d->K == 9 * d->Cin && (int64_t)d->nb * d->Ho * d->Wo == d->M && d->Ho == d->H && d->Wo == d->W)
                                       : (d->lda % 8 == 0 && d->lda >= 3 * (int64_t)d->K));
         if (!ok) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt (BF16X3): needs K (conv: Cin) % 64 == 0, N % 8 == 0, bias / ReLU epilogue, "
-                                                           "exactly one of OUT_F32 / OUT_X3, no aux / remap / C2 / reduction (include/umr.h)");
+                                                           "exactly one of OUT_F32 / OUT_X3 (or red_w with no_store), no aux / remap / C2 (include/umr.h)");
         UMR_CHECK_ARG(!(d->flags & UMR_EPI_BIAS) || d->bias, "gemm_nt: bias flag without pointer");
         UMR_CHECK_ARG((int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) < (1ll << 31), "gemm_nt: grid too large");
         return umr_launch_gemm_nt256p(d, (hipStream_t)stream);

@@ -756,6 +756,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             fetch_bias(it + 1);
             const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
             const bool planes = (p.flags & UMR_EPI_OUT_X3) != 0;
+            if (RED) {
+                // fused output layer (1024 -> {1,2}) of a head at inference: dot products of the f32 values with the reduction
+                // weights (brought into the staging region by LDS-DMA at the start of the tile), C itself is never stored
+                f32x4 rw[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl)
+                        rw[c][ntl] = *(const f32x4*)(smem + STG_OFF + c * 1024 + (wc * 64 + ntl * 16 + fq * 4) * 4);
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) {
+                        const f32x4 v = acc[mt][ntl];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = fmaxf(v[e], relu_floor);
+                            rs0 += t * rw[0][ntl][e];
+                            rs1 += t * rw[1][ntl][e];
+                        }
+                    }
+                    rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
+                    rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
+                    const int m = m0 + wr * 128 + mt * 16 + frow;
+                    if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
+                        float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
+                        ro[0] = rs0;
+                        if (p.red_c == 2) ro[1] = rs1;
+                    }
+                }
+            } else {
 #pragma unroll 1
             for (int mt = 0; mt < 8; ++mt) {
                 if (mt > 0) __syncthreads();
@@ -800,6 +832,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         *(f32x4*)(cp + 4) = v1;
                     }
                 }
+            }
             }
         } else {
             // generic epilogue (every flag / activation / remap of include/umr.h): ONE copy of the store code in a
@@ -963,7 +996,14 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
         hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm); \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
-        if (d->conv == 0) L256PX(0); else L256PX(1);
+        if (d->red_w) {
+            static bool set_ = false;
+            if (!set_) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<0, 5, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P);
+                set_ = true;
+            }
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm);
+        } else if (d->conv == 0) L256PX(0); else L256PX(1);
         UMR_LAUNCH_CHECK();
         return UMR_OK;
     }

@@ -453,11 +453,13 @@ class Engine:
                 h1p = ops.gemm_nt_x3(featp, self._wx3(P, f"{name}.{idx[0]}.weight", "lin"), b_(0), act=act, out_planes=True)
                 h2p = ops.gemm_nt_x3(h1p.view(B, H, W, -1), self._wx3(P, f"{name}.{idx[1]}.weight", "c3"), b_(1), act=act, conv=1, out_planes=True)
                 del h1p
-                h3 = ops.gemm_nt_x3(h2p, self._wx3(P, f"{name}.{idx[2]}.weight", "lin"), b_(2), act=act)
-                del h2p
+                # the 1024 -> {1,2} output layer rides in the epilogue of the layer that produces its input: h3 is never stored
                 w4 = self._f32(P, f"{name}.{idx[3]}.weight")
-                outs.append(ops.head_out_fwd(h3, w4.reshape(w4.shape[0], -1), b_(3), B, H, W, _ACT[lay["final"]]))
-                del h3
+                parts = ops.gemm_nt_x3(h2p, self._wx3(P, f"{name}.{idx[2]}.weight", "lin"), b_(2), act=act,
+                                       red_w=w4.reshape(w4.shape[0], -1).contiguous())
+                del h2p
+                outs.append(ops.head_out_finish(parts, b_(3), B, H, W, _ACT[lay["final"]]))
+                del parts
                 continue
             # a head that is linear up to its output activation needs none of its 512/1024-channel activations in backward
             # (exact gradients from three pixel reductions over feat, _linear_head_backward); sin is not invertible from its value

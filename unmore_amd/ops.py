@@ -161,7 +161,7 @@ def split3(x, out=None):
     return out
 
 
-def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False):
+def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, red_w=None):
     """fp32-grade C = act(A . B^T + bias) from operands held as three bf16 planes per f32 value (split3): Ap [M, 3K] (or NHWC
     [nb,H,W,3*Cin] when conv == 1), Bp [N, 3K].  Returns f32 [M, N], or planes [M, 3N] bf16 with out_planes=True (what the next
     gemm_nt_x3 layer takes).  Persistent 256x256 bf16 kernel, six plane pairs per K-tile (csrc/gemm_nt256p.hip, X3)."""
@@ -182,7 +182,14 @@ def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False):
         assert A2.stride(1) == 1 and A2.shape[1] == 3 * K
         M_ = A2.shape[0]
         d.lda = A2.stride(0)
-    if out_planes:
+    partials = None
+    if red_w is not None:
+        # fused row reduction (the 1024 -> {1,2} output layer of a head): returns partials [ceil(N/64), M, c] for head_out_finish
+        assert red_w.dtype == torch.float32 and red_w.is_contiguous() and red_w.shape[1] == N and red_w.shape[0] in (1, 2) and not conv
+        partials = torch.empty(((N + 63) // 64, M_, red_w.shape[0]), dtype=torch.float32, device=Ap.device)
+        d.red_w, d.red_out, d.red_c, d.no_store = _p(red_w), _p(partials), red_w.shape[0], 1
+        out, flags = None, 0
+    elif out_planes:
         out = torch.empty((M_, 3 * N), dtype=torch.bfloat16, device=Ap.device)
         flags = L.EPI_OUT_X3
     else:
@@ -192,11 +199,11 @@ def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False):
         assert bias.dtype == torch.float32
         flags |= L.EPI_BIAS
     d.A, d.B, d.C, d.bias = _p(Ap), _p(Bp), _p(out), _p(bias)
-    d.ldb, d.ldc = Bp.stride(0), out.stride(0)
+    d.ldb, d.ldc = Bp.stride(0), (out.stride(0) if out is not None else N)
     d.M, d.N, d.K, d.dtype = M_, N, K, L.BF16X3
     d.flags, d.act, d.conv = flags, act, conv
     L.check(_timed_call(d), "umr_gemm_nt")
-    return out
+    return partials if red_w is not None else out
 
 
 def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_remap=None, x_remap=None, lddy=None, ldx=None):
@@ -343,6 +350,29 @@ def zero_stuff2(dy, H, W):
 _pack_recorder = None
 
 
+_PERM_TILE_MAX = 4608
+
+
+def _perm_tile(dims, strides):
+    """Block shape for one permute of umr_permute4_batched: None = linear (innermost destination dimension contiguous in the
+    source, or a tiny tensor), else (extents e[4], order ord[4]): a destination hyper-rectangle of <= 4608 elements whose
+    innermost extent is >= 64 (stores in runs of >= 128 B) and which grows along the dimensions of smallest source stride first
+    (gathers in long runs)."""
+    total = dims[0] * dims[1] * dims[2] * dims[3]
+    if abs(strides[3]) == 1 or dims[3] == 1 or total < 4096:
+        return None
+    order = sorted(range(4), key=lambda k: (abs(strides[k]) if dims[k] > 1 else 0, k))   # size-1 dimensions first (free)
+    e = [1, 1, 1, 1]
+    e[3] = min(dims[3], 64)
+    prod = e[3]
+    for k in order:
+        if k == 3:
+            continue
+        e[k] = max(1, min(dims[k], _PERM_TILE_MAX // prod))
+        prod *= e[k]
+    return e, order
+
+
 def permute4_batched(recipes):
     """Replays recorded permutes (list of (src, dst, dims, strides, offset)) in one launch.  Returns a callable that launches
     it again on the current stream (the device-side table is built once)."""
@@ -350,19 +380,33 @@ def permute4_batched(recipes):
     n = len(recipes)
     arr = (L.PermEntry * n)()
     blk = 0
+    counts = []
     for i, (src, dst, dims, strides, off) in enumerate(recipes):
         e = arr[i]
         e.src, e.dst = src.data_ptr(), dst.data_ptr()
         for k in range(4):
             e.d[k], e.sstride[k] = dims[k], strides[k]
         e.soff, e.dtype_in, e.dtype_out, e.blk_start = off, _DT[src.dtype], _DT[dst.dtype], blk
-        blk += (dims[0] * dims[1] * dims[2] * dims[3] + 2047) // 2048
+        tile = _perm_tile(dims, strides)
+        if tile is None:
+            for k in range(4):
+                e.e[k], e.ord[k] = 0, k
+            blk += (dims[0] * dims[1] * dims[2] * dims[3] + 2047) // 2048
+        else:
+            ext, order = tile
+            nb = 1
+            for k in range(4):
+                e.e[k], e.ord[k] = ext[k], order[k]
+                nb *= (dims[k] + ext[k] - 1) // ext[k]
+            blk += nb
+        counts.append(blk - e.blk_start)
     host = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
     table = host.to(recipes[0][1].device)
+    blk_entry = torch.from_numpy(np.repeat(np.arange(n, dtype=np.int32), counts)).to(recipes[0][1].device)
     keep = [r[0] for r in recipes] + [r[1] for r in recipes]   # the table holds raw pointers: keep the tensors alive with it
 
     def launch():
-        L.check(L.lib().umr_permute4_batched(_p(table), n, blk, _stream()), "umr_permute4_batched")
+        L.check(L.lib().umr_permute4_batched(_p(table), n, blk, _p(blk_entry), _stream()), "umr_permute4_batched")
     launch.keep = keep
     return launch
 

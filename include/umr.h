@@ -176,7 +176,7 @@ int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int6
 /* many permutes in one launch (the per-step refresh of the kernel-layout weight copies after the optimizer step).
  * table_dev: n entries IN DEVICE MEMORY, sorted by blk_start; entry e covers blocks [blk_start_e, blk_start_{e+1}), blk_start_0 = 0;
  * total_blocks = the sum.  Same element semantics as umr_permute4 (dst[i0,i1,i2,i3] = src[soff + sum i_k * sstride[k]], cast to
- * dtype_out; no accumulate).  Block shape per entry: e[3] == 0 -> linear, ceil(elements / 2048) blocks of 2048 consecutive
+ * dtype_out; no accumulate).  Block shape per entry: e[3] == 0 -> linear, ceil(elements / 8192) blocks of 8192 consecutive
  * destination elements; otherwise TILED: a block handles the hyper-rectangle e[0] x e[1] x e[2] x e[3] (product <= 4608) of the
  * destination index space, read in source-address order (ord[] = the four dimensions by ascending |sstride|) through LDS --
  * prod_k ceil(d[k] / e[k]) blocks, tile coordinate of dimension 3 fastest.  Use tiles when the innermost destination dimension

@@ -513,3 +513,36 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
             assert torch.equal(a, b), bm
     ref = F.relu(x.float() @ w.float().t() + bias)
     torch.testing.assert_close(res[224][0].float(), ref, atol=3e-2, rtol=3e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(64 * 577, 768, 768), (40000 + 77, 1024, 512), (3 * 128 + 5, 512, 256), (9000, 520, 1024), (128 * 300, 256, 64)])
+def test_two_workgroups_per_cu_kernel_equals_persistent_kernel(M, N, K, monkeypatch):
+    """gemm_nt128w.hip (128x256 tiles, two 256-thread workgroups per CU, BK = 32 three-stage ring) against the persistent 256x256
+    kernel on the same problems: every K sum is the same MFMA sequence (k ascending in steps of 32), so plain / ReLU / residual /
+    ReLU-mask / fused-reduction results must be BIT-IDENTICAL; and both match torch.  Ragged M and N tails included."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    x = _rnd((M, K), torch.bfloat16, dev, 81)
+    w = _rnd((N, K), torch.bfloat16, dev, 82, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 83)
+    aux = _rnd((M, N), torch.bfloat16, dev, 84)
+    redw = _rnd((2, N), torch.float32, dev, 85)
+    monkeypatch.setenv("UMR_GEMM_TILE", "256")
+
+    def run():
+        outs = [ops.gemm_nt(x, w, bias), ops.gemm_nt(x, w, bias, act=L.ACT_RELU), ops.gemm_nt(x, w, bias, aux=aux),
+                ops.gemm_nt(x, w, None, aux=aux, mask_relu=True)]
+        outs += list(ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw))
+        outs.append(ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw[:1].contiguous(), no_store=True)[1])
+        torch.cuda.synchronize()
+        return outs
+
+    monkeypatch.setenv("UMR_NT128W", "0")
+    ref = run()
+    monkeypatch.setenv("UMR_NT128W", "2")
+    new = run()
+    for i, (a, b) in enumerate(zip(ref, new)):
+        assert torch.equal(a, b), i
+    gold = x.float() @ w.float().t() + bias
+    torch.testing.assert_close(new[0].float(), gold, atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(new[2].float(), gold + aux.float(), atol=5e-2, rtol=3e-2)

@@ -217,32 +217,37 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
     const int64_t lb = b - e.blk_start;
     if (e.e[3] == 0) {
         const int64_t total = (int64_t)e.d[0] * e.d[1] * e.d[2] * e.d[3];
-        const int64_t base = lb * 2048;
         // a plain cast (the Linear weights: most of the bytes): 16-byte loads
-        if (e.d[0] == 1 && e.d[1] == 1 && e.d[2] == 1 && e.sstride[3] == 1 && e.dtype_in == UMR_F32 && (e.soff & 3) == 0 &&
-            (((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0 && base + 2048 <= total) {
-            const float* sp = (const float*)e.src + e.soff + base;
+        const bool vec = e.d[0] == 1 && e.d[1] == 1 && e.d[2] == 1 && e.sstride[3] == 1 && e.dtype_in == UMR_F32 && (e.soff & 3) == 0 &&
+                         (((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0;
+#pragma unroll 1
+        for (int rep = 0; rep < 4; ++rep) {      // 4 x 2048 consecutive destination elements per block
+            const int64_t base = (lb * 4 + rep) * 2048;
+            if (base >= total) break;
+            if (vec && base + 2048 <= total) {
+                const float* sp = (const float*)e.src + e.soff + base;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int o = (j * 256 + threadIdx.x) * 4;
-                const f32x4 v = *(const f32x4*)(sp + o);
-                if (e.dtype_out == UMR_F32) *(f32x4*)((float*)e.dst + base + o) = v;
-                else { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)((bf16_t*)e.dst + base + o) = t; }
+                for (int j = 0; j < 2; ++j) {
+                    const int o = (j * 256 + threadIdx.x) * 4;
+                    const f32x4 v = *(const f32x4*)(sp + o);
+                    if (e.dtype_out == UMR_F32) *(f32x4*)((float*)e.dst + base + o) = v;
+                    else { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)((bf16_t*)e.dst + base + o) = t; }
+                }
+                continue;
             }
-            return;
-        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t idx = base + j * 256 + threadIdx.x;
-            if (idx >= total) break;
-            int64_t r = idx;
-            const int i3 = (int)(r % e.d[3]); r /= e.d[3];
-            const int i2 = (int)(r % e.d[2]); r /= e.d[2];
-            const int i1 = (int)(r % e.d[1]);
-            const int i0 = (int)(r / e.d[1]);
-            const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
-            const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
-            if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+            for (int j = 0; j < 8; ++j) {
+                const int64_t idx = base + j * 256 + threadIdx.x;
+                if (idx >= total) break;
+                int64_t r = idx;
+                const int i3 = (int)(r % e.d[3]); r /= e.d[3];
+                const int i2 = (int)(r % e.d[2]); r /= e.d[2];
+                const int i1 = (int)(r % e.d[1]);
+                const int i0 = (int)(r / e.d[1]);
+                const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
+                const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
+                if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+            }
         }
         return;
     }

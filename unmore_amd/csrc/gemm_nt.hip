@@ -397,6 +397,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip
+int umr_launch_gemm_nt128w(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt128w.hip (two workgroups per CU, short K)
+bool umr_nt128w_eligible(const umr_gemm_desc* d);
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
 static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch
@@ -420,6 +422,7 @@ static bool uses_256(const umr_gemm_desc* d) {
 
 extern "C" int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d) {
     if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    if (umr_nt128w_eligible(d)) return 1;
     return (uses_256(d) && umr_nt256_rowreduce_path(d)) ? 1 : 0;
 }
 
@@ -472,6 +475,7 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         UMR_CHECK_ARG(umr_gemm_nt_rowreduce_ok(d) == 1, "gemm_nt: fused row reduction / no_store requested on a path that does not implement it (umr_gemm_nt_rowreduce_ok)");
         UMR_CHECK_ARG(!d->red_w || (d->red_out && (d->red_c == 1 || d->red_c == 2)), "gemm_nt: red_out / red_c");
     }
+    if (umr_nt128w_eligible(d)) return umr_launch_gemm_nt128w(d, s);
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     dim3 g((unsigned)grid), b(256);
     const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&

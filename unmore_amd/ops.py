@@ -391,7 +391,7 @@ def permute4_batched(recipes):
         if tile is None:
             for k in range(4):
                 e.e[k], e.ord[k] = 0, k
-            blk += (dims[0] * dims[1] * dims[2] * dims[3] + 2047) // 2048
+            blk += (dims[0] * dims[1] * dims[2] * dims[3] + 8191) // 8192
         else:
             ext, order = tile
             nb = 1

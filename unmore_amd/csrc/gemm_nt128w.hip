@@ -24,6 +24,15 @@
 // One barrier per stage; no wait inside the loop ever drains the DMA queue.  Stages past the end of K are issued too (the
 // descriptor bounds make them read zeros or dead padding; nobody consumes them) so that the counted wait is uniform.
 //
+// MEASURED (round 3, tools/nt128w_bench.py, profiles/r03_nt128w_ab.txt, interleaved rounds in one process): bit-identical to the
+// persistent kernel and 11-23 % SLOWER on every short-K GEMM of the step (heads 1x1: 256->512 -19 %, 512->1024 + fused output -17 %
+// storing / -11 % not storing, masked 1024->512 -18 %; ViT qkv -14 %, proj -13 %, fc1 dgrad -23 %).  A stage takes ~2400 cycles per
+// workgroup for 512 cycles of MFMA work per wave.  Reason: a 128x256 tile needs 1 byte of LDS fill per 85 FLOP against 1 per 128 for
+// 256x256, and the L2 -> LDS fill (~70 GB/s = 29 B/clk per CU, MI355X_MICROARCH.md "Indexed rows: gather into LDS") is what bounds
+// the 256x256 kernel's K loop already (32 B/clk needed at full MFMA rate): two co-resident workgroups need 47 B/clk.  What the
+// partner workgroup hides (epilogue, barrier skew) is less than what the smaller tile costs.  The kernel therefore is OFF by default
+// (UMR_NT128W=2 selects it; tests/test_gemm_gpu.py keeps it correct); an epilogue-overlap form has to keep 256x256 tiles.
+//
 // Epilogue = the fast class of gemm_nt256p.hip (bias as the accumulators' start value, ReLU, residual add / ReLU mask applied
 // in the copy-out layout, fused 1024 -> {1,2} row reduction, no_store): the whole 128x256 bf16 tile is staged at once in the
 // (drained) ring, two barriers per tile.
@@ -268,9 +277,10 @@ bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d);
 
 // would umr_gemm_nt hand d to this kernel?  (bf16 plain GEMM, fast epilogue class, short K, enough tiles to fill the chip twice)
 bool umr_nt128w_eligible(const umr_gemm_desc* d) {
-    // UMR_NT128W: 0 = never, 1 = by the rule below (default), 2 = whenever the kernel can run the problem; read per launch (tests A/B it)
+    // UMR_NT128W: 0 = never (DEFAULT: measured 11-23 % SLOWER than the persistent 256x256 kernel on every short-K GEMM of the step,
+    // see the header), 1 = by the rule below, 2 = whenever the kernel can run the problem; read per launch (tests A/B it)
     const char* e = getenv("UMR_NT128W");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = e ? atoi(e) : 0;
     if (mode == 0) return false;
     if (d->dtype != UMR_BF16 || d->conv != 0 || d->a_rows_in > 0 || (d->K % 64) != 0 || (d->lda % 8) != 0 || (d->ldb % 8) != 0) return false;
     if (!umr_nt256p_fast_epilogue(d)) return false;

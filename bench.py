@@ -441,7 +441,6 @@ def run_rank(a):
         images = [torch.from_numpy(synth.blob_images(1, Hi, Wi, seed=1000 * rank + i)[0]).to(dev) for i in range(n_img)]
         counter = [0]
         peaks = [0, 0]
-        n_with_peak = [0, 0]    # proposals with a peak / proposals swept, over the timed steps
         M_head = 50 * 128 * 128
 
         def one():

@@ -517,8 +517,8 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
 
 @pytest.mark.parametrize("M,N,K", [(64 * 577, 768, 768), (40000 + 77, 1024, 512), (3 * 128 + 5, 512, 256), (9000, 520, 1024), (128 * 300, 256, 64)])
 def test_two_workgroups_per_cu_kernel_equals_persistent_kernel(M, N, K, monkeypatch):
-    """gemm_nt128w.hip (128x256 tiles, two 256-thread workgroups per CU, BK = 32 three-stage ring) against the persistent 256x256
-    kernel on the same problems: every K sum is the same MFMA sequence (k ascending in steps of 32), so plain / ReLU / residual /
+    """gemm_nt128w.hip (128x256 tiles / two 256-thread workgroups per CU, and 128x512 tiles / one 512-thread workgroup; BK = 32
+    three-stage ring) against the persistent 256x256 kernel on the same problems: every K sum is the same MFMA sequence (k ascending in steps of 32), so plain / ReLU / residual /
     ReLU-mask / fused-reduction results must be BIT-IDENTICAL; and both match torch.  Ragged M and N tails included."""
     from unmore_amd import ops, _lib as L
     dev = _dev()
@@ -539,10 +539,11 @@ def test_two_workgroups_per_cu_kernel_equals_persistent_kernel(M, N, K, monkeypa
 
     monkeypatch.setenv("UMR_NT128W", "0")
     ref = run()
-    monkeypatch.setenv("UMR_NT128W", "2")
-    new = run()
-    for i, (a, b) in enumerate(zip(ref, new)):
-        assert torch.equal(a, b), i
+    for mode in ("2", "3"):        # 2 = 128x256 tiles, two workgroups per CU; 3 = 128x512 tiles, eight waves
+        monkeypatch.setenv("UMR_NT128W", mode)
+        new = run()
+        for i, (a, b) in enumerate(zip(ref, new)):
+            assert torch.equal(a, b), (mode, i)
     gold = x.float() @ w.float().t() + bias
     torch.testing.assert_close(new[0].float(), gold, atol=3e-2, rtol=3e-2)
     torch.testing.assert_close(new[2].float(), gold + aux.float(), atol=5e-2, rtol=3e-2)

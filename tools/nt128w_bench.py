@@ -36,6 +36,7 @@ add("head 256->512 relu", Mh, 512, 256, act=L.ACT_RELU)
 add("head 512->1024 relu + fused out", Mh, 1024, 512, act=L.ACT_RELU, red=True)
 add("head 512->1024 + fused out, no store", Mh, 1024, 512, red=True, no_store=True)
 add("head 1024->512 masked dgrad", Mh, 512, 1024, aux_kind="mask")
+add("head 1024->512 dgrad (no mask)", Mh, 512, 1024)
 add("head 1024->256 dfeat", Mh, 256, 1024)
 add("vit qkv", Mt, 2304, 768)
 add("vit proj (+res)", Mt, 768, 768, aux_kind="add")
@@ -43,8 +44,8 @@ add("vit fc1 dgrad", Mt, 768, 3072)
 for name, fl, fn in cases:
     res = {}
     for rnd_ in range(3):
-        for mode in ("0", "2"):
+        for mode in ("0", "2", "3"):
             os.environ["UMR_NT128W"] = mode
             res.setdefault(mode, []).append(timeit(fn, n=7, warm=2))
-    a, b = min(res["0"]), min(res["2"])
-    print(f"{name:40s} 256p {a:8.3f} ms {fl / a / 1e9:7.1f} TF/s | 128w {b:8.3f} ms {fl / b / 1e9:7.1f} TF/s | {100 * (a / b - 1):+5.1f} %", flush=True)
+    a, b, c = min(res["0"]), min(res["2"]), min(res["3"])
+    print(f"{name:40s} 256p {a:8.3f} ms {fl / a / 1e9:7.1f} TF/s | 128x256 {b:8.3f} ms {100 * (a / b - 1):+5.1f} % | 128x512 {c:8.3f} ms {fl / c / 1e9:7.1f} TF/s {100 * (a / c - 1):+5.1f} %", flush=True)

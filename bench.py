@@ -544,6 +544,25 @@ def run_rank(a):
                 mx0, am0, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
                 lo, hi = SWEEP_CHECK
                 hip_peaks = (mx0[lo:hi].cpu(), am0[lo:hi].cpu())
+                # beside the headline, never `value`: the opt-in three-term plane products (UMR_F32_X3_FAST: products to 2^-16, half
+                # the matrix work) with what they cost in the maps and in the peak indices, measured on the same image
+                ops.set_f32_mode("x3_fast")
+                try:
+                    dtf = timed_sweeps(2)
+                    mxf, amf, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
+                    crops_chk, _ = reasoning.crop_resize(images[0], props[SWEEP_CHECK[0]:SWEEP_CHECK[1]], 128)
+                    with torch.no_grad():
+                        pf = net.get_prediction(crops_chk)
+                    ops.set_f32_mode("x3")
+                    with torch.no_grad():
+                        p6 = net.get_prediction(crops_chk)
+                finally:
+                    ops.set_f32_mode("x3")
+                res["alt_fp32_3term"] = {"value": 1.0 / dtf, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dtf,
+                                         "peak_index_differs_from_6term": int((amf != am0).sum().item()),
+                                         "max_abs_map_difference_vs_6term": float(max((pf[k] - p6[k]).abs().max().item() for k in ("center_fields", "sdf_maps"))),
+                                         "note": "opt-in umr_set_f32_mode(UMR_F32_X3_FAST): three instead of six bf16 products per f32 product in the heads' "
+                                                 "plane GEMMs (2^-16 per product); not the headline"}
                 # beside the headline: the same sweep with bf16 storage (no bit-exact-peak claim) ...
                 net.set_compute_dtype(torch.bfloat16)
                 dt2 = timed_sweeps(2)

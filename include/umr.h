@@ -37,8 +37,12 @@ const char* umr_last_error_string(void);
  *     operands with 2^-100 < |x| < 2^126.  Outside that range it is NOT IEEE: an inf operand gives NaN (inf - inf in the split),
  *     |x| within 2^-8 of FLT_MAX rounds its leading term to inf -> NaN, and the m / l terms of |x| < 2^-110 underflow in
  *     bf16 (the product then keeps only 8 / 16 significant bits -- of a value that is itself ~1e-33).  A NaN operand gives NaN
- *     in both modes.  tests/test_gemm_gpu.py::test_f32_x3_* pins this behaviour. */
-enum umr_f32_mode { UMR_F32_EXACT = 0, UMR_F32_X3 = 1 };
+ *     in both modes.  tests/test_gemm_gpu.py::test_f32_x3_* pins this behaviour.
+ *   UMR_F32_X3_FAST (opt-in, never a default): as X3, but the UMR_BF16X3 plane GEMMs keep only the three leading terms
+ *     (hh + hm + mh): every product to 2^-16 instead of 2^-24, at half the matrix work.  Meant for inference
+ *     under a 1e-4 output tolerance (measured field error and peak-index agreement: bench.py --workload cfg5, alt_fp32_3term);
+ *     the non-plane f32 kernels behave as in X3. */
+enum umr_f32_mode { UMR_F32_EXACT = 0, UMR_F32_X3 = 1, UMR_F32_X3_FAST = 2 };
 int umr_set_f32_mode(int mode);   /* returns UMR_OK or UMR_ERR_INVALID */
 int umr_get_f32_mode(void);
 

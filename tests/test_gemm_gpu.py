@@ -464,6 +464,23 @@ def test_gemm_nt_x3_fused_row_reduction():
         torch.testing.assert_close(out[0, :, 0, :].t().double(), ref, atol=2e-5, rtol=2e-5)
 
 
+def test_gemm_nt_x3_three_term_mode(f32_mode_restored):
+    """opt-in UMR_F32_X3_FAST: the plane GEMMs keep hh + hm + mh only -- relative rms error ~2^-17..2^-16 instead of ~2^-24"""
+    from unmore_amd import ops
+    dev = _dev()
+    M, N, K = 5000, 256, 512
+    A = _rnd((M, K), torch.float32, dev, 91)
+    B = _rnd((N, K), torch.float32, dev, 92, K ** -0.5)
+    ref = A.double() @ B.double().t()
+    Ap, Bp = ops.split3(A), ops.split3(B)
+    e6 = _rel_rms(ops.gemm_nt_x3(Ap, Bp), ref)
+    ops.set_f32_mode("x3_fast")
+    assert ops.get_f32_mode() == "x3_fast"
+    e3 = _rel_rms(ops.gemm_nt_x3(Ap, Bp), ref)
+    print(f"plane GEMM relative rms error vs float64: six terms {e6:.2e}, three terms {e3:.2e}")
+    assert e6 < 1e-6 and 1e-6 < e3 < 2e-5
+
+
 def test_gemm_nt_x3_refuses_what_it_does_not_implement():
     from unmore_amd import ops
     dev = _dev()

@@ -219,7 +219,12 @@ def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
         out = net(images=img.cuda())
         objectness_loss(out, cf.cuda(), sdf.cuda(), sal.cuda()).backward()
         res[mode] = (out, {n: p.grad for n, p in net.named_parameters()})
-    assert torch.equal(res["gemm"][0]["sdf_maps"], res["algebraic"][0]["sdf_maps"])       # same forward, bit for bit
+    if dtype == torch.float32:
+        # fp32 mode: a head without saved activations runs its forward on the bf16-plane kernel (same six-term fp32-grade products,
+        # different tiling: equal to rounding, not bit for bit)
+        torch.testing.assert_close(res["gemm"][0]["sdf_maps"], res["algebraic"][0]["sdf_maps"], atol=3e-6, rtol=0)
+    else:
+        assert torch.equal(res["gemm"][0]["sdf_maps"], res["algebraic"][0]["sdf_maps"])       # same forward, bit for bit
     assert torch.equal(res["gemm"][0]["center_fields"], res["algebraic"][0]["center_fields"])
     gg, ga = res["gemm"][1], res["algebraic"][1]
     if dtype == torch.float32:

@@ -12,7 +12,7 @@ F32, BF16, BF16X3 = 0, 1, 2
 EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS, EPI_OUT_X3 = 1, 2, 4, 8, 16, 32, 64, 128
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 ACT_SIGMOID = 5
-F32_EXACT, F32_X3 = 0, 1   # umr_f32_mode
+F32_EXACT, F32_X3, F32_X3_FAST = 0, 1, 2   # umr_f32_mode
 
 _vp, _i32, _i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
 

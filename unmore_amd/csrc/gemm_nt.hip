@@ -494,7 +494,7 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
         if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 0, true>), g, b, LDS_BYTES, s, *d, tiles_n); \
         else hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 1, true>), g, b, LDS_BYTES, s, *d, tiles_n);         \
     } while (0)
-    const int f32_x3 = umr_f32_mode_now();   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
+    const int f32_x3 = umr_f32_mode_now() != UMR_F32_EXACT;   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
     if (d->dtype == UMR_BF16) {
         if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
     } else if (f32_x3 && !((d->conv == 0 ? d->K : d->Cin) % 32)) {   // whole 32-wide K-tiles only (the tail path zero-fills, which is fine, but keep it simple)

@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
 // products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
 template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm) {
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm, int npairs = 6) {
     // bm: output rows per tile, 256 | 224 | 192 (plain GEMMs only).  A persistent grid of G workgroups needs ceil(tiles / G) tile
     // times however full the last round is: the transformer GEMMs at 36,928 tokens have 435 (N = 768) or 1305 (N = 2304) tiles of
     // 256 rows for 256 CUs -- 2 resp. 6 rounds of which the last is 70 % / 10 % full.  With 224-row tiles they have 495 / 1485 tiles:
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     }
 
     const int ktiles_per_tap = (CONV == 0) ? 0 : p.Cin / BK2;
-    const int nt = ((CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap) * (X3 ? 6 : 1);   // K % 64 == 0 guaranteed by the dispatcher
+    // X3: npairs = 6 (fp32-grade) or 3 (UMR_F32_X3_FAST: only (m,h) (h,m) (h,h), products to 2^-16)
+    const int nt = ((CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap) * (X3 ? npairs : 1);   // K % 64 == 0 guaranteed by the dispatcher
 
     // ---- staging side state
     __amdgpu_buffer_rsrc_t rsA, rsB;
@@ -195,9 +196,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             stage_setup(s_it);
         }
         // X3: planes of this K-tile's pair, 2 bits per pair: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
-        const int pa = X3 ? ((0x049 >> (2 * st_pp)) & 3) : 0;   // A planes 1,2,0,1,0,0
-        const int pb = X3 ? ((0x121 >> (2 * st_pp)) & 3) : 0;   // B planes 1,0,2,0,1,0
-        const bool next_k = !X3 || st_pp == 5;
+        const int pa = X3 ? (((npairs == 6 ? 0x049 : 0x001) >> (2 * st_pp)) & 3) : 0;   // A planes 1,2,0,1,0,0  |  1,0,0
+        const int pb = X3 ? (((npairs == 6 ? 0x121 : 0x004) >> (2 * st_pp)) & 3) : 0;   // B planes 1,0,2,0,1,0  |  0,1,0
+        const bool next_k = !X3 || st_pp == npairs - 1;
         if (X3) st_pp = next_k ? 0 : st_pp + 1;
         if (CONV == 0) {
             const int kt = X3 ? st_k : st_tile;
@@ -993,16 +994,17 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, 5, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
             set_ = true;                                                                                               \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm); \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs); \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
+        const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
         if (d->red_w) {
             static bool set_ = false;
             if (!set_) {
                 (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<0, 5, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P);
                 set_ = true;
             }
-            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm);
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs);
         } else if (d->conv == 0) L256PX(0); else L256PX(1);
         UMR_LAUNCH_CHECK();
         return UMR_OK;

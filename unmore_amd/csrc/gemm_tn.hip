@@ -505,7 +505,7 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     dim3 g((unsigned)(pl.tiles_n * pl.tiles_k), (unsigned)pl.splits), b(256);
 #define LAUNCH(T, CV) hipLaunchKernelGGL((gemm_tn_kernel<T, CV>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
 #define LAUNCH_X3(CV) hipLaunchKernelGGL((gemm_tn_kernel<float, CV, true>), g, b, TN_LDS, s, *d, pl.tiles_k, pl.rows_per_split, slab, bslab)
-    const int f32_x3 = umr_f32_mode_now();   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
+    const int f32_x3 = umr_f32_mode_now() != UMR_F32_EXACT;   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
     if (d->dtype == UMR_BF16) {
         if (d->conv == 0) LAUNCH(bf16_t, 0); else if (d->conv == 1) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 2);
     } else if (f32_x3) {

@@ -27,7 +27,7 @@ int umr_f32_mode_now() {
     return m;
 }
 extern "C" int umr_set_f32_mode(int mode) {
-    if (mode != UMR_F32_EXACT && mode != UMR_F32_X3) return umr_set_error(UMR_ERR_INVALID, "umr_set_f32_mode: unknown mode");
+    if (mode != UMR_F32_EXACT && mode != UMR_F32_X3 && mode != UMR_F32_X3_FAST) return umr_set_error(UMR_ERR_INVALID, "umr_set_f32_mode: unknown mode");
     g_f32_mode.store(mode, std::memory_order_relaxed);
     return UMR_OK;
 }

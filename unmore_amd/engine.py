@@ -249,6 +249,9 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def _w(self, P, name, kind):
         p = P[name]
+        if kind == "lin" and self.dt == torch.float32 and p.dtype == torch.float32 and p.is_contiguous():
+            return p.detach().reshape(p.shape[0], -1)    # fp32 mode: the [N, K] kernel layout IS the parameter's layout -- no copy
+
         return self.cache.get((name, kind, self.dt), p, lambda: {
             "lin": lambda: _pack_linear(p, self.dt),
             "lin_t": lambda: _pack_linear_t(p.detach().reshape(p.shape[0], -1), self.dt),
@@ -436,10 +439,15 @@ class Engine:
         # value held as three bf16 planes (six plane pairs per K-tile, csrc/gemm_nt256p.hip X3) -- the same six-term products as
         # the 128x128 fp32 kernel's in-register split (UMR_F32_X3), without the split arithmetic in the loop.  Training keeps
         # f32 activations (its backward reads them), and the exact-f32 mode keeps the f32 MFMA.
-        x3_heads = _X3_HEADS and dt == torch.float32 and not save and ops.get_f32_mode() == "x3"
-        featp = ops.split3(feat.view(-1, 256)) if x3_heads else None
+        x3_ok = _X3_HEADS and dt == torch.float32 and ops.get_f32_mode() in ("x3", "x3_fast")
+        featp = None
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
+            # in training the plane form serves the heads that keep no activation for their backward (algebraic backward)
+            alg_ = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"
+            x3_heads = x3_ok and (not save or alg_) and not (self.collapse_linear_heads and not lay["relu"])
+            if x3_heads and featp is None:
+                featp = ops.split3(feat.view(-1, 256))
             if self.collapse_linear_heads and not lay["relu"]:
                 out, cs = self._linear_head_forward(P, name, idx, feat, _ACT[lay["final"]])
                 outs.append(out)
@@ -458,8 +466,11 @@ class Engine:
                 parts = ops.gemm_nt_x3(h2p, self._wx3(P, f"{name}.{idx[2]}.weight", "lin"), b_(2), act=act,
                                        red_w=w4.reshape(w4.shape[0], -1).contiguous())
                 del h2p
-                outs.append(ops.head_out_finish(parts, b_(3), B, H, W, _ACT[lay["final"]]))
+                out = ops.head_out_finish(parts, b_(3), B, H, W, _ACT[lay["final"]])
                 del parts
+                outs.append(out)
+                if save:
+                    heads_saved.append(dict(algebraic=True, act=_ACT[lay["final"]], out=out))
                 continue
             # a head that is linear up to its output activation needs none of its 512/1024-channel activations in backward
             # (exact gradients from three pixel reductions over feat, _linear_head_backward); sin is not invertible from its value

@@ -331,11 +331,7 @@ int umr_launch_gemm_nt128w(const umr_gemm_desc* d, hipStream_t s) {
     const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
 #define LW(AX, RD, NWV)                                                                                                             \
     do {                                                                                                                            \
-        static bool set_ = false;                                                                                                   \
-        if (!set_) {                                                                                                                \
-            (void)hipFuncSetAttribute((const void*)gemm_nt128w_kernel<AX, RD, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, WG<NWV>::LDS); \
-            set_ = true;                                                                                                            \
-        }                                                                                                                           \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt128w_kernel<AX, RD, NWV>), WG<NWV>::LDS);                                                                                                                           \
         hipLaunchKernelGGL((gemm_nt128w_kernel<AX, RD, NWV>), g, b, WG<NWV>::LDS, s, *d, tiles_n);                                   \
     } while (0)
 #define LWN(AX, RD) do { if (nw == 4) LW(AX, RD, 4); else LW(AX, RD, 8); } while (0)

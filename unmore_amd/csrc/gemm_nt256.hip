@@ -345,8 +345,7 @@ int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
     dim3 g((unsigned)grid), b(512);
 #define L256(CV)                                                                                                       \
     do {                                                                                                               \
-        static bool set_ = false;                                                                                      \
-        if (!set_) { hipFuncSetAttribute((const void*)gemm_nt256_kernel<CV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2); set_ = true; } \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt256_kernel<CV>), LDS2); \
         hipLaunchKernelGGL((gemm_nt256_kernel<CV>), g, b, LDS2, s, *d, tiles_n);                                        \
     } while (0)
     if (d->conv == 0) L256(0);

@@ -975,11 +975,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
 #define L256P(CV, EP, AX, RD)                                                                                          \
     do {                                                                                                               \
-        static bool set_ = false;                                                                                      \
-        if (!set_) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, EP, AX, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
-            set_ = true;                                                                                               \
-        }                                                                                                              \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, AX, RD>), LDS2P);                                                                                                              \
         hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm);     \
     } while (0)
     // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged; one instantiation per aux mode, plus the fused
@@ -989,21 +985,13 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
 #define L256PX(CV)                                                                                                     \
     do {                                                                                                               \
-        static bool set_ = false;                                                                                      \
-        if (!set_) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<CV, 5, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P); \
-            set_ = true;                                                                                               \
-        }                                                                                                              \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, 5, 0, false, true>), LDS2P);                                                                                                              \
         hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs); \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
         const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
         if (d->red_w) {
-            static bool set_ = false;
-            if (!set_) {
-                (void)hipFuncSetAttribute((const void*)gemm_nt256p_kernel<0, 5, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2P);
-                set_ = true;
-            }
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, true, true>), LDS2P);
             hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs);
         } else if (d->conv == 0) L256PX(0); else L256PX(1);
         UMR_LAUNCH_CHECK();

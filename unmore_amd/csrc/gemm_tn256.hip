@@ -414,12 +414,8 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
     if (ph2 < 0) { const char* e = getenv("UMR_TN256_PH2"); ph2 = e ? atoi(e) : 1; }  // two-phase stage: +1-2 % (tools/kbench.py)
 #define LT(CV, WFV)                                                                                                    \
     do {                                                                                                               \
-        static bool set_ = false;                                                                                      \
-        if (!set_) {                                                                                                   \
-            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, false, WFV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);             \
-            (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel<CV, true, WFV>, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS);              \
-            set_ = true;                                                                                               \
-        }                                                                                                              \
+        UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, false, WFV>), TLDS); \
+        UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, true, WFV>), TLDS);                                                                                                              \
         if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode); \
         else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);   \
     } while (0)

@@ -193,8 +193,7 @@ extern "C" int umr_center_peaks(const float* sdf_maps, const float* center_field
     if ((int64_t)H * W * 2 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "center_peaks: map larger than the LDS mask planes (H*W <= 76800)");
     PeakCfg cfg{H, W, border, erode_kernel, erode_rounds};
     const size_t lds = (size_t)H * W * 2;
-    static bool set_ = false;
-    if (!set_) { hipFuncSetAttribute((const void*)center_peaks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set_ = true; }
+    UMR_SET_MAX_LDS_ONCE(center_peaks_kernel, 150 * 1024);
     hipLaunchKernelGGL(center_peaks_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sdf_maps, center_fields, filter50, score_out,
                        max_values, argmax, cfg);
     UMR_LAUNCH_CHECK();

@@ -98,6 +98,18 @@ __device__ __forceinline__ float wave_max(float v) {
 // the library is built without relocatable device code)
 static __device__ uint4 umr_zero_page[16];
 
+// Raise a kernel's dynamic-LDS limit once per process.  Thread-safe: the flag is published AFTER the attribute call (release /
+// acquire), so a thread that sees it set launches with the limit in place; two threads racing both make the (idempotent) call.
+#include <atomic>
+#define UMR_SET_MAX_LDS_ONCE(fn, bytes)                                                                             \
+    do {                                                                                                            \
+        static std::atomic<bool> done_{false};                                                                      \
+        if (!done_.load(std::memory_order_acquire)) {                                                               \
+            (void)hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));      \
+            done_.store(true, std::memory_order_release);                                                           \
+        }                                                                                                           \
+    } while (0)
+
 // host-side error plumbing (umr_api.hip)
 int umr_set_error(int code, const char* msg);
 int umr_f32_mode_now();   // umr_api.hip: UMR_F32_EXACT / UMR_F32_X3

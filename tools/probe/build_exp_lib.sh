@@ -6,6 +6,7 @@ SRC=$1; shift
 cd "$(dirname "$0")/../../unmore_amd/csrc"
 make -j8 > /dev/null
 EXTRA=""; [ "$SRC" = gemm_nt256p.hip ] && EXTRA="-fno-honor-nans"
+[ "$SRC" = attention.hip ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form=1 -fno-honor-nans"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $EXTRA "$@" -c $SRC -o build/exp_tmp.o
 OBJS=$(for f in *.hip; do [ "$f" != "$SRC" ] && echo build/${f%.hip}.o; done)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libumr_exp.so $OBJS build/exp_tmp.o

@@ -238,7 +238,13 @@ __device__ __forceinline__ u32x2 ds_tr_b64(unsigned addr) {
 }
 
 template <int QB>   // 16-query blocks per wave: a workgroup covers 64 * QB queries; K / V^T fragments are read once per QB MFMAs
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+#ifndef UMR_ATTN_FWD_MIN_WAVES
+#define UMR_ATTN_FWD_MIN_WAVES 1   // experiment hook (tools/probe/build_exp_lib.sh attention.hip -DUMR_ATTN_FWD_MIN_WAVES=4)
+#endif
+#ifndef UMR_ATTN_DKV_MIN_WAVES
+#define UMR_ATTN_DKV_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, int N, int heads) {
     constexpr int TK = 64;                 // keys per tile
     constexpr int OPB = TK * 128;          // one operand tile: 8 KiB
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 }
 
 template <int KB>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+__global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
                                                                 int Npad, int heads) {
     constexpr int TQ = 64, OPB = TQ * 128, STB = 2 * OPB;

@@ -71,7 +71,7 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // X3 (dtype UMR_BF16X3, EPI 5): fp32-grade products from operands that arrive PRE-SPLIT into three bf16 planes per value
 // (x = h + m + l, exact for f32 data; umr_split3).  Operand rows hold [h(K) | m(K) | l(K)] (conv A: [h(Cin) | m(Cin) | l(Cin)]
 // per pixel; conv B: [plane][tap][ci]).  The K loop walks, for every 64-wide K-tile, the six plane pairs
-// (m,m) (l,h) (h,l) (m,h) (h,m) (h,h) -- the terms of (ah+am+al)(bh+bm+bl) above 2^-26 of the product -- as six ordinary bf16
+// (h,h) (h,m) (h,l) (m,h) (m,m) (l,h) -- the terms of (ah+am+al)(bh+bm+bl) above 2^-26 of the product -- as six ordinary bf16
 // K-tiles accumulated in f32: the main loop is the bf16 kernel unchanged (no split arithmetic in it; the 128x128 fp32 kernel of
 // gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
 // products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
@@ -195,9 +195,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             ++s_it;
             stage_setup(s_it);
         }
-        // X3: planes of this K-tile's pair, 2 bits per pair: (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
-        const int pa = X3 ? (((npairs == 6 ? 0x049 : 0x001) >> (2 * st_pp)) & 3) : 0;   // A planes 1,2,0,1,0,0  |  1,0,0
-        const int pb = X3 ? (((npairs == 6 ? 0x121 : 0x004) >> (2 * st_pp)) & 3) : 0;   // B planes 1,0,2,0,1,0  |  0,1,0
+        // X3: planes of this K-tile's pair, 2 bits per pair
+        // pairs ordered so that equal A planes are consecutive -- (h,h) (h,m) (h,l) (m,h) (m,m) (l,h): the second and third
+        // read of an A-plane tile come 1.5 us after the first and hit L2 (+1.8 % on the head conv against the order that
+        // alternated planes, tools/probe/x3_order_ab.sh); three-term mode: (h,h) (h,m) (m,h)
+        const int pa = X3 ? (((npairs == 6 ? 0x940 : 0x010) >> (2 * st_pp)) & 3) : 0;   // A planes 0,0,0,1,1,2  |  0,0,1
+        const int pb = X3 ? (((npairs == 6 ? 0x124 : 0x004) >> (2 * st_pp)) & 3) : 0;   // B planes 0,1,2,0,1,0  |  0,1,0
         const bool next_k = !X3 || st_pp == npairs - 1;
         if (X3) st_pp = next_k ? 0 : st_pp + 1;
         if (CONV == 0) {

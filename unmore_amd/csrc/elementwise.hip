@@ -200,8 +200,9 @@ struct PermEntry { const void* src; void* dst; int32_t d[4]; int64_t sstride[4];
                    int32_t e[4]; int32_t ord[4]; };
 static_assert(sizeof(PermEntry) == sizeof(umr_perm_entry), "umr_perm_entry layout");
 constexpr int PERM_TILE_MAX = 4608;
+constexpr int PERM_LDS_FLOATS = PERM_TILE_MAX;   // tile rows of e[3] floats are padded by one: e[0] e[1] e[2] (e[3] + 1) <= 4608
 __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* __restrict__ table, int n, const int32_t* __restrict__ blk_entry) {
-    __shared__ float tile[PERM_TILE_MAX];
+    __shared__ float tile[PERM_LDS_FLOATS];
     const int64_t b = blockIdx.x;
     int lo = 0;
     if (blk_entry) {
@@ -273,7 +274,9 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         if (in) {
             const int64_t si = e.soff + (int64_t)(org[0] + l[0]) * e.sstride[0] + (int64_t)(org[1] + l[1]) * e.sstride[1] +
                                (int64_t)(org[2] + l[2]) * e.sstride[2] + (int64_t)(org[3] + l[3]) * e.sstride[3];
-            tile[((l[0] * e.e[1] + l[1]) * e.e[2] + l[2]) * e.e[3] + l[3]] =
+            // row pitch e[3] + 1: the gather walks the tile along a dimension other than 3, i.e. at a stride of e[3] floats -- 64
+            // floats = 256 B = every lane on the same LDS bank without the pad (the transposes ran at 1.2 TB/s because of it)
+            tile[((l[0] * e.e[1] + l[1]) * e.e[2] + l[2]) * (e.e[3] + 1) + l[3]] =
                 e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
         }
     }
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         const int i0 = org[0] + l0, i1 = org[1] + l1, i2 = org[2] + l2, i3 = org[3] + l3;
         if (i0 < e.d[0] && i1 < e.d[1] && i2 < e.d[2] && i3 < e.d[3]) {
             const int64_t di = (((int64_t)i0 * e.d[1] + i1) * e.d[2] + i2) * e.d[3] + i3;
-            const float v = tile[idx];
+            const float v = tile[((l0 * e.e[1] + l1) * e.e[2] + l2) * (e.e[3] + 1) + l3];
             if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = v; else ((bf16_t*)e.dst)[di] = (bf16_t)v;
         }
     }

@@ -356,6 +356,18 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
     UMR_CHECK_ARG(workspace_bytes >= umr_layernorm_bwd_workspace(M, D), "layernorm_bwd: workspace too small");
     int nb = (M + 63) / 64;
     if (nb > 1024) nb = 1024;
+    {
+        // ONE round of workgroups: the bf16 kernel needs 214 VGPRs (two workgroups per CU), so more than 2 x CUs blocks run as a
+        // second, nearly empty round -- 577 blocks at the cfg2 token count took two rounds for 1.13 rounds of work
+        static int cus = 0;
+        if (cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                      ? prop.multiProcessorCount : 256;
+        }
+        if (nb > 2 * cus) nb = 2 * cus;
+    }
     const int rpb = (M + nb - 1) / nb;
     nb = (M + rpb - 1) / rpb;
     hipStream_t s = (hipStream_t)stream;

@@ -365,12 +365,13 @@ def _perm_tile(dims, strides):
     order = sorted(range(4), key=lambda k: (abs(strides[k]) if dims[k] > 1 else 0, k))   # size-1 dimensions first (free)
     e = [1, 1, 1, 1]
     e[3] = min(dims[3], 64)
-    prod = e[3]
+    rows_max = _PERM_TILE_MAX // (e[3] + 1)      # the kernel pads every row of e[3] floats by one (LDS bank spread)
+    rows = 1
     for k in order:
         if k == 3:
             continue
-        e[k] = max(1, min(dims[k], _PERM_TILE_MAX // prod))
-        prod *= e[k]
+        e[k] = max(1, min(dims[k], rows_max // rows))
+        rows *= e[k]
     return e, order
 
 

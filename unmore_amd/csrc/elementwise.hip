@@ -131,6 +131,114 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
     }
 }
 
+// bf16 with C % 8 == 0: the same two kernels on 16-byte accesses (one bf16x8 per tap instead of two bf16x4: half the vector-memory
+// instructions; the generic forms above reach 3.4 / 2.9 TB/s on the final x2 resize of the feature map, tools/bilinear_bench.py)
+__device__ __forceinline__ void ld_bf16x8(const bf16_t* p, float (&f)[8]) {
+    const bf16x8 t = *(const bf16x8*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)t[j];
+}
+// forward: a thread computes the same (ox, 8 channels) of FOUR consecutive output rows: its 16 loads are issued before the first
+// is used (one element per thread left the kernel latency-bound at 3.4 TB/s: tools/bilinear_bench.py)
+__global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
+                                                                int Wo, int C, int align) {
+    constexpr int R = 4;
+    const int cv = C >> 3;
+    const int rowlen = Wo * cv;
+    const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
+    const int groups = (Ho + R - 1) / R;
+    for (int bg = blockIdx.y; bg < B * groups; bg += gridDim.y) {
+        const int b = bg / groups, oy0 = (bg - b * groups) * R;
+        const bf16_t* xb = x + (int64_t)b * Hi * Wi * C;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+            const int ox = i / cv, c = (i - ox * cv) * 8;
+            int x0, x1;
+            float lx0, lx1;
+            src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+            bf16x8 t[R][4];
+            float ly0[R], ly1[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int oy = min(oy0 + r, Ho - 1);
+                int y0, y1;
+                src_index(oy, sh, align, Hi, y0, y1, ly0[r], ly1[r]);
+                const bf16_t* r0 = xb + (int64_t)y0 * Wi * C + c;
+                const bf16_t* r1 = xb + (int64_t)y1 * Wi * C + c;
+                t[r][0] = *(const bf16x8*)(r0 + (int64_t)x0 * C);
+                t[r][1] = *(const bf16x8*)(r0 + (int64_t)x1 * C);
+                t[r][2] = *(const bf16x8*)(r1 + (int64_t)x0 * C);
+                t[r][3] = *(const bf16x8*)(r1 + (int64_t)x1 * C);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (oy0 + r >= Ho) break;
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = (bf16_t)(ly0[r] * (lx0 * (float)t[r][0][j] + lx1 * (float)t[r][1][j]) + ly1[r] * (lx0 * (float)t[r][2][j] + lx1 * (float)t[r][3][j]));
+                *(bf16x8*)(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * C + c) = o;
+            }
+        }
+    }
+}
+// adjoint: the output pixels that touch input pixel i lie in [ (i-1)/s , (i+1)/s ) -- at most 2/s + 2 candidates per axis (8 for
+// s >= 0.4; the host picks this kernel only then).  Their weights are computed ONCE per thread and axis (the generic kernel
+// re-derives the x weights for every candidate row and scans 7 x 7 candidates at s = 0.5: index arithmetic, not memory, bound it
+// at 2.9 TB/s).
+__global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int Hi, int Wi, int Ho,
+                                                                int Wo, int C, int align) {
+    constexpr int NC = 8;
+    const int cv = C >> 3;
+    const int rowlen = Wi * cv;
+    const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
+    auto weights = [&](int i, float sc, int in, int out, int& lo, float (&wv)[NC]) {
+        lo = (int)floorf(((float)i - 1.f) / sc - 1e-3f);
+        if (lo < 0) lo = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int o = lo + k;
+            int i0, i1; float l0, l1;
+            src_index(o < out ? o : out - 1, sc, align, in, i0, i1, l0, l1);
+            wv[k] = (o < out) ? ((i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f)) : 0.f;
+        }
+    };
+    for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
+        const int b = by / Hi, iy = by - b * Hi;
+        int ylo;
+        float wy[NC];
+        weights(iy, sh, Hi, Ho, ylo, wy);
+        const bf16_t* base = dy + (int64_t)b * Ho * Wo * C;
+        bf16_t* xr = dx + (int64_t)by * Wi * C;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+            const int ix = i / cv, c = (i - ix * cv) * 8;
+            int xlo;
+            float wx[NC];
+            weights(ix, sw, Wi, Wo, xlo, wx);
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < NC; ++ky) {
+                if (wy[ky] == 0.f) continue;
+                const bf16_t* rowp = base + ((int64_t)(ylo + ky) * Wo + xlo) * C + c;
+#pragma unroll
+                for (int kx = 0; kx < NC; ++kx) {
+                    if (wx[kx] == 0.f) continue;
+                    float g[8];
+                    ld_bf16x8(rowp + (int64_t)kx * C, g);
+                    const float wgt = wy[ky] * wx[kx];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += g[j] * wgt;
+                }
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
+            *(bf16x8*)(xr + (int64_t)ix * C + c) = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- pixel shuffle (ConvTranspose k == stride)
 // src [B*H*W][s*s*C] (column = (i*s+j)*C + c)  <->  dst [B, H*s, W*s, C];  inverse=1 gathers dst -> src layout
 template <typename T>
@@ -610,6 +718,14 @@ extern "C" int umr_patchify(const float* images, void* out, int B, int H, int W,
     return UMR_OK;
 }
 
+// rows of blocks of the resize kernels: a block loops over (image, row) pairs at stride gridDim.y.  UMR_BILINEAR_GY (read per
+// launch) caps it: one output row per block is 1.2 M blocks of one element per thread at the cfg2 feature map
+static int bilinear_gy_cap() {
+    const char* e = getenv("UMR_BILINEAR_GY");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 65535;
+}
+
 extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
                                 umr_stream_t stream) {
     UMR_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
@@ -618,9 +734,14 @@ extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, i
         const int nv = (C % 8 == 0) ? 2 : 1;
         const int rowlen = Wo * (C / (4 * nv));
         int64_t gy = (int64_t)B * Ho;
-        if (gy > 65535) gy = 65535;
+        if (gy > bilinear_gy_cap()) gy = bilinear_gy_cap();
         const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
-        if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        if (nv == 2 && dtype == UMR_BF16) {
+            int64_t gy4 = (int64_t)B * ((Ho + 3) / 4);
+            if (gy4 > bilinear_gy_cap()) gy4 = bilinear_gy_cap();
+            hipLaunchKernelGGL(bilinear_fwd_bf16x8_kernel, dim3(g.x, (unsigned)gy4), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, align_corners);
+        }
+        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
         else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
     }
     UMR_LAUNCH_CHECK();
@@ -635,9 +756,13 @@ extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi,
         const int nv = (C % 8 == 0) ? 2 : 1;
         const int rowlen = Wi * (C / (4 * nv));
         int64_t gy = (int64_t)B * Hi;
-        if (gy > 65535) gy = 65535;
+        if (gy > bilinear_gy_cap()) gy = bilinear_gy_cap();
         const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
-        if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        const float sh_ = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) : (float)Hi / (float)Ho;
+        const float sw_ = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) : (float)Wi / (float)Wo;
+        if (nv == 2 && dtype == UMR_BF16 && sh_ >= 0.4f && sw_ >= 0.4f)    // <= 8 candidate outputs per axis (see the kernel)
+            hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
+        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
         else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
     }
     UMR_LAUNCH_CHECK();

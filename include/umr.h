@@ -109,7 +109,8 @@ typedef struct umr_gemm_desc {
  * B: [N][3K] bf16 (ldb >= 3K; conv: K = 9*Cin ordered (ky,kx,ci) inside each plane).  K (conv: Cin) must be a multiple of 64,
  * N of 8; epilogue: bias, ReLU, and exactly one of UMR_EPI_OUT_F32 (C f32 [M][N]) / UMR_EPI_OUT_X3 (C planes [M][3N] bf16) -- or,
  * for a plain GEMM, the fused row reduction red_* with no_store = 1 (dot products of the f32 values, C never stored);
- * no aux / remap / C2.  Anything else returns UMR_ERR_UNSUPPORTED. */
+ * optionally UMR_EPI_MASK_RELU with aux = an F32 [M][N] tensor (ldaux): v *= (aux > 0), the ReLU-masked data gradient;
+ * no other aux / remap / C2.  Anything else returns UMR_ERR_UNSUPPORTED. */
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */

@@ -441,7 +441,8 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
                                    (out_x3 ? (d->ldc % 8 == 0 && d->ldc >= 3 * (int64_t)d->N) : (d->ldc % 4 == 0)));
         const bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && out_ok && d->c2_mode == 0 &&
                         d->a_rows_in <= 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
-                        !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3)) && (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU) &&
+                        !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3 | UMR_EPI_MASK_RELU)) && (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU) &&
+                        (!(d->flags & UMR_EPI_MASK_RELU) || (d->aux && !red && d->ldaux % 4 == 0 && d->ldaux >= d->N)) &&
                         (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) &&
                         (d->conv == 1 ? (d->K == 9 * d->Cin && (int64_t)d->nb * d->Ho * d->Wo == d->M && d->Ho == d->H && d->Wo == d->W)
                                       : (d->lda % 8 == 0 && d->lda >= 3 * (int64_t)d->K));

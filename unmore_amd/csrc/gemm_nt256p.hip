@@ -760,6 +760,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             fetch_bias(it + 1);
             const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
             const bool planes = (p.flags & UMR_EPI_OUT_X3) != 0;
+            const bool maskf = (p.flags & UMR_EPI_MASK_RELU) != 0;
             if (RED) {
                 // fused output layer (1024 -> {1,2}) of a head at inference: dot products of the f32 values with the reduction
                 // weights (brought into the staging region by LDS-DMA at the start of the tile), C itself is never stored
@@ -816,6 +817,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], relu_floor); v1[e] = fmaxf(v1[e], relu_floor); }
+                    if (maskf) {   // ReLU-masked data gradient: aux = the f32 activation whose sign decides (objectness_net.py:111-115)
+                        const float* ap = (const float*)p.aux + (int64_t)m * p.ldaux + n;
+                        const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = a0[e] > 0.f ? v0[e] : 0.f; v1[e] = a1[e] > 0.f ? v1[e] : 0.f; }
+                    }
                     if (planes) {
                         bf16x8 h, mm, l;
 #pragma unroll

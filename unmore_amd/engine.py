@@ -266,6 +266,10 @@ class Engine:
         p = P[name]
         if kind == "lin":
             build = lambda: ops.split3(p.detach().reshape(p.shape[0], -1).contiguous())
+        elif kind == "lin_t":
+            build = lambda: ops.split3(_pack_linear_t(p.detach().reshape(p.shape[0], -1), torch.float32))
+        elif kind == "c3_d":
+            build = lambda: ops.split3(_pack_conv3_dgrad(p, torch.float32))
         else:
             build = lambda: ops.split3(_pack_conv3(p, torch.float32))
         return self.cache.get((name, kind + "_x3"), p, build)
@@ -476,6 +480,21 @@ class Engine:
             # (exact gradients from three pixel reductions over feat, _linear_head_backward); sin is not invertible from its value
             algebraic = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"
             keep = save and not algebraic
+            if x3_ok and keep and lay["final"] != "sine":
+                # fp32 training, a head whose backward reads its activations: the three big layers on the plane kernel with f32
+                # outputs (saved for the backward as before), a split pass between them
+                if featp is None:
+                    featp = ops.split3(feat.view(-1, 256))
+                b_ = lambda k: self._f32(P, f"{name}.{idx[k]}.bias")
+                h1 = ops.gemm_nt_x3(featp, self._wx3(P, f"{name}.{idx[0]}.weight", "lin"), b_(0), act=act)
+                h2 = ops.gemm_nt_x3(ops.split3(h1).view(B, H, W, -1), self._wx3(P, f"{name}.{idx[1]}.weight", "c3"), b_(1), act=act, conv=1)
+                h3 = ops.gemm_nt_x3(ops.split3(h2), self._wx3(P, f"{name}.{idx[2]}.weight", "lin"), b_(2), act=act)
+                w4 = self._f32(P, f"{name}.{idx[3]}.weight")
+                out = ops.head_out_fwd(h3, w4.reshape(w4.shape[0], -1), b_(3), B, H, W, _ACT[lay["final"]])
+                outs.append(out)
+                heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=out, x3=True))
+                del h1, h2, h3
+                continue
             h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
             h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
                              conv=1, act=act)
@@ -545,7 +564,11 @@ class Engine:
                                    G[f"{name}.{idx[3]}.weight"].view(w4.shape[0], -1), G[f"{name}.{idx[3]}.bias"])
             hs["h3"] = None
             wgrad_lin(f"{name}.{idx[2]}.weight", dh3, hs["h2"], f"{name}.{idx[2]}.bias")
-            dh2 = ops.gemm_nt(dh3, self._w(P, f"{name}.{idx[2]}.weight", "lin_t"), None, aux=(hs["h2"] if relu else None), mask_relu=relu)
+            x3b = bool(hs.get("x3")) and dt == torch.float32
+            if x3b:
+                dh2 = ops.gemm_nt_x3(ops.split3(dh3), self._wx3(P, f"{name}.{idx[2]}.weight", "lin_t"), None, mask=(hs["h2"] if relu else None))
+            else:
+                dh2 = ops.gemm_nt(dh3, self._w(P, f"{name}.{idx[2]}.weight", "lin_t"), None, aux=(hs["h2"] if relu else None), mask_relu=relu)
             del dh3
             h1 = hs["h1"].view(B, H, W, 512)
             wgrad_c3(f"{name}.{idx[1]}.weight", dh2, h1, f"{name}.{idx[1]}.bias")
@@ -553,9 +576,13 @@ class Engine:
             c1 = hs["h1"].shape[-1]
             if merge_dfeat and dh1cat is None:
                 dh1cat = torch.empty((B * H * W, 2 * c1), dtype=dt, device=dev)
-            dh1 = ops.gemm_nt(dh2.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
-                              aux=(hs["h1"] if relu else None), mask_relu=relu,
-                              out=(dh1cat[:, hi * c1:(hi + 1) * c1] if merge_dfeat else None))
+            if x3b and not merge_dfeat:
+                dh1 = ops.gemm_nt_x3(ops.split3(dh2).view(B, H, W, -1), self._wx3(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
+                                     mask=(hs["h1"] if relu else None))
+            else:
+                dh1 = ops.gemm_nt(dh2.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
+                                  aux=(hs["h1"] if relu else None), mask_relu=relu,
+                                  out=(dh1cat[:, hi * c1:(hi + 1) * c1] if merge_dfeat else None))
             del dh2
             hs["h1"] = None
             wgrad_lin(f"{name}.{idx[0]}.weight", dh1, feat.view(-1, 256), f"{name}.{idx[0]}.bias")

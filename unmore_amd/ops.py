@@ -162,7 +162,7 @@ def split3(x, out=None):
     return out
 
 
-def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, red_w=None):
+def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, red_w=None, mask=None):
     """fp32-grade C = act(A . B^T + bias) from operands held as three bf16 planes per f32 value (split3): Ap [M, 3K] (or NHWC
     [nb,H,W,3*Cin] when conv == 1), Bp [N, 3K].  Returns f32 [M, N], or planes [M, 3N] bf16 with out_planes=True (what the next
     gemm_nt_x3 layer takes).  Persistent 256x256 bf16 kernel, six plane pairs per K-tile (csrc/gemm_nt256p.hip, X3)."""
@@ -199,6 +199,11 @@ def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, r
     if bias is not None:
         assert bias.dtype == torch.float32
         flags |= L.EPI_BIAS
+    if mask is not None:   # ReLU-masked data gradient: keep the result where the f32 tensor `mask` [M, N] is > 0
+        m2 = mask.reshape(-1, N)
+        assert mask.dtype == torch.float32 and m2.stride(1) == 1 and m2.shape[0] == M_ and red_w is None
+        flags |= L.EPI_MASK_RELU
+        d.aux, d.ldaux = _p(m2), m2.stride(0)
     d.A, d.B, d.C, d.bias = _p(Ap), _p(Bp), _p(out), _p(bias)
     d.ldb, d.ldc = Bp.stride(0), (out.stride(0) if out is not None else N)
     d.M, d.N, d.K, d.dtype = M_, N, K, L.BF16X3

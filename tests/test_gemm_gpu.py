@@ -564,3 +564,65 @@ def test_two_workgroups_per_cu_kernel_equals_persistent_kernel(M, N, K, monkeypa
     gold = x.float() @ w.float().t() + bias
     torch.testing.assert_close(new[0].float(), gold, atol=3e-2, rtol=3e-2)
     torch.testing.assert_close(new[2].float(), gold + aux.float(), atol=5e-2, rtol=3e-2)
+
+
+def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
+    """40 random plain-GEMM problems (ragged M and N, K a multiple of 64, every epilogue class) through the persistent 256x256
+    kernel -- every tile height it may choose -- against the 128x128 kernel (the one the fixture tests exercise): bf16 results
+    within two output ulps of each other and of torch fp32; the fp32 plane kernel against the in-register-split kernel to 2e-6."""
+    import random
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    rng = random.Random(1234)
+    for case in range(40):
+        M = rng.choice([1, 17, 255, 256, 257, 1000, 4097, 20000 + rng.randrange(512)])
+        N = 8 * rng.randrange(24, 130)
+        K = 64 * rng.randrange(1, 9)
+        kind = rng.choice(["bias_relu", "residual", "mask", "gelu2", "dgelu", "f32out", "red", "x3"])
+        x = _rnd((M, K), torch.bfloat16, dev, 1000 + case)
+        w = _rnd((N, K), torch.bfloat16, dev, 2000 + case, K ** -0.5)
+        bias = _rnd((N,), torch.float32, dev, 3000 + case)
+        aux = _rnd((M, N), torch.bfloat16, dev, 4000 + case)
+        redw = _rnd((2, N), torch.float32, dev, 5000 + case, N ** -0.5)
+
+        def run():
+            if kind == "bias_relu":
+                return [ops.gemm_nt(x, w, bias, act=L.ACT_RELU)]
+            if kind == "residual":
+                return [ops.gemm_nt(x, w, bias, aux=aux)]
+            if kind == "mask":
+                return [ops.gemm_nt(x, w, None, aux=aux, mask_relu=True)]
+            if kind == "gelu2":
+                return list(ops.gemm_nt(x, w, bias, act=L.ACT_GELU, c2_mode=2))
+            if kind == "dgelu":
+                return [ops.gemm_nt(x, w, None, aux=aux, mask_dgelu=True)]
+            if kind == "f32out":
+                return [ops.gemm_nt(x, w, bias, out_f32=True)]
+            return []
+
+        if kind == "x3":
+            xf, wf = x.float() * 1.37, w.float() * 0.91
+            a = ops.gemm_nt_x3(ops.split3(xf), ops.split3(wf), bias, act=L.ACT_RELU)
+            b = ops.gemm_nt(xf, wf, bias, act=L.ACT_RELU)
+            torch.testing.assert_close(a, b, atol=2e-6 * float(b.abs().max() + 1), rtol=0)
+            continue
+        if kind == "red":
+            monkeypatch.setenv("UMR_GEMM_TILE", "256")
+            h, parts = ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw)
+            out = ops.head_out_finish(parts, torch.zeros(2, device=dev), 1, 1, M, L.ACT_NONE)[0, :, 0, :].t()
+            ref = h.float() @ redw.t()
+            torch.testing.assert_close(out, ref, atol=2e-3, rtol=2e-3)
+            continue
+        monkeypatch.setenv("UMR_GEMM_TILE", "128")
+        small = run()
+        for bm in ("0", "256", "224", "192"):
+            monkeypatch.setenv("UMR_GEMM_TILE", "256")
+            if bm == "0":
+                monkeypatch.delenv("UMR_NT256_BM", raising=False)
+            else:
+                monkeypatch.setenv("UMR_NT256_BM", bm)
+            big = run()
+            for a, b in zip(small, big):
+                tol = 1e-5 if a.dtype == torch.float32 else 2.0 ** -7
+                assert ((a.float() - b.float()).abs() <= tol * (b.float().abs() + 1)).all(), (case, kind, M, N, K, bm)
+        monkeypatch.delenv("UMR_NT256_BM", raising=False)

@@ -74,6 +74,22 @@ def test_peak_oracle_matches_reference_functions(tag):
             assert (int(arg[b]) // W, int(arg[b]) % W) == (int(yx[b, 0]), int(yx[b, 1]))
 
 
+@pytest.mark.parametrize("tag", sorted(pc.SYN) + sorted(pc.E2E))
+def test_oracle_peak_certificate_matches_the_fixture(tag):
+    """oracle.peak_certificate (used by bench.py --workload cfg5 to say which peak-index mismatches would be real errors) against
+    the certificate the fixture generator computed with the reference's own erode / score functions: same certified set"""
+    g = pc.load()
+    if tag in pc.SYN:
+        B, H, W, seed = pc.SYN[tag]
+        sdf, cen = (torch.from_numpy(a) for a in synth.object_like_fields(B, H, W, seed))
+    else:
+        sdf, cen = torch.from_numpy(g[f"{tag}_sdf_maps"]), torch.from_numpy(g[f"{tag}_center_fields"])
+        B = sdf.shape[0]
+    amax, arg, cert = orc.peak_certificate(sdf, cen, float(g["meta_cert_eps"]))
+    np.testing.assert_array_equal(arg.numpy(), g[f"{tag}_argmax"][:B])
+    np.testing.assert_array_equal(cert.numpy(), g[f"{tag}_argmax_certified"][:B].astype(bool))
+
+
 @pytest.mark.parametrize("tag", sorted(pc.E2E))
 def test_oracle_forward_to_peaks_matches_reference(tag):
     """oracle forward (edited hash weights, blob images) -> oracle peaks == reference forward -> reference peaks"""

@@ -623,6 +623,7 @@ def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
                 monkeypatch.setenv("UMR_NT256_BM", bm)
             big = run()
             for a, b in zip(small, big):
-                tol = 1e-5 if a.dtype == torch.float32 else 2.0 ** -7
+                # bf16: the large-tile path rounds acc + bias to bf16 before a residual add / mask (documented in include/umr.h): two output ulps
+                tol = 1e-5 if a.dtype == torch.float32 else 2.0 ** -6
                 assert ((a.float() - b.float()).abs() <= tol * (b.float().abs() + 1)).all(), (case, kind, M, N, K, bm)
         monkeypatch.delenv("UMR_NT256_BM", raising=False)

@@ -205,6 +205,41 @@ def test_head_out(dtype, Cout, act):
     torch.testing.assert_close(db.double(), br.grad, atol=2e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("Cout,act,relu_mask", [(2, 3, True), (1, 0, False), (2, 0, True)])
+def test_head_out_bwd_k1024_kernel_against_generic_and_fp64(Cout, act, relu_mask, monkeypatch):
+    """The 1024-channel bf16 kernel (64-row runs, two row streams per block, ragged last runs, runs that straddle an image
+    boundary) against the generic kernel and an fp64 reference."""
+    from unmore_amd import ops
+    dev = _dev()
+    B, H, W, K = 3, 37, 41, 1024
+    h = _rnd((B * H * W, K), torch.bfloat16, dev, 1)
+    w = _rnd((Cout, K), torch.float32, dev, 2, K ** -0.5)
+    dout = _rnd((B, Cout, H, W), torch.float32, dev, 4)
+    yout = torch.tanh(_rnd((B, Cout, H, W), torch.float32, dev, 5))
+    got = {}
+    for name in ("k1024", "generic"):
+        if name == "generic":
+            monkeypatch.setenv("UMR_HEAD_OUT_BWD_GENERIC", "1")
+        else:
+            monkeypatch.delenv("UMR_HEAD_OUT_BWD_GENERIC", raising=False)
+        dw = torch.full_like(w, float("nan"))
+        db = torch.full((Cout,), float("nan"), device=dev)
+        dh = ops.head_out_bwd(h, w, dout, yout, act, relu_mask, dw, db)
+        got[name] = (dh, dw, db)
+    g = dout.double() * ((1 - yout.double() ** 2) if act == 3 else 1.0)
+    g = g.permute(0, 2, 3, 1).reshape(-1, Cout)
+    dh_ref = g @ w.double()
+    if relu_mask:
+        dh_ref = dh_ref * (h.double() > 0)
+    for name, (dh, dw, db) in got.items():
+        torch.testing.assert_close(dh.double(), dh_ref, atol=2e-2, rtol=2e-2, msg=lambda m: f"{name}: {m}")
+        torch.testing.assert_close(dw.double(), g.t() @ h.double(), atol=2e-3, rtol=1e-4, msg=lambda m: f"{name}: {m}")
+        torch.testing.assert_close(db.double(), g.sum(0), atol=1e-3, rtol=1e-5, msg=lambda m: f"{name}: {m}")
+    # the two kernels round the same f32 value to bf16, up to the contraction of w0*g0 + w1*g1: at most one bf16 ulp apart
+    a, b = got["k1024"][0].float(), got["generic"][0].float()
+    assert float(((a - b).abs() / b.abs().clamp_min(1e-3)).max()) <= 2 ** -7
+
+
 @pytest.mark.parametrize("center_l2,sdf_l2,use_grad,use_bce", [(True, False, True, True), (False, True, True, False),
                                                                (True, False, False, False)])
 def test_loss_matches_oracle(center_l2, sdf_l2, use_grad, use_bce):

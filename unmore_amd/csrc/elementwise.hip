@@ -564,6 +564,106 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const T* __restrict__
     if (t == 0) { p[2 * K] = b0; p[2 * K + 1] = b1; }
 }
 
+// K = 1024, bf16 (the centre head's 1024-channel layer: 19.3 GB in, 19.3 GB out at cfg2).  The generic kernel above walks its
+// rows one at a time behind a chain of scalar loads of dout / yout (one 8-byte load in flight per lane: 5.1 TB/s).  Here a wave
+// owns one 512-column half of a run of 64 consecutive rows: lane l first fetches the gradient pair of row l (coalesced), the row
+// loop broadcasts it with v_readlane and keeps HOB_UNROLL 16-byte loads per lane in flight.  Waves (half, stream) = (wv & 1,
+// wv >> 1); the two row streams of a block are added in a fixed order through LDS, so the partial slab keeps its layout.
+#ifndef HOB_UNROLL
+#define HOB_UNROLL 2
+#endif
+#ifndef HOB_NT
+#define HOB_NT 0
+#endif
+__global__ __launch_bounds__(256) void head_out_bwd_k1024_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w,
+                                                                 const float* __restrict__ dout, const float* __restrict__ yout,
+                                                                 bf16_t* __restrict__ dh, float* __restrict__ part, int64_t M, int Cout,
+                                                                 int HW, int act, int relu_mask, int rows_per_block) {
+    constexpr int K = 1024;
+    __shared__ float sh[2 * K + 2];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch = wv & 1, rs = wv >> 1;
+    const int col = ch * 512 + lane * 8;
+    float w0[8], w1[8], a0[8], a1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w0[j] = w[col + j]; w1[j] = Cout == 2 ? w[K + col + j] : 0.f; a0[j] = 0.f; a1[j] = 0.f; }
+    float bs0 = 0.f, bs1 = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int64_t base = r0 + rs * 64; base < r1; base += 128) {
+        const int n = (int)(r1 - base < 64 ? r1 - base : 64);
+        float g0v = 0.f, g1v = 0.f;
+        if (lane < n) {
+            const int64_t m = base + lane;
+            const int64_t b = m / HW, hw = m - b * HW;
+            const int64_t o0 = (b * Cout) * HW + hw;
+            g0v = dout[o0];
+            if (act == UMR_ACT_TANH) { const float y = yout[o0]; g0v *= (1.f - y * y); }
+            if (Cout == 2) {
+                g1v = dout[o0 + HW];
+                if (act == UMR_ACT_TANH) { const float y = yout[o0 + HW]; g1v *= (1.f - y * y); }
+            }
+        }
+        bs0 += g0v;
+        bs1 += g1v;
+        const bf16_t* hp = h + base * K + col;
+        bf16_t* dp = dh + base * K + col;
+        auto row = [&](const bf16x8 t, int i) {
+            const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0v), i));
+            const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1v), i));
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float hv = (float)t[j];
+                float d = w0[j] * g0 + w1[j] * g1;
+                if (relu_mask) d = hv > 0.f ? d : 0.f;
+                o[j] = (bf16_t)d;
+                a0[j] += hv * g0;
+                a1[j] += hv * g1;
+            }
+#if HOB_NT & 2
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, o), (f32x4*)(dp + (int64_t)i * K));
+#else
+            *(bf16x8*)(dp + (int64_t)i * K) = o;
+#endif
+        };
+        int i = 0;
+        for (; i + HOB_UNROLL <= n; i += HOB_UNROLL) {
+            bf16x8 t[HOB_UNROLL];
+#pragma unroll
+            for (int u = 0; u < HOB_UNROLL; ++u) {
+#if HOB_NT & 1
+                t[u] = __builtin_bit_cast(bf16x8, __builtin_nontemporal_load((const f32x4*)(hp + (int64_t)(i + u) * K)));
+#else
+                t[u] = *(const bf16x8*)(hp + (int64_t)(i + u) * K);
+#endif
+            }
+#pragma unroll
+            for (int u = 0; u < HOB_UNROLL; ++u) row(t[u], i + u);
+        }
+        for (; i < n; ++i) row(*(const bf16x8*)(hp + (int64_t)i * K), i);
+    }
+    bs0 = wave_sum(bs0);
+    bs1 = wave_sum(bs1);
+    for (int s = 0; s < 2; ++s) {
+        if (rs == s) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                sh[col + j] = s ? sh[col + j] + a0[j] : a0[j];
+                sh[K + col + j] = s ? sh[K + col + j] + a1[j] : a1[j];
+            }
+            if (ch == 0 && lane == 0) {
+                sh[2 * K] = s ? sh[2 * K] + bs0 : bs0;
+                sh[2 * K + 1] = s ? sh[2 * K + 1] + bs1 : bs1;
+            }
+        }
+        __syncthreads();
+    }
+    float* p = part + (int64_t)blockIdx.x * (2 * K + 2);
+    for (int i = threadIdx.x; i < 2 * K + 2; i += 256) p[i] = sh[i];
+}
+
 // fixed-order sum of the per-block partials: 64 entries x 4 interleaved block slices per workgroup, four independent
 // accumulation chains per thread (the one-thread-per-entry loop over 2048 blocks took 0.7 ms)
 __global__ __launch_bounds__(256) void head_out_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
@@ -905,7 +1005,12 @@ extern "C" int umr_head_out_bwd(const void* h, const float* w, const float* dout
     const int rpb = (int)((M + nb - 1) / nb);
     nb = (int)((M + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
-    DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)h, w, dout, yout, (T*)dh, (float*)workspace, M, K, Cout, HW, act, relu_mask, rpb));
+    const bool generic_only = getenv("UMR_HEAD_OUT_BWD_GENERIC") != nullptr;   // A/B hook, read per launch (tests compare both forms)
+    if (dtype == UMR_BF16 && K == 1024 && act != 4 && !generic_only) {
+        hipLaunchKernelGGL(head_out_bwd_k1024_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)h, w, dout, yout, (bf16_t*)dh, (float*)workspace, M, Cout, HW, act, relu_mask, rpb);
+    } else {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(head_out_bwd_kernel<T>, dim3(nb), dim3(256), 0, s, (const T*)h, w, dout, yout, (T*)dh, (float*)workspace, M, K, Cout, HW, act, relu_mask, rpb));
+    }
     UMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_out_reduce_kernel, dim3((2 * K + 2 + 63) / 64), dim3(256), 0, s, (const float*)workspace, dw, db, nb, K, Cout);
     UMR_LAUNCH_CHECK();

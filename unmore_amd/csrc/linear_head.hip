@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void lh_fwd_kernel(const T* __restrict__ x, co
 // coalesced 512-byte (bf16) access and every element of the big tensor is touched once (the first version walked the 9
 // taps per output pixel and pulled every channel vector nine times through L1/L2: 10.6 + 6.6 ms at cfg2, against the
 // 1.2 + 2.4 ms of the HBM traffic).
+#ifndef LH_WEIGHT_UNROLL
+#define LH_WEIGHT_UNROLL 4
+#endif
+#ifndef LH_DATA_UNROLL
+#define LH_DATA_UNROLL 1
+#endif
 struct RunG { float g[3][3]; };   // [row dy = -1,0,1][column shift dx = -1,0,1], lane l <-> pixel x0 + l
 
 __device__ __forceinline__ RunG load_run_g(const float* __restrict__ dout, const float* __restrict__ yout, int64_t rowbase, int py, int x0,
@@ -91,13 +97,31 @@ __global__ __launch_bounds__(256) void lh_bwd_data_kernel(const float* __restric
         const int n = (W - x0) < 64 ? (W - x0) : 64;
         const RunG r = load_run_g(dout, yout, rowbase, py, x0, H, W, act, lane);
         T* o = dx + (rowbase + x0) * C + lane * 4;
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
+        // blocked by hand for the same reason as lh_bwd_weight_kernel (convergent v_readlane blocks "#pragma unroll N")
+        int i = 0;
+        for (; i + LH_DATA_UNROLL <= n; i += LH_DATA_UNROLL) {
+            f32x4 acc[LH_DATA_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LH_DATA_UNROLL; ++u) {
+                acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (accumulate) acc[u] = Vec4<T>::load(o + (int64_t)(i + u) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < LH_DATA_UNROLL; ++u) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    // tap t of output pixel q = p - off_t reads x(p): g at row py - (t/3 - 1), column px - (t%3 - 1)
+                    const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.g[2 - t / 3][2 - t % 3]), i + u));
+                    acc[u] += k[t] * g;
+                }
+                Vec4<T>::store(o + (int64_t)(i + u) * C, acc[u]);
+            }
+        }
+        for (; i < n; ++i) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             if (accumulate) acc = Vec4<T>::load(o + (int64_t)i * C);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                // tap t of output pixel q = p - off_t reads x(p): g at row py - (t/3 - 1), column px - (t%3 - 1)
                 const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.g[2 - t / 3][2 - t % 3]), i));
                 acc += k[t] * g;
             }
@@ -112,7 +136,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void lh_bwd_weight_kernel(const T* __restrict__ x, const float* __restrict__ dout,
                                                             const float* __restrict__ yout, float* __restrict__ part, int B, int H, int W,
                                                             int C, int act, int runs_per_row, int64_t total_runs, int64_t runs_per_block) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];  // [4 waves][9*C + 16]
+    extern __shared__ __attribute__((aligned(16))) float sh[];  // [9*C + 16]: the four waves add their partials in turn
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t r0 = (int64_t)blockIdx.x * runs_per_block;
@@ -134,8 +158,24 @@ __global__ __launch_bounds__(256) void lh_bwd_weight_kernel(const T* __restrict_
 #pragma unroll
             for (int t = 0; t < 9; ++t) nt[t] += r.g[2 - t / 3][2 - t % 3];
         }
-#pragma unroll 4
-        for (int i = 0; i < n; ++i) {
+        // v_readlane is convergent, so the compiler refuses "#pragma unroll N" on a run-time trip count (a remainder loop
+        // would duplicate it under new control flow) and the loop ran with ONE 512-byte load in flight per wave: 2.9 TB/s.
+        // Blocked by hand: LH_WEIGHT_UNROLL loads issued back to back, then their 9 x U broadcasts and FMAs.
+        int i = 0;
+        for (; i + LH_WEIGHT_UNROLL <= n; i += LH_WEIGHT_UNROLL) {
+            f32x4 v[LH_WEIGHT_UNROLL];
+#pragma unroll
+            for (int u = 0; u < LH_WEIGHT_UNROLL; ++u) v[u] = Vec4<T>::load(xi + (int64_t)(i + u) * C);
+#pragma unroll
+            for (int u = 0; u < LH_WEIGHT_UNROLL; ++u) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float g = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.g[2 - t / 3][2 - t % 3]), i + u));
+                    acc[t] += v[u] * g;
+                }
+            }
+        }
+        for (; i < n; ++i) {
             const f32x4 v = Vec4<T>::load(xi + (int64_t)i * C);
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -144,26 +184,54 @@ __global__ __launch_bounds__(256) void lh_bwd_weight_kernel(const T* __restrict_
             }
         }
     }
+    // one slab of LDS (9.3 KB instead of 37 KB, so the block count is bounded by registers: 8 waves per SIMD keep twice the
+    // bytes in flight of the four-slab version) -- waves 0..3 add in a fixed order, so the result is reproducible
     const int stride = 9 * C + 16;
-    float* mine = sh + wv * stride;
+    float ns[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        *(f32x4*)(mine + t * C + lane * 4) = acc[t];
-        const float s = wave_sum(nt[t]);
-        if (lane == 0) mine[9 * C + t] = s;
-        if (lane == 0 && t == 4) mine[9 * C + 9] = s;   // D = sum_p g(p): the centre tap is inside for every pixel
+    for (int t = 0; t < 9; ++t) ns[t] = wave_sum(nt[t]);
+    for (int w = 0; w < 4; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                f32x4* d = (f32x4*)(sh + t * C + lane * 4);
+                *d = w ? *d + acc[t] : acc[t];
+                if (lane == 0) sh[9 * C + t] = w ? sh[9 * C + t] + ns[t] : ns[t];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* o = part + (int64_t)blockIdx.x * stride;
-    for (int i = threadIdx.x; i < 9 * C + 10; i += 256) o[i] = (sh[i] + sh[stride + i]) + (sh[2 * stride + i] + sh[3 * stride + i]);
+    for (int i = threadIdx.x; i < 9 * C + 9; i += 256) o[i] = sh[i];
+    if (threadIdx.x == 0) o[9 * C + 9] = sh[9 * C + 4];   // D = sum_p g(p): the centre tap is inside for every pixel
 }
 
-__global__ void lh_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int n, int stride) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// block = 64 columns x 16 slab phases; phase y sums slabs y, y+16, ... (8 loads in flight), the 16 phase sums are added in
+// a fixed order through LDS (one thread per column walking all slabs serially took 0.29 ms for 9.5 MB)
+__global__ __launch_bounds__(1024) void lh_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int n, int stride) {
+    __shared__ float sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * stride + i];
-    out[i] = s;
+    if (i < n) {
+        int b = ty;
+        for (; b + 16 * 7 < nblocks; b += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + 16 * u) * stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; b < nblocks; b += 16) s += part[(int64_t)b * stride + i];
+    }
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n) {
+        float r = sh[0][tx];
+#pragma unroll
+        for (int y = 1; y < 16; ++y) r += sh[y][tx];
+        out[i] = r;
+    }
 }
 
 // tiny strided f32 matrix product for the weight algebra of the collapsed head (all operands <= a few MB):
@@ -201,7 +269,10 @@ __global__ __launch_bounds__(256) void small_gemm_wave_kernel(const float* __res
     }
 }
 
-int lh_blocks(int64_t M) { int64_t nb = (M + 4095) / 4096; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1; return (int)nb; }   // upper bound on partial slabs (4 blocks per CU)
+#ifndef LH_BLOCKS_CAP
+#define LH_BLOCKS_CAP 2048
+#endif
+int lh_blocks(int64_t M) { int64_t nb = (M + 4095) / 4096; if (nb > LH_BLOCKS_CAP) nb = LH_BLOCKS_CAP; if (nb < 1) nb = 1; return (int)nb; }   // upper bound on partial slabs (8 blocks per CU)
 
 }  // namespace
 
@@ -256,11 +327,11 @@ extern "C" int umr_linear_head_bwd_weight(const void* x, const float* dout, cons
     const int64_t rpb = (runs + nb - 1) / nb;
     nb = (int)((runs + rpb - 1) / rpb);
     const int stride = 9 * C + 16;
-    const size_t lds = (size_t)4 * stride * 4;
+    const size_t lds = (size_t)stride * 4;
     hipStream_t s = (hipStream_t)stream;
     LH_DISPATCH(dtype, hipLaunchKernelGGL(lh_bwd_weight_kernel<T>, dim3(nb), dim3(256), lds, s, (const T*)x, dout, yout, (float*)workspace, B, H, W, C, act, rpr, runs, rpb));
     UMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lh_reduce_kernel, dim3((9 * C + 10 + 255) / 256), dim3(256), 0, s, (const float*)workspace, out, nb, 9 * C + 10, stride);
+    hipLaunchKernelGGL(lh_reduce_kernel, dim3((9 * C + 10 + 63) / 64), dim3(1024), 0, s, (const float*)workspace, out, nb, 9 * C + 10, stride);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -15,7 +15,7 @@ K = 1024
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 M = B * H * W
-h = torch.randn(M, K, device=dev).bfloat16()
+h = torch.randn(M, K, device=dev).relu_().bfloat16()   # post-ReLU activations, as in the step
 w = torch.randn(2, K, device=dev) * 0.05
 dout = torch.randn(B, 2, H, W, device=dev)
 yout = torch.tanh(torch.randn(B, 2, H, W, device=dev))

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     auto stage_issue = [&](auto gtag, auto itag) {
         constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
         char* dst = smem + (st_tile & 1) * TBUF + G * TSUB + (w * 2 + I) * 1024;
-        if (G == 0 || G == 3) {
+        if constexpr (G == 0 || G == 3) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], soffY, 0, 0);
         } else {
             const unsigned v = (CONV == 0) ? vo[G][I] : x_eff[G - 1][I];

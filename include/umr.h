@@ -182,7 +182,8 @@ int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int6
  * table_dev: n entries IN DEVICE MEMORY, sorted by blk_start; entry e covers blocks [blk_start_e, blk_start_{e+1}), blk_start_0 = 0;
  * total_blocks = the sum.  Same element semantics as umr_permute4 (dst[i0,i1,i2,i3] = src[soff + sum i_k * sstride[k]], cast to
  * dtype_out; no accumulate).  Block shape per entry: e[3] == 0 -> linear, ceil(elements / 8192) blocks of 8192 consecutive
- * destination elements; otherwise TILED: a block handles the hyper-rectangle e[0] x e[1] x e[2] x e[3] (e[0] e[1] e[2] (e[3] + 1) <= 4608) of the
+ * destination elements; e[3] == -1 -> 2-D transpose (needs d[0] == d[1] == 1, sstride[2] == 1): ceil(d[2] / 64) * ceil(d[3] / 64)
+ * blocks of 64 x 64, tile coordinate of dimension 3 fastest; otherwise TILED: a block handles the hyper-rectangle e[0] x e[1] x e[2] x e[3] (e[0] e[1] e[2] (e[3] + 1) <= 4608) of the
  * destination index space, read in source-address order (ord[] = the four dimensions by ascending |sstride|) through LDS --
  * prod_k ceil(d[k] / e[k]) blocks, tile coordinate of dimension 3 fastest.  Use tiles when the innermost destination dimension
  * is strided in the source (transposes). */

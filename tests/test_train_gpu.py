@@ -444,7 +444,9 @@ def test_permute4_batched_equals_single_launches():
     record(lambda: engine._rep_bias(torch.randn(96, generator=g).to(dev), 16))
     big = torch.randn(300001, generator=g).to(dev)      # a cast (1-D) with a ragged tail, more than one block
     record(lambda: ops.cast(big, torch.bfloat16))
-    assert sum(ops._perm_tile(r[2], r[3]) is not None for r in recipes) >= 10 and any(ops._perm_tile(r[2], r[3]) is None for r in recipes)
+    kinds = [ops._perm_tile(r[2], r[3]) for r in recipes]
+    assert sum(k is not None for k in kinds) >= 10 and any(k is None for k in kinds)
+    assert sum(k == "t2d" for k in kinds) >= 3 and any(isinstance(k, tuple) for k in kinds)   # 64x64 transposes and generic tiles
     launch = ops.permute4_batched(recipes)
     launch()
     torch.cuda.synchronize()

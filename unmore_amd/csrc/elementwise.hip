@@ -360,6 +360,38 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         }
         return;
     }
+    if (e.e[3] < 0) {
+        // 2-D transpose (the Linear weights' data-gradient form, [N,K] f32 -> [K,N] bf16: most of the transposed bytes): 64 x 64
+        // tiles, shifts instead of the generic tile's run-time divisions (three per element, twice), 16 loads in flight per
+        // thread.  dst[r][c] = src[soff + r * sstride[2] + c * sstride[3]], sstride[2] == 1: reads run along r, writes along c.
+        const int R = e.d[2], C = e.d[3];
+        const int ntc = (C + 63) >> 6;
+        const int r0 = (int)(lb / ntc) << 6, c0 = (int)(lb % ntc) << 6;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int cc = c0 + k * 4 + ty, rr = r0 + tx;
+            v[k] = 0.f;
+            if (cc < C && rr < R) {
+                const int64_t si = e.soff + (int64_t)rr + (int64_t)cc * e.sstride[3];
+                v[k] = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[(k * 4 + ty) * 65 + tx] = v[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int rr = k * 4 + ty, cc = tx;
+            if (r0 + rr < R && c0 + cc < C) {
+                const float o = tile[cc * 65 + rr];
+                const int64_t di = (int64_t)(r0 + rr) * C + c0 + cc;
+                if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = o; else ((bf16_t*)e.dst)[di] = (bf16_t)o;
+            }
+        }
+        return;
+    }
     // tiled: tile coordinates (dimension 3 fastest), then its origin
     int nt[4], org[4];
 #pragma unroll

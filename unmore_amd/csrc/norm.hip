@@ -342,9 +342,16 @@ extern "C" int umr_layernorm_fwd(const void* x, const float* gamma, const float*
     return UMR_OK;
 }
 
-extern "C" int64_t umr_layernorm_bwd_workspace(int M, int D) {
-    int nb = (M + 63) / 64;
+// partial slabs: one per workgroup; a workgroup takes >= 8 rows (one pass of its four waves x two rows).  64 rows per
+// workgroup left a 1300-token batch (the reference's 128^2 recipe) on 21 of 256 CUs: 44 us for 5 MB
+static int ln_bwd_blocks(int M) {
+    int nb = (M + 7) / 8;
     if (nb > 1024) nb = 1024;
+    return nb;
+}
+
+extern "C" int64_t umr_layernorm_bwd_workspace(int M, int D) {
+    int nb = ln_bwd_blocks(M);
     return (int64_t)nb * 2 * D * 4;
 }
 
@@ -354,8 +361,7 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
     UMR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
     UMR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D must be a multiple of 8, <= 2048");
     UMR_CHECK_ARG(workspace_bytes >= umr_layernorm_bwd_workspace(M, D), "layernorm_bwd: workspace too small");
-    int nb = (M + 63) / 64;
-    if (nb > 1024) nb = 1024;
+    int nb = ln_bwd_blocks(M);
     {
         // ONE round of workgroups: the bf16 kernel needs 214 VGPRs (two workgroups per CU), so more than 2 x CUs blocks run as a
         // second, nearly empty round -- 577 blocks at the cfg2 token count took two rounds for 1.13 rounds of work

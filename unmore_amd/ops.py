@@ -367,6 +367,8 @@ def _perm_tile(dims, strides):
     total = dims[0] * dims[1] * dims[2] * dims[3]
     if abs(strides[3]) == 1 or dims[3] == 1 or total < 4096:
         return None
+    if dims[0] == 1 and dims[1] == 1 and strides[2] == 1 and strides[3] > 0:
+        return "t2d"                             # plain 2-D transpose: the kernel's 64 x 64 shift-indexed form
     order = sorted(range(4), key=lambda k: (abs(strides[k]) if dims[k] > 1 else 0, k))   # size-1 dimensions first (free)
     e = [1, 1, 1, 1]
     e[3] = min(dims[3], 64)
@@ -399,6 +401,10 @@ def permute4_batched(recipes):
             for k in range(4):
                 e.e[k], e.ord[k] = 0, k
             blk += (dims[0] * dims[1] * dims[2] * dims[3] + 8191) // 8192
+        elif tile == "t2d":
+            for k in range(4):
+                e.e[k], e.ord[k] = (-1 if k == 3 else 0), k
+            blk += ((dims[2] + 63) // 64) * ((dims[3] + 63) // 64)
         else:
             ext, order = tile
             nb = 1

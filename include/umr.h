@@ -112,6 +112,14 @@ typedef struct umr_gemm_desc {
  * optionally UMR_EPI_MASK_RELU with aux = an F32 [M][N] tensor (ldaux): v *= (aux > 0), the ReLU-masked data gradient;
  * no other aux / remap / C2.  Anything else returns UMR_ERR_UNSUPPORTED. */
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
+/* Same, with a scratch buffer that lets small problems use split-K: plain GEMMs with few 128x128 tiles and a long K (the
+ * transformer's projections at a few thousand tokens -- the reference's own recipe trains on 128x128 images, batch 20 = 1300
+ * tokens, train_objectness_net.py:96-110) run as tiles x splits workgroups; partial accumulators go to the workspace and the
+ * workgroup that arrives last at a tile adds them in split order (bitwise reproducible) and runs the epilogue.  workspace:
+ * umr_gemm_nt_workspace() bytes of device memory, 16-byte aligned, whose first 16 KiB are ZERO on first use (tile counters; every
+ * launch leaves them zero) and which no other stream uses concurrently.  workspace == NULL is umr_gemm_nt. */
+int64_t umr_gemm_nt_workspace(void);
+int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
 int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);

@@ -627,3 +627,54 @@ def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
                 tol = 1e-5 if a.dtype == torch.float32 else 2.0 ** -6
                 assert ((a.float() - b.float()).abs() <= tol * (b.float().abs() + 1)).all(), (case, kind, M, N, K, bm)
         monkeypatch.delenv("UMR_NT256_BM", raising=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,force", [(1300, 1024, 4096, None), (1300, 1024, 1024, None), (300, 200, 1096, "3"), (129, 136, 520, "8"),
+                                         (700, 3072, 1024, "2")])
+def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
+    """Split-K of the 128x128 kernel (umr_gemm_nt_ws: few tiles, long K -- the reference recipe's 1300-token projections): against
+    fp64, against the unsplit launch, twice in a row (counters are left zero; the fixed-order slab sum is bitwise reproducible),
+    through every epilogue class (bias, residual, ReLU mask, GELU + saved pre-activation), with ragged M / N and a K tail."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    A = _rnd((M, K), dtype, dev, 1)
+    B = _rnd((N, K), dtype, dev, 2, K ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 3)
+    aux = _rnd((M, N), dtype, dev, 4)
+    ref = A.double() @ B.double().t() + bias.double()
+
+    def run():
+        o1 = ops.gemm_nt(A, B, bias)
+        o2, pre = ops.gemm_nt(A, B, bias, act=L.ACT_GELU, c2_mode=2) if dtype == torch.bfloat16 else (None, None)
+        o3 = ops.gemm_nt(A, B, bias, aux=aux)
+        o4 = ops.gemm_nt(A, B, None, aux=aux, mask_relu=True)
+        return [t for t in (o1, o2, pre, o3, o4) if t is not None]
+
+    if force:
+        monkeypatch.setenv("UMR_NT_SPLITK", force)
+    else:
+        monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+    for mode in (("x3", "exact") if dtype == torch.float32 else (None,)):
+        if mode:
+            ops.set_f32_mode(mode)
+        first = run()
+        second = run()
+        for a, b in zip(first, second):
+            assert torch.equal(a, b)
+        monkeypatch.setenv("UMR_NT_SPLITK", "0")
+        unsplit = run()
+        if force:
+            monkeypatch.setenv("UMR_NT_SPLITK", force)
+        else:
+            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+        torch.testing.assert_close(first[0].double(), ref, **_tol(dtype))
+        torch.testing.assert_close(first[-2].double(), ref + aux.double(), **_tol(dtype))
+        torch.testing.assert_close(first[-1].double(), (ref - bias.double()) * (aux.double() > 0), **_tol(dtype))
+        if dtype == torch.bfloat16:
+            torch.testing.assert_close(first[2].double(), ref, **_tol(dtype))
+            torch.testing.assert_close(first[1].double(), F.gelu(ref), **_tol(dtype))
+        for a, b in zip(first, unsplit):     # same products, another f32 summation order: a rounding apart at most
+            torch.testing.assert_close(a.float(), b.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)
+        # the split launch really ran split (or the shape is one the heuristic leaves alone): results differ somewhere, or are equal
+    assert ops._sk_cache, "the split-K workspace was never requested"

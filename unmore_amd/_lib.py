@@ -60,6 +60,8 @@ _lib = None
 _f32 = ctypes.c_float
 _SIGS = {
     "umr_gemm_nt": [_vp, _vp],
+    "umr_gemm_nt_ws": [_vp, _vp, _i64, _vp],
+    "umr_gemm_nt_workspace": [],
     "umr_gemm_nt_rowreduce_ok": [_vp],
     "umr_label_synthesis_workspace": [_i32, _i32, _i32],
     "umr_label_synthesis": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],
@@ -133,7 +135,7 @@ def lib():
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
                    "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
-                   "umr_distance_transform_workspace"):
+                   "umr_distance_transform_workspace", "umr_gemm_nt_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

@@ -19,6 +19,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128;
+constexpr int UMR_SPLITK_COUNTERS = 4096;   // int32 tile counters at the head of the split-K workspace (16 KiB), slabs behind
 constexpr int ROWB = 128;
 constexpr int TILE_BYTES = BM * ROWB;       // 16 KiB
 constexpr int STAGE_BYTES = 2 * TILE_BYTES; // A + B
@@ -63,8 +64,11 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf
 // accumulated in f32 as before.  Every product is within ~2.4e-7 of the f32 product (f32's own rounding is 6e-8) -- fp32-grade
 // results (measured: every fp32 parity test unchanged), not the bit-exact f32 FMA chain of the plain path; +35 % on the fp32 head conv
 // (48.3 -> 35.8 ms at 50 crops: the splitting VALU work, not the matrix pipe, bounds it).  Default; UMR_F32_X3=0 restores the f32 MFMA.
+// (A four-deep K-tile ring for grids of at most one workgroup per CU was built and measured: no change -- 43.0 vs 43.5 us at
+// 1300 x 1024 x 4096 -- a lone workgroup is bound by its own ds_read -> MFMA serialisation inside a K-tile, not by the load
+// round trip; what helps small grids is more co-resident workgroups: split-K below.)
 template <typename T, int CONV, int EPI, bool X3 = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n, int splits, float* __restrict__ skws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int EPC = Tr<T>::EPC, BK = Tr<T>::BK;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,7 +82,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
     }
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    // split-K (plain GEMMs with few tiles and a long K: umr_gemm_nt_ws): the `splits` workgroups of a tile are neighbours in
+    // the remapped order (same XCD, except where a tile straddles two XCD runs), each takes a contiguous range of K-tiles
+    int sk = 0, tile_id = bid;
+    if (CONV == 0 && splits > 1) { tile_id = bid / splits; sk = bid - tile_id * splits; }
+    const int tm = tile_id / tiles_n, tn = tile_id - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging by buffer LDS-DMA (buffer_load_dwordx4 ... lds): address = descriptor base (tile-local,
@@ -257,17 +265,70 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         }
     };
 
-    stage(0, 0);
-    for (int t = 0; t < nt; t += 2) {
+    int t_beg = 0, t_end = nt;
+    if (CONV == 0 && splits > 1) {
+        const int per = (nt + splits - 1) / splits;     // the launcher chose splits so that no range is empty
+        t_beg = sk * per;
+        t_end = t_beg + per < nt ? t_beg + per : nt;
+    }
+    stage(t_beg, 0);
+    for (int t = t_beg; t < t_end; t += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 1 < nt) stage(t + 1, 1);
+        if (t + 1 < t_end) stage(t + 1, 1);
         compute(smem);
-        if (t + 1 >= nt) break;
+        if (t + 1 >= t_end) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (t + 2 < nt) stage(t + 2, 0);
+        if (t + 2 < t_end) stage(t + 2, 0);
         compute(smem + STAGE_BYTES);
+    }
+
+    if (CONV == 0 && splits > 1) {
+        // Every workgroup leaves its partial accumulators in its slab (register-major: 16 x [256 threads] x 16 B, coalesced);
+        // the one that arrives last at the tile's counter adds the slabs IN SPLIT ORDER (so the result does not depend on
+        // arrival order: bitwise reproducible), resets the counter for the next launch and runs the epilogue.
+        // Slab traffic uses agent-scope relaxed atomic 8-byte stores / loads (sc1: written through to / read from the memory
+        // side, whichever XCD's L2 the workgroups sit behind) and the hand-over is "my stores have been acknowledged"
+        // (s_waitcnt vmcnt(0)) + the agent-scope counter atomic.  An agent-scope FENCE would be correct too, but on this
+        // chip it writes back and invalidates the XCD's whole L2 -- twice per workgroup: measured 27.5 -> 31.7 ms on the
+        // reference recipe's step, slower than not splitting at all.
+        int* counters = (int*)skws;
+        unsigned long long* slabs = (unsigned long long*)(skws + UMR_SPLITK_COUNTERS);
+        constexpr int64_t SLAB = (int64_t)BM * BN / 2;      // in 8-byte units
+        unsigned long long* mine = slabs + ((int64_t)tile_id * splits + sk) * SLAB + tid * 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 v = acc[r >> 2][r & 3];
+            __hip_atomic_store(mine + r * 512, __builtin_bit_cast(unsigned long long, f32x2{v[0], v[1]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(mine + r * 512 + 1, __builtin_bit_cast(unsigned long long, f32x2{v[2], v[3]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // every thread's slab stores are acknowledged; the K loop's LDS reads are done
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == splits - 1;
+            if (last) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(int*)smem = last;
+        }
+        __syncthreads();
+        if (*(const int*)smem == 0) return;
+        const unsigned long long* base = slabs + (int64_t)tile_id * splits * SLAB + tid * 2;
+        auto ld4 = [&](const unsigned long long* q) {
+            const f32x2 lo = __builtin_bit_cast(f32x2, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const f32x2 hi = __builtin_bit_cast(f32x2, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            return f32x4{lo[0], lo[1], hi[0], hi[1]};
+        };
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r >> 2][r & 3] = ld4(base + r * 512);
+        for (int q = 1; q < splits; ++q) {      // 32 loads in flight per split, added in split order
+            const unsigned long long* bq = base + (int64_t)q * SLAB;
+            f32x4 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = ld4(bq + r * 512);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r >> 2][r & 3] += v[r];
+        }
     }
 
     // ---- epilogue.  Accumulators (lane: row (lane&15), 4 consecutive columns) are staged through LDS in two
@@ -426,7 +487,55 @@ extern "C" int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d) {
     return (uses_256(d) && umr_nt256_rowreduce_path(d)) ? 1 : 0;
 }
 
-extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
+static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
+
+extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) { return gemm_nt_impl(d, nullptr, 0, stream); }
+
+extern "C" int64_t umr_gemm_nt_workspace(void) { return (int64_t)UMR_SPLITK_COUNTERS * 4 + (int64_t)512 * BM * BN * 4; }   // 16 KiB + 32 MiB
+
+extern "C" int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream) {
+    UMR_CHECK_ARG(workspace == nullptr || (workspace_bytes >= umr_gemm_nt_workspace() && ((uintptr_t)workspace & 15) == 0),
+                  "gemm_nt_ws: workspace smaller than umr_gemm_nt_workspace() or not 16-byte aligned");
+    return gemm_nt_impl(d, workspace, workspace_bytes, stream);
+}
+
+// Split-K for the 128x128 kernel: plain GEMMs whose tiles fill less than ~a third of the chip's 2 x CUs workgroup slots and
+// whose K loop is long (the transformer's projections at a few thousand tokens: 88 tiles x 64 K-tiles on 256 CUs).  Every
+// range gets >= 6 K-tiles; all tiles x splits workgroups are co-resident.  UMR_NT_SPLITK=0 disables, =n forces n (tests).
+static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
+    if (!have_ws || d->conv != 0 || tiles > UMR_SPLITK_COUNTERS) return 1;
+    const int bk = d->dtype == UMR_BF16 ? 64 : 32;
+    const int nt = (d->K + bk - 1) / bk;
+    int want;
+    const char* e = getenv("UMR_NT_SPLITK");
+    if (e) {
+        want = atoi(e);
+    } else {
+        // measured (tools/probe/small_gemm.py, 1300 tokens): bf16 pays ~10 us for the slab round trip -- two ranges from
+        // K = 2048 on (43 -> 33 us at K = 4096), never more; the f32 forms do 6-8x the matrix work per K-tile -- up to five
+        // ranges of >= 16 K-tiles (235 -> 92 us at K = 4096)
+        if (tiles > 170) return 1;
+        if (d->dtype == UMR_BF16) {
+            want = nt >= 32 ? 2 : 1;
+        } else {
+            want = (int)(448 / tiles);
+            if (want > nt / 16) want = nt / 16;
+            if (want > 8) want = 8;
+        }
+    }
+    if (want > nt) want = nt;
+    if (want < 2 || tiles * want > 512) return 1;
+    const int per = (nt + want - 1) / want;
+    return (nt + per - 1) / per;      // no empty range
+}
+
+template <typename T, int CV, int EPI, bool X3>
+static void launch_nt(dim3 g, hipStream_t s, const umr_gemm_desc* d, int tiles_n, int splits, float* skws) {
+    hipLaunchKernelGGL((gemm_nt_kernel<T, CV, EPI, X3>), g, dim3(256), LDS_BYTES, s, *d, tiles_n, splits, skws);
+}
+
+static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream) {
+    (void)workspace_bytes;
     UMR_CHECK_ARG(d != nullptr, "gemm_nt: null descriptor");
     UMR_CHECK_ARG(d->A && d->B && (d->C || d->no_store), "gemm_nt: null operand");
     UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem");
@@ -478,22 +587,24 @@ extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) {
     }
     if (umr_nt128w_eligible(d)) return umr_launch_gemm_nt128w(d, s);
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
-    dim3 g((unsigned)grid), b(256);
+    const int splits = pick_splits(d, grid, workspace != nullptr);
+    float* skws = (float*)workspace;
+    dim3 g((unsigned)(grid * splits)), b(256);
     const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&
                          (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) || (d->ldaux & 7) == 0) &&
                          (!(d->flags & UMR_EPI_ADD_AUX2) || (d->ldaux2 & 7) == 0) && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
                          !(d->flags & (UMR_EPI_ROWBIAS | UMR_EPI_OUT_F32)) &&
                          (!(d->flags & UMR_EPI_MASK_DGELU) || d->dtype == UMR_BF16) &&   // GELU forms: 16-bit mode only (cheap erf)
                          (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU || (d->act == UMR_ACT_GELU && d->dtype == UMR_BF16));
-#define LAUNCH(T, CV)                                                                                   \
-    do {                                                                                                \
-        if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 0>), g, b, LDS_BYTES, s, *d, tiles_n);   \
-        else hipLaunchKernelGGL((gemm_nt_kernel<T, CV, 1>), g, b, LDS_BYTES, s, *d, tiles_n);           \
+#define LAUNCH(T, CV)                                                                   \
+    do {                                                                                \
+        if (fast_ep) launch_nt<T, CV, 0, false>(g, s, d, tiles_n, splits, skws);  \
+        else launch_nt<T, CV, 1, false>(g, s, d, tiles_n, splits, skws);          \
     } while (0)
-#define LAUNCH_X3(CV)                                                                                          \
-    do {                                                                                                       \
-        if (fast_ep) hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 0, true>), g, b, LDS_BYTES, s, *d, tiles_n); \
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, CV, 1, true>), g, b, LDS_BYTES, s, *d, tiles_n);         \
+#define LAUNCH_X3(CV)                                                                      \
+    do {                                                                                   \
+        if (fast_ep) launch_nt<float, CV, 0, true>(g, s, d, tiles_n, splits, skws);  \
+        else launch_nt<float, CV, 1, true>(g, s, d, tiles_n, splits, skws);          \
     } while (0)
     const int f32_x3 = umr_f32_mode_now() != UMR_F32_EXACT;   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
     if (d->dtype == UMR_BF16) {

@@ -4,6 +4,7 @@ PyTorch here is plumbing only: it owns device memory and the current HIP stream;
 every computation below is a hand-written gfx950 kernel in unmore_amd/csrc.
 All wrappers raise if the tensor is not on a GPU or the library is missing --
 there is no CPU / eager fallback."""
+import collections
 import ctypes
 
 import torch
@@ -64,6 +65,22 @@ def _workspace(nbytes, device):
     _ws_cache[key] = buf   # re-inserted last = most recently used
     while len(_ws_cache) > _WS_MAX_ENTRIES:
         _ws_cache.pop(next(iter(_ws_cache)))
+    return buf
+
+
+_sk_cache = collections.OrderedDict()
+
+
+def _splitk_workspace(device):
+    """Per-(device, stream) scratch of umr_gemm_nt_ws: tile counters (zeroed once here; every launch leaves them zero) + slabs."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _sk_cache.pop(key, None)
+    if buf is None:
+        buf = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
+        buf[:16384].zero_()
+    _sk_cache[key] = buf
+    while len(_sk_cache) > _WS_MAX_ENTRIES:
+        _sk_cache.pop(next(iter(_sk_cache)))
     return buf
 
 
@@ -546,16 +563,24 @@ def kernel_timer_results_ms():
 _raw_gemm_nt_call = None
 
 
+def _gemm_nt_call(d):
+    # few 128x128 tiles and a long K: hand the library its split-K scratch (include/umr.h: umr_gemm_nt_ws); the library decides
+    if d.conv == 0 and d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32):
+        ws = _splitk_workspace(torch.device("cuda", torch.cuda.current_device()))
+        return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
+    return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
+
+
 def _timed_call(d):
     sel = _timer["select"]
     if sel is not None and sel(d):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        st = L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
+        st = _gemm_nt_call(d)
         b.record()
         _timer["events"].append((a, b))
         return st
-    return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
+    return _gemm_nt_call(d)
 
 
 # ---------------------------------------------------------------- collapsed linear head (opt-in)

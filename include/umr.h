@@ -114,7 +114,7 @@ typedef struct umr_gemm_desc {
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
 /* Same, with a scratch buffer that lets small problems use split-K: plain GEMMs with few 128x128 tiles and a long K (the
  * transformer's projections at a few thousand tokens -- the reference's own recipe trains on 128x128 images, batch 20 = 1300
- * tokens, train_objectness_net.py:96-110) run as tiles x splits workgroups; partial accumulators go to the workspace and the
+ * tokens, README.md:148-155, train_objectness_net.py:783-788,815-817) run as tiles x splits workgroups; partial accumulators go to the workspace and the
  * workgroup that arrives last at a tile adds them in split order (bitwise reproducible) and runs the epilogue.  workspace:
  * umr_gemm_nt_workspace() bytes of device memory, 16-byte aligned, whose first 16 KiB are ZERO on first use (tile counters; every
  * launch leaves them zero) and which no other stream uses concurrently.  workspace == NULL is umr_gemm_nt. */

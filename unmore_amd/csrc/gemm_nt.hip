@@ -65,8 +65,8 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf
 // results (measured: every fp32 parity test unchanged), not the bit-exact f32 FMA chain of the plain path; +35 % on the fp32 head conv
 // (48.3 -> 35.8 ms at 50 crops: the splitting VALU work, not the matrix pipe, bounds it).  Default; UMR_F32_X3=0 restores the f32 MFMA.
 // (A four-deep K-tile ring for grids of at most one workgroup per CU was built and measured: no change -- 43.0 vs 43.5 us at
-// 1300 x 1024 x 4096 -- a lone workgroup is bound by its own ds_read -> MFMA serialisation inside a K-tile, not by the load
-// round trip; what helps small grids is more co-resident workgroups: split-K below.)
+// 1300 x 1024 x 4096.  A lone workgroup takes 0.68 us per K-tile: not the load round trip but the CU's L2 -> LDS fill rate,
+// 32 KiB per K-tile at ~29 B/clk = 0.46 us; what helps small grids is the K range on more CUs: split-K below.)
 template <typename T, int CONV, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n, int splits, float* __restrict__ skws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

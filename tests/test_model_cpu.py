@@ -71,3 +71,18 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/umr.h but not exported"
     assert declared == set(_lib.exported_symbols())
     assert lib.umr_version() >= 100
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """Argument checks run before any HIP call: a null descriptor and an undersized split-K workspace come back as
+    UMR_ERR_INVALID with a message (no compute is attempted on this box)."""
+    from unmore_amd import _lib
+    lib = _lib.lib()
+    assert lib.umr_gemm_nt(None, None) != 0
+    assert b"null descriptor" in lib.umr_last_error_string()
+    need = lib.umr_gemm_nt_workspace()
+    assert need >= 16384 + 32 * 1024 * 1024
+    d = _lib.GemmDesc()
+    buf = ctypes.create_string_buffer(64)
+    assert lib.umr_gemm_nt_ws(ctypes.byref(d), ctypes.cast(buf, ctypes.c_void_p), 64, None) != 0
+    assert b"workspace" in lib.umr_last_error_string()

@@ -2,6 +2,7 @@
 // biased variance; vit.py:196-199 via timm Block).  HBM-bound: one wave per row,
 // 16-byte vector loads, statistics in f32, two-pass variance in registers.
 #include "umr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -195,7 +196,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 // bf16 fast path of the backward (see ln_fwd_bf16x8_kernel): 16-byte loads, two rows per wave and iteration
-template <int NCH>
+#ifndef LN_BWD_ROWS
+#define LN_BWD_ROWS 1   // rows per wave and iteration: 1 measured 6 % faster than 2 at 36928 x 768 (fewer registers), 4 is 60 % slower
+#endif
+template <int NCH, int R = LN_BWD_ROWS>
 __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
@@ -216,11 +220,13 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __rest
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    for (int row = r0 + 2 * wv; row < r1; row += 8) {
-        f32x4 xh[2][NCH][2], dg[2][NCH][2];
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rsv[2];
+    for (int row = r0 + R * wv; row < r1; row += 4 * R) {
+        f32x4 xh[R][NCH][2], dg[R][NCH][2];
+        float s1[R], s2[R], rsv[R];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) s1[r] = s2[r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             const bool rok = row + r < r1;
             const float mu = rok ? mean[row + r] : 0.f;
             rsv[r] = rok ? rstd[row + r] : 0.f;
@@ -248,10 +254,10 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __rest
                     }
             }
         }
-        s1[0] = wave_sum(s1[0]) / D; s1[1] = wave_sum(s1[1]) / D;
-        s2[0] = wave_sum(s2[0]) / D; s2[1] = wave_sum(s2[1]) / D;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < R; ++r) { s1[r] = wave_sum(s1[r]) / D; s2[r] = wave_sum(s2[r]) / D; }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
             if (row + r >= r1) continue;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
@@ -292,31 +298,35 @@ __global__ __launch_bounds__(256) void ln_bwd_bf16x8_kernel(const bf16_t* __rest
     }
 }
 
-// fixed-order sum of the per-block partials: 64 columns x 4 interleaved block slices per workgroup, four independent
-// accumulators per thread, slices combined in index order (bitwise reproducible)
-__global__ __launch_bounds__(256) void ln_bwd_reduce(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int nblocks, int D, int accumulate) {
-    __shared__ float sh[4][64];
+// fixed-order sum of the per-block partials (bitwise reproducible)
+__global__ __launch_bounds__(1024) void ln_bwd_reduce(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      int nblocks, int D, int accumulate) {
+    // 64 columns x 16 slab phases per workgroup, 8 loads in flight per thread; phases added in index order (reproducible).
+    // (4 phases x 4 chains walked 512 slabs in 32 dependent steps: 13 us for 3 MB)
+    __shared__ float sh[16][64];
     const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float acc = 0.f;
     if (c < 2 * D) {
         const int which = c / D, col = c - which * D;
         const float* q = part + (int64_t)which * D + col;
         const int64_t st = (int64_t)2 * D;
         int b = sl;
-        for (; b + 12 < nblocks; b += 16) {
-            s0 += q[(int64_t)b * st];
-            s1 += q[(int64_t)(b + 4) * st];
-            s2 += q[(int64_t)(b + 8) * st];
-            s3 += q[(int64_t)(b + 12) * st];
+        for (; b + 16 * 7 < nblocks; b += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q[(int64_t)(b + 16 * u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
         }
-        for (; b < nblocks; b += 4) s0 += q[(int64_t)b * st];
+        for (; b < nblocks; b += 16) acc += q[(int64_t)b * st];
     }
-    sh[sl][cl] = (s0 + s1) + (s2 + s3);
+    sh[sl][cl] = acc;
     __syncthreads();
     if (sl == 0 && c < 2 * D) {
-        const float s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        float s = sh[0][cl];
+#pragma unroll
+        for (int y = 1; y < 16; ++y) s += sh[y][cl];
         const int which = c / D, col = c - which * D;
         float* o = which == 0 ? dgamma : dbeta;
         o[col] = accumulate ? o[col] + s : s;
@@ -372,7 +382,9 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
                       ? prop.multiProcessorCount : 256;
         }
-        if (nb > 2 * cus) nb = 2 * cus;
+        static int wg_per_cu = 0;       // UMR_LN_BWD_WG_PER_CU: experiment hook (register use decides how many are co-resident)
+        if (wg_per_cu == 0) { const char* e = getenv("UMR_LN_BWD_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 2; if (wg_per_cu < 1) wg_per_cu = 2; }
+        if (nb > wg_per_cu * cus) nb = wg_per_cu * cus;
     }
     const int rpb = (M + nb - 1) / nb;
     nb = (M + rpb - 1) / rpb;
@@ -392,7 +404,7 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
                            (const float*)dres, (float*)dx, (float*)workspace, M, D, rpb);
     else return umr_set_error(UMR_ERR_INVALID, "layernorm_bwd: dtype");
     UMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 63) / 64), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, nb, D, accumulate);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 63) / 64), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, D, accumulate);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

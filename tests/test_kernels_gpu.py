@@ -116,7 +116,8 @@ def test_patchify(dtype, p, H, W):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Hi,Wi,Ho,Wo,align", [(6, 4, 12, 8, True), (12, 12, 24, 24, True), (24, 24, 8, 8, False),
-                                               (24, 24, 37, 30, False), (19, 19, 37, 37, True), (1, 1, 2, 2, True)])
+                                               (24, 24, 37, 30, False), (19, 19, 37, 37, True), (1, 1, 2, 2, True),
+                                               (48, 40, 96, 80, True), (25, 13, 49, 26, True), (48, 40, 96, 80, False)])
 def test_bilinear(dtype, Hi, Wi, Ho, Wo, align):
     from unmore_amd import ops
     dev = _dev()

@@ -12,8 +12,12 @@ from kbench import timeit
 dev = torch.device("cuda:0")
 x = torch.randn(64, 192, 192, 256, device=dev).bfloat16()
 dy = torch.randn(64, 384, 384, 256, device=dev).bfloat16()
-for cap in ("0", "8192", "4096", "2048", "1024", "512", "0"):
-    os.environ["UMR_BILINEAR_GY"] = cap
+for cap in (None, "0", "8192", "4096", "2048", "1024", "512", None):      # None = the library's defaults
+    if cap is None:
+        os.environ.pop("UMR_BILINEAR_GY", None)
+    else:
+        os.environ["UMR_BILINEAR_GY"] = cap
+    cap = cap or "dflt"
     tf = timeit(lambda: ops.bilinear_fwd(x, 384, 384, True), n=9, warm=2)
     tb = timeit(lambda: ops.bilinear_bwd(dy, 192, 192, True), n=9, warm=2)
     print(f"gy cap {cap:>5s}: fwd {tf:6.3f} ms ({6.04 / tf:5.2f} TB/s)   bwd {tb:6.3f} ms ({6.04 / tb:5.2f} TB/s)", flush=True)

@@ -185,6 +185,11 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
 // s >= 0.4; the host picks this kernel only then).  Their weights are computed ONCE per thread and axis (the generic kernel
 // re-derives the x weights for every candidate row and scans 7 x 7 candidates at s = 0.5: index arithmetic, not memory, bound it
 // at 2.9 TB/s).
+// NCX = x candidates per output row (6 covers scales >= 0.49: <= 5 contributors + the one-early window start; 8 down to 0.4).
+// The candidate rows are skipped by a block-uniform branch (iy is the block's); inside a row ALL NCX taps are loaded
+// unconditionally (zero weight / clamped address where a tap does not contribute) so that the NCX loads go out back to back --
+// a per-tap `continue` left one load in flight per thread (3.3 TB/s on the final x2 resize).
+template <int NCX>
 __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int Hi, int Wi, int Ho,
                                                                 int Wo, int C, int align) {
     constexpr int NC = 8;
@@ -202,39 +207,42 @@ __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* 
             wv[k] = (o < out) ? ((i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f)) : 0.f;
         }
     };
-    for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
-        const int b = by / Hi, iy = by - b * Hi;
-        int ylo;
-        float wy[NC];
-        weights(iy, sh, Hi, Ho, ylo, wy);
-        const bf16_t* base = dy + (int64_t)b * Ho * Wo * C;
-        bf16_t* xr = dx + (int64_t)by * Wi * C;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
-            const int ix = i / cv, c = (i - ix * cv) * 8;
-            int xlo;
-            float wx[NC];
-            weights(ix, sw, Wi, Wo, xlo, wx);
+    // a thread's column (ix, 8 channels) is the same for every row it visits: the x weights are computed once per thread
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+        const int ix = i / cv, c = (i - ix * cv) * 8;
+        int xlo;
+        float wx[NC];
+        weights(ix, sw, Wi, Wo, xlo, wx);
+        int xoff[NCX];       // element offsets of the NCX candidate columns, clamped inside the row
+#pragma unroll
+        for (int kx = 0; kx < NCX; ++kx) xoff[kx] = ((xlo + kx < Wo ? xlo + kx : Wo - 1) - xlo) * C;
+        for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
+            const int b = by / Hi, iy = by - b * Hi;
+            int ylo;
+            float wy[NC];
+            weights(iy, sh, Hi, Ho, ylo, wy);
+            const bf16_t* base = dy + (int64_t)b * Ho * Wo * C + (int64_t)xlo * C + c;
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int ky = 0; ky < NC; ++ky) {
-                if (wy[ky] == 0.f) continue;
-                const bf16_t* rowp = base + ((int64_t)(ylo + ky) * Wo + xlo) * C + c;
+                if (wy[ky] == 0.f) continue;          // block-uniform
+                const bf16_t* rowp = base + (int64_t)(ylo + ky) * Wo * C;
+                bf16x8 t[NCX];
 #pragma unroll
-                for (int kx = 0; kx < NC; ++kx) {
-                    if (wx[kx] == 0.f) continue;
-                    float g[8];
-                    ld_bf16x8(rowp + (int64_t)kx * C, g);
+                for (int kx = 0; kx < NCX; ++kx) t[kx] = *(const bf16x8*)(rowp + xoff[kx]);
+#pragma unroll
+                for (int kx = 0; kx < NCX; ++kx) {
                     const float wgt = wy[ky] * wx[kx];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += g[j] * wgt;
+                    for (int j = 0; j < 8; ++j) acc[j] += (float)t[kx][j] * wgt;
                 }
             }
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
-            *(bf16x8*)(xr + (int64_t)ix * C + c) = o;
+            *(bf16x8*)(dx + ((int64_t)by * Wi + ix) * C + c) = o;
         }
     }
 }
@@ -894,11 +902,18 @@ extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi,
         const int rowlen = Wi * (C / (4 * nv));
         int64_t gy = (int64_t)B * Hi;
         if (gy > bilinear_gy_cap()) gy = bilinear_gy_cap();
-        const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
+        dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
         const float sh_ = align_corners ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) : (float)Hi / (float)Ho;
         const float sw_ = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) : (float)Wi / (float)Wo;
         if (nv == 2 && dtype == UMR_BF16 && sh_ >= 0.4f && sw_ >= 0.4f)    // <= 8 candidate outputs per axis (see the kernel)
-            hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
+        {
+            // the x weights are per thread, not per row: a block should visit several rows (1.80 ms with one row per block,
+            // 1.57-1.59 with 3-12 on the final x2 resize at cfg2, tools/bilinear_bench.py)
+            if (getenv("UMR_BILINEAR_GY") == nullptr && g.y > 2048) g.y = 2048;
+            // align_corners: contributors of input column i are the outputs o with o * sw in (i - 1, i + 1): at most lo + 5 for sw >= 0.49
+            if (align_corners && sw_ >= 0.49f) hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<6>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
+            else hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<8>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
+        }
         else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
         else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
     }

@@ -894,8 +894,7 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
     hipStream_t s = (hipStream_t)stream;
     dim3 g((N + 63) / 64, B * heads), b(256);
-    static int fast_fwd = -1;   // UMR_ATTN_FAST=0: the generic kernel for bf16 too (A/B)
-    if (fast_fwd < 0) { const char* e = getenv("UMR_ATTN_FAST"); fast_fwd = e ? atoi(e) : 1; }
+    static const int fast_fwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernel for bf16 too (A/B)
     if (dtype == UMR_BF16 && fast_fwd) {
         if (N >= 128 && fast_fwd != 2) {   // 32 queries per wave: half the LDS reads per MFMA
             dim3 g2((N + 127) / 128, B * heads);
@@ -924,8 +923,7 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * N * heads;
     dim3 gp((unsigned)((total + 255) / 256)), g((N + 63) / 64, B * heads), b(256);
-    static int fast_bwd = -1;   // UMR_ATTN_FAST=0: the generic kernels for bf16 too (A/B)
-    if (fast_bwd < 0) { const char* e = getenv("UMR_ATTN_FAST"); fast_bwd = e ? atoi(e) : 1; }
+    static const int fast_bwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernels for bf16 too (A/B)
     if (dtype == UMR_BF16 && fast_bwd) {
         const int Npad = (N + 63) / 64 * 64;
         const int64_t tp = (int64_t)B * heads * Npad * 8;

@@ -474,8 +474,8 @@ static bool uses_256(const umr_gemm_desc* d) {
     const bool kfit = d->conv == 0 ? (d->K % 64 == 0) : (d->Cin % 64 == 0);  // the 256 kernel has no K-tail path
     // >= 8 full rounds of one 256x256 tile per CU (no tail, overheads amortised); plain GEMMs already win from 1.5 rounds on
     // when K >= 512 or there are >= 4 rounds (the transformer's GEMMs at 37 k tokens: tools/vit_block_bench.py)
-    static int min_tiles = -1;   // UMR_NT256_MIN_TILES: smallest plain-GEMM problem (in 256x256 tiles) given to the 256x256 kernel
-    if (min_tiles < 0) { const char* e = getenv("UMR_NT256_MIN_TILES"); min_tiles = e ? atoi(e) : 300; }   // 384 -> 300: +2 % on the ViT-L/14 step (proj / fc2 at 344 tiles), neutral at cfg2
+    // UMR_NT256_MIN_TILES: smallest plain-GEMM problem (in 256x256 tiles) given to the 256x256 kernel
+    static const int min_tiles = umr_env_int("UMR_NT256_MIN_TILES", 300);   // 384 -> 300: +2 % on the ViT-L/14 step (proj / fc2 at 344 tiles), neutral at cfg2
     const bool big = kfit && d->N >= 192 &&
                      (t256 >= 2048 || (d->conv == 0 && d->a_rows_in <= 0 && t256 >= min_tiles && (d->K >= 512 || t256 >= 1024)));
     return kfit && (ov == 256 || (ov == 0 && big));

@@ -335,8 +335,7 @@ bool umr_nt256_rowreduce_path(const umr_gemm_desc* d) {
 // launched from umr_gemm_nt (gemm_nt.hip) for bf16 problems large enough to fill the chip with 256x256 tiles
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
     {   // the persistent kernel covers plain GEMMs without A-row remap and stride-1 convs; UMR_NT256_PERSIST=0 disables it
-        static int persist = -1;
-        if (persist < 0) { const char* e = getenv("UMR_NT256_PERSIST"); persist = e ? atoi(e) : 1; }
+        static const int persist = umr_env_int("UMR_NT256_PERSIST", 1);
         if (persist && ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1)) return umr_launch_gemm_nt256p(d, s);
     }
     if (d->red_w || d->no_store) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store is only implemented by the persistent 256x256 path");

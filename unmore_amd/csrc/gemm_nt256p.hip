@@ -905,15 +905,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 }
 
 int num_cus() {
-    static int n = 0;
-    if (n == 0) {
+    static const int n = [] {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n = prop.multiProcessorCount;
-        else
-            n = 256;
-    }
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                   ? prop.multiProcessorCount : 256;
+    }();
     return n;
 }
 
@@ -948,10 +945,9 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     // rows per tile (see the kernel): for plain GEMMs of a few rounds, the bm in {256, 224, 192} with the smallest
     // rounds x tile time (tile time ~ a fixed quarter -- epilogue, first-load latency -- plus the K loop, which scales with bm);
     // the waves that skip blocks are the non-ahead half, so the stagger has to be on.  UMR_NT256_BM forces a value.
-    static int stagger = -1;
+    static const int stagger = umr_env_int("UMR_NT256_STAGGER", 1);   // A/B switch (0 = all waves in lock-step)
     const char* bm_e = getenv("UMR_NT256_BM");   // read per launch: tests switch it inside one process
     const int bm_env = bm_e ? atoi(bm_e) : 0;
-    if (stagger < 0) { const char* e = getenv("UMR_NT256_STAGGER"); stagger = e ? atoi(e) : 1; }   // A/B switch (0 = all waves in lock-step)
     int bm = BM2;
     if (d->conv == 0 && d->dtype == UMR_BF16) {
         if (bm_env == 256 || bm_env == 224 || bm_env == 192) bm = bm_env;
@@ -972,8 +968,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     // others -- up to 2x the kernel time.  With several shorter workgroups per CU the dispatcher balances them itself; a
     // workgroup still walks >= 32 tiles, so the cross-tile prefetch keeps its value, and workgroups that run together on
     // one XCD still own neighbouring tiles (pw in the kernel).  UMR_NT256_WG_PER_CU overrides the factor.
-    static int wg_per_cu = -1;
-    if (wg_per_cu < 0) { const char* e = getenv("UMR_NT256_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 0; }
+    static const int wg_per_cu = umr_env_int("UMR_NT256_WG_PER_CU", 0);
     int64_t kf = wg_per_cu > 0 ? wg_per_cu : total / ((int64_t)cus * 32);
     if (kf < 1) kf = 1;
     if (kf > 8) kf = 8;

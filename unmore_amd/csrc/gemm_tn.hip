@@ -421,11 +421,7 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
 namespace {
 
 static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("UMR_GEMM_TILE");
-        v = e ? atoi(e) : 0;
-    }
+    static const int v = umr_env_int("UMR_GEMM_TILE", 0);
     return v;
 }
 

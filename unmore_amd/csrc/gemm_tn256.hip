@@ -378,8 +378,7 @@ bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force) {
 
 void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split) {
     const int64_t tiles = (int64_t)((d->N + 255) / 256) * ((d->K + 255) / 256);
-    static int rounds_env = -2;
-    if (rounds_env == -2) { const char* e = getenv("UMR_TN256_ROUNDS"); rounds_env = e ? atoi(e) : -1; }
+    static const int rounds_env = umr_env_int("UMR_TN256_ROUNDS", -1);
     // Rounds of one workgroup per CU: every split writes a 256 KiB fp32 partial per tile and the reduction reads it back,
     // so few-row problems (the transformer weight gradients: 37 k tokens) want ONE round of long splits -- 4 rounds cost
     // +50 % there (tools/vit_block_bench.py) -- while the pixel-sized ones (>= 64 stages per split even at 4 rounds) keep
@@ -408,10 +407,8 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
 int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s) {
     const int tiles_n = (d->N + 255) / 256, tiles_k = (d->K + 255) / 256;
     dim3 g((unsigned)(tiles_n * tiles_k * splits)), b(512);
-    static int mapmode = -1;
-    if (mapmode < 0) { const char* e = getenv("UMR_TN_MAP"); mapmode = e ? atoi(e) : 3; }
-    static int ph2 = -1;
-    if (ph2 < 0) { const char* e = getenv("UMR_TN256_PH2"); ph2 = e ? atoi(e) : 1; }  // two-phase stage: +1-2 % (tools/kbench.py)
+    static const int mapmode = umr_env_int("UMR_TN_MAP", 3);
+    static const int ph2 = umr_env_int("UMR_TN256_PH2", 1);   // two-phase stage: +1-2 % (tools/kbench.py)
 #define LT(CV, WFV)                                                                                                    \
     do {                                                                                                               \
         UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, false, WFV>), TLDS); \

@@ -375,15 +375,14 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
     {
         // ONE round of workgroups: the bf16 kernel needs 214 VGPRs (two workgroups per CU), so more than 2 x CUs blocks run as a
         // second, nearly empty round -- 577 blocks at the cfg2 token count took two rounds for 1.13 rounds of work
-        static int cus = 0;
-        if (cus == 0) {
+        static const int cus = [] {
             int dev = 0;
             hipDeviceProp_t prop;
-            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                      ? prop.multiProcessorCount : 256;
-        }
-        static int wg_per_cu = 0;       // UMR_LN_BWD_WG_PER_CU: experiment hook (register use decides how many are co-resident)
-        if (wg_per_cu == 0) { const char* e = getenv("UMR_LN_BWD_WG_PER_CU"); wg_per_cu = e ? atoi(e) : 2; if (wg_per_cu < 1) wg_per_cu = 2; }
+            return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                       ? prop.multiProcessorCount : 256;
+        }();
+        // UMR_LN_BWD_WG_PER_CU: experiment hook (register use decides how many are co-resident); initialised once, thread-safe
+        static const int wg_per_cu = [] { const char* e = getenv("UMR_LN_BWD_WG_PER_CU"); const int v = e ? atoi(e) : 2; return v < 1 ? 2 : v; }();
         if (nb > wg_per_cu * cus) nb = wg_per_cu * cus;
     }
     const int rpb = (M + nb - 1) / nb;

@@ -111,6 +111,10 @@ static __device__ uint4 umr_zero_page[16];
         }                                                                                                           \
     } while (0)
 
+// environment switch read ONCE per process, thread-safely:  static const int v = umr_env_int("NAME", dflt);
+#include <stdlib.h>
+static inline int umr_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
 // host-side error plumbing (umr_api.hip)
 int umr_set_error(int code, const char* msg);
 int umr_f32_mode_now();   // umr_api.hip: UMR_F32_EXACT / UMR_F32_X3

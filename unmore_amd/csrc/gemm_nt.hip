@@ -476,8 +476,11 @@ static bool uses_256(const umr_gemm_desc* d) {
     // when K >= 512 or there are >= 4 rounds (the transformer's GEMMs at 37 k tokens: tools/vit_block_bench.py)
     // UMR_NT256_MIN_TILES: smallest plain-GEMM problem (in 256x256 tiles) given to the 256x256 kernel
     static const int min_tiles = umr_env_int("UMR_NT256_MIN_TILES", 300);   // 384 -> 300: +2 % on the ViT-L/14 step (proj / fc2 at 344 tiles), neutral at cfg2
+    // smallest 3x3-conv problem on the 256x256 kernel: its K loop is 9 x Cin long, so two to three rounds of tiles already beat
+    // the 128x128 kernel (cfg1's head convs, 784 tiles: 542 -> 577 images/s; cfg2 / cfg4 / ref / the sweep unchanged)
+    static const int conv_min_tiles = umr_env_int("UMR_NT256_CONV_MIN_TILES", 512);
     const bool big = kfit && d->N >= 192 &&
-                     (t256 >= 2048 || (d->conv == 0 && d->a_rows_in <= 0 && t256 >= min_tiles && (d->K >= 512 || t256 >= 1024)));
+                     (t256 >= 2048 || (d->conv == 1 && t256 >= conv_min_tiles) || (d->conv == 0 && d->a_rows_in <= 0 && t256 >= min_tiles && (d->K >= 512 || t256 >= 1024)));
     return kfit && (ov == 256 || (ov == 0 && big));
 }
 

@@ -10,7 +10,7 @@ from oracle import mask_parity
 from oracle import objectness_oracle as orc
 
 
-def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, **head_kw):
+def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, grads_out=None, **head_kw):
     """net: unmore_amd ObjectnessNet on the GPU in fp32 mode holding `sd`.  Returns (worst max-norm error / max|g|, its
     parameter, worst relative L2, number of ReLU decisions that differ from float64's own)."""
     from unmore_amd import ops
@@ -44,4 +44,6 @@ def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, **head
             worst_inf, worst_n = e_inf, n
         worst_l2 = max(worst_l2, e_l2)
         assert e_inf <= bar and e_l2 <= bar, (n, e_inf, e_l2)
+    if grads_out is not None:
+        grads_out.update(G)      # the engine-level gradients (callers compare them with what autograd delivered)
     return worst_inf, worst_n, worst_l2, sum(flips.values())

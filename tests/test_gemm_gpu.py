@@ -428,9 +428,10 @@ def test_gemm_nt_x3_planes(M, N, K, relu, f32_mode_restored):
 
 
 @pytest.mark.parametrize("nb,H,W,Cin,N", [(2, 20, 24, 64, 128), (1, 37, 19, 128, 72), (5, 128, 128, 64, 256)])
-def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored):
+def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored, monkeypatch):
     from unmore_amd import ops, _lib as L
     dev = _dev()
+    monkeypatch.setenv("UMR_NT_SPLITK", "0")   # the yardstick is ONE f32 accumulation chain per output (split-K shortens the chains)
     x = _rnd((nb, H, W, Cin), torch.float32, dev, 41)
     w = _rnd((N, 3, 3, Cin), torch.float32, dev, 42, (9 * Cin) ** -0.5)
     bias = _rnd((N,), torch.float32, dev, 43)
@@ -678,3 +679,36 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
             torch.testing.assert_close(a.float(), b.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)
         # the split launch really ran split (or the shape is one the heuristic leaves alone): results differ somewhere, or are equal
     assert ops._sk_cache, "the split-K workspace was never requested"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nb,H,W,Cin,N,stride,force", [(2, 7, 7, 256, 256, 1, None), (2, 14, 9, 128, 200, 1, "5"), (3, 12, 12, 128, 128, 2, "3"),
+                                                        (20, 16, 16, 256, 256, 1, None)])
+def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, monkeypatch, f32_mode_restored):
+    """Split-K of the implicit 3x3 conv on small maps (a K range starts in the middle of the tap sequence): against torch conv2d in
+    fp64, twice (bitwise reproducible), and against the unsplit launch."""
+    from unmore_amd import ops
+    dev = _dev()
+    x = _rnd((nb, H, W, Cin), dtype, dev, 1)
+    w = _rnd((N, Cin, 3, 3), dtype, dev, 2, (9 * Cin) ** -0.5)
+    bias = _rnd((N,), torch.float32, dev, 3)
+    wp = w.permute(0, 2, 3, 1).reshape(N, 9 * Cin).contiguous()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, N)
+    if force:
+        monkeypatch.setenv("UMR_NT_SPLITK", force)
+    else:
+        monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+    for mode in (("x3", "exact") if dtype == torch.float32 else (None,)):
+        if mode:
+            ops.set_f32_mode(mode)
+        a = ops.gemm_nt(x, wp, bias, conv=stride)
+        b = ops.gemm_nt(x, wp, bias, conv=stride)
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a.double().reshape(-1, N), ref, **_tol(dtype))
+        monkeypatch.setenv("UMR_NT_SPLITK", "0")
+        c = ops.gemm_nt(x, wp, bias, conv=stride)
+        if force:
+            monkeypatch.setenv("UMR_NT_SPLITK", force)
+        else:
+            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+        torch.testing.assert_close(a.float(), c.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)

@@ -78,11 +78,16 @@ def _labels(B, H, W, seed):
 
 @pytest.mark.parametrize("H,W", [(64, 64), (96, 64)])
 def test_backward_fp32_matches_oracle_autograd(H, W):
-    """Every parameter gradient of the 4-term loss vs the oracle's autograd.  The oracle is
-    evaluated in float64 (ground truth) and in float32 (what the reference CPU path computes);
-    the HIP fp32 gradients must sit within 5e-4 of max|grad| of the truth and be no worse
-    than 2x the fp32 CPU path's own worst error."""
+    """Every parameter gradient of the 4-term loss, delivered through the autograd.Function boundary (net(images) ->
+    objectness_loss -> loss.backward() -> p.grad).  Three statements:
+      (1) p.grad is bit-identical to what the engine-level forward / loss kernel / backward produce (same kernels, another door);
+      (2) those gradients agree with the float64 oracle to 5e-5 * max|g| on the HIP path's own linear piece (the oracle runs with
+          the HIP path's ReLU decisions imposed, tests/grad_common.py) -- the statement that is about arithmetic;
+      (3) against the oracle's OWN ReLU decisions the whole-gradient relative L2 error stays below 5e-4 (a decision that falls
+          the other way within rounding of zero moves single entries by ~1e-3 * max|g| -- which one does depends on the summation
+          order, e.g. on split-K -- so the max-norm is printed, not asserted; round 2 asserted it and the bar followed the luck)."""
     from unmore_amd.loss import objectness_loss
+    from grad_common import masked_gradient_check
     B = 2
     net, sd = _net("dpt_tiny", "tiny")
     net.train()
@@ -101,20 +106,29 @@ def test_backward_fp32_matches_oracle_autograd(H, W):
     loss.backward()
     assert abs(loss.item() - loss_o.item()) < 1e-4
     nograd = net.nograd_names()
+    autograd_grads = {n: (p.grad.clone() if p.grad is not None else None) for n, p in net.named_parameters()}
+    G = {}
+    worst_inf, worst_n, worst_l2, flips = masked_gradient_check(net, sd, "dpt_tiny", x, gc, gs, sal, grads_out=G)     # (2)
+    num = den = num_c = 0.0
     worst_mine, worst_cpu = 0.0, 0.0
     for n, p in net.named_parameters():
         ref = grads["f64"][n]
         if n in nograd:
-            assert p.grad is None and ref is None, n
+            assert autograd_grads[n] is None and ref is None, n
             continue
-        assert p.grad is not None and p.grad.shape == p.shape, n
+        g = autograd_grads[n]
+        assert g is not None and g.shape == p.shape, n
+        assert torch.equal(g, G[n]), f"{n}: autograd delivered something else than the engine computes"                 # (1)
         scale = ref.abs().max().item() + 1e-12
-        e_m = (p.grad.cpu().double() - ref).abs().max().item() / scale
-        e_c = (grads["f32"][n].double() - ref).abs().max().item() / scale
-        worst_mine, worst_cpu = max(worst_mine, e_m), max(worst_cpu, e_c)
-        assert e_m <= 5e-4, f"{n}: HIP fp32 rel err {e_m} (cpu fp32 {e_c})"
-    print(f"worst relative gradient error: HIP fp32 {worst_mine:.2e}, reference-style CPU fp32 {worst_cpu:.2e}")
-    assert worst_mine <= max(2 * worst_cpu, 2e-4)
+        worst_mine = max(worst_mine, (g.cpu().double() - ref).abs().max().item() / scale)
+        worst_cpu = max(worst_cpu, (grads["f32"][n].double() - ref).abs().max().item() / scale)
+        num += (g.cpu().double() - ref).pow(2).sum().item()
+        num_c += (grads["f32"][n].double() - ref).pow(2).sum().item()
+        den += ref.pow(2).sum().item()
+    l2, l2_c = (num / den) ** 0.5, (num_c / den) ** 0.5
+    print(f"linear piece: worst {worst_inf:.2e} * max|g| ({worst_n}), {flips} ReLU decisions differ from float64's own; against the "
+          f"unmasked oracle: relative L2 {l2:.2e} (reference-style CPU fp32 {l2_c:.2e}), worst entry {worst_mine:.2e} (CPU fp32 {worst_cpu:.2e})")
+    assert l2 <= 5e-4                                                                                                  # (3)
 
 
 def test_backward_bf16_gradients_are_close():
@@ -160,13 +174,20 @@ def test_backward_fp32_other_sdf_activations(bg, act):
     loss.backward()
     assert abs(loss.item() - loss_o.item()) < 1e-4
     nograd = net.nograd_names()
+    # against the oracle's OWN ReLU decisions: whole-gradient relative L2 (a decision within rounding of zero that falls the other
+    # way moves single entries by ~1e-3 * max|g|; which one does depends on the summation order -- see the test above)
+    num = den = worst = 0.0
     for n, p in net.named_parameters():
         if n in nograd:
             continue
         ref = sdo[n].grad
-        e = (p.grad.cpu().double() - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
-        assert e <= 5e-4, f"{n}: rel err {e}"
-    # and on the HIP path's own linear piece (float64 oracle with its ReLU decisions imposed): rounding only
+        d = p.grad.cpu().double() - ref
+        num += d.pow(2).sum().item()
+        den += ref.pow(2).sum().item()
+        worst = max(worst, d.abs().max().item() / (ref.abs().max().item() + 1e-12))
+    assert (num / den) ** 0.5 <= 5e-4, (num / den) ** 0.5
+    print(f"unmasked oracle: relative L2 {(num / den) ** 0.5:.2e}, worst entry {worst:.2e} * max|g|")
+    # and on the HIP path's own linear piece (float64 oracle with its ReLU decisions imposed): rounding only, every entry
     from grad_common import masked_gradient_check
     w_inf, w_n, w_l2, n_flip = masked_gradient_check(net, sd, "dpt_tiny", x, gc, gs, sal, use_bg_sdf=bg, sdf_activation=act)
     print(f"use_bg_sdf={bg} sdf_activation={act}: worst max-norm {w_inf:.2e} ({w_n}), worst relative L2 {w_l2:.2e}, {n_flip} decisions differ")

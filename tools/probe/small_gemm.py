@@ -37,3 +37,21 @@ for dt in (torch.bfloat16, torch.float32):
             res.append(f"{env or 'auto'}: {bench(lambda: ops.gemm_nt(A, B, bias, out=out)):6.1f}")
         os.environ.pop("UMR_NT_SPLITK", None)
         print(f"{str(dt)[6:]:9s} M={M} N={N} K={K}  us per launch  " + "  ".join(res), flush=True)
+
+
+# 3x3 convs on small maps (the DPT fusion blocks at 224^2 batch 2 / 128^2 batch 20): [nb, H, W, Cin] -> N
+for dt in (torch.bfloat16, torch.float32):
+    for (nb, H, W, Cin, N) in [(2, 7, 7, 256, 256), (2, 14, 14, 256, 256), (2, 28, 28, 256, 256), (2, 56, 56, 256, 256), (20, 16, 16, 256, 256), (20, 32, 32, 256, 256)]:
+        A = torch.randn((nb, H, W, Cin), generator=g).to(dev).to(dt)
+        B = (torch.randn((N, 9 * Cin), generator=g) * (9 * Cin) ** -0.5).to(dev).to(dt)
+        bias = torch.zeros(N, device=dev)
+        res = []
+        for env in ("0", None, "2", "3", "4", "6", "8"):
+            if env is None:
+                os.environ.pop("UMR_NT_SPLITK", None)
+            else:
+                os.environ["UMR_NT_SPLITK"] = env
+            res.append(f"{env or 'auto'}: {bench(lambda: ops.gemm_nt(A, B, bias, conv=1)):6.1f}")
+        os.environ.pop("UMR_NT_SPLITK", None)
+        tiles = ((nb * H * W + 127) // 128) * ((N + 127) // 128)
+        print(f"{str(dt)[6:]:9s} conv3x3 [{nb},{H},{W},{Cin}]->{N} ({tiles} tiles)  us per launch, UMR_NT_SPLITK =  " + "  ".join(res), flush=True)

@@ -82,10 +82,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
     }
-    // split-K (plain GEMMs with few tiles and a long K: umr_gemm_nt_ws): the `splits` workgroups of a tile are neighbours in
+    // split-K (few tiles and a long K, plain or conv: umr_gemm_nt_ws): the `splits` workgroups of a tile are neighbours in
     // the remapped order (same XCD, except where a tile straddles two XCD runs), each takes a contiguous range of K-tiles
     int sk = 0, tile_id = bid;
-    if (CONV == 0 && splits > 1) { tile_id = bid / splits; sk = bid - tile_id * splits; }
+    if (splits > 1) { tile_id = bid / splits; sk = bid - tile_id * splits; }
     const int tm = tile_id / tiles_n, tn = tile_id - tm * tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -266,10 +266,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     };
 
     int t_beg = 0, t_end = nt;
-    if (CONV == 0 && splits > 1) {
+    if (splits > 1) {
         const int per = (nt + splits - 1) / splits;     // the launcher chose splits so that no range is empty
         t_beg = sk * per;
         t_end = t_beg + per < nt ? t_beg + per : nt;
+        if (CONV != 0) { st_ci = t_beg / 9; st_tap = t_beg - st_ci * 9; }   // conv K order: channel chunk major, tap minor
     }
     stage(t_beg, 0);
     for (int t = t_beg; t < t_end; t += 2) {
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         compute(smem + STAGE_BYTES);
     }
 
-    if (CONV == 0 && splits > 1) {
+    if (splits > 1) {
         // Every workgroup leaves its partial accumulators in its slab (register-major: 16 x [256 threads] x 16 B, coalesced);
         // the one that arrives last at the tile's counter adds the slabs IN SPLIT ORDER (so the result does not depend on
         // arrival order: bitwise reproducible), resets the counter for the next launch and runs the epilogue.
@@ -506,9 +507,9 @@ extern "C" int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t w
 // whose K loop is long (the transformer's projections at a few thousand tokens: 88 tiles x 64 K-tiles on 256 CUs).  Every
 // range gets >= 6 K-tiles; all tiles x splits workgroups are co-resident.  UMR_NT_SPLITK=0 disables, =n forces n (tests).
 static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
-    if (!have_ws || d->conv != 0 || tiles > UMR_SPLITK_COUNTERS) return 1;
+    if (!have_ws || tiles > UMR_SPLITK_COUNTERS) return 1;
     const int bk = d->dtype == UMR_BF16 ? 64 : 32;
-    const int nt = (d->K + bk - 1) / bk;
+    const int nt = d->conv == 0 ? (d->K + bk - 1) / bk : 9 * ((d->Cin + bk - 1) / bk);   // K-tiles, as the kernel counts them
     int want;
     const char* e = getenv("UMR_NT_SPLITK");
     if (e) {
@@ -518,11 +519,14 @@ static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
         // K = 2048 on (43 -> 33 us at K = 4096), never more; the f32 forms do 6-8x the matrix work per K-tile -- up to five
         // ranges of >= 16 K-tiles (235 -> 92 us at K = 4096)
         if (tiles > 170) return 1;
+        // a handful of tiles (3x3 convs on 7^2 ... 28^2 maps): the slab traffic is negligible, only the ~10 us hand-over counts --
+        // bf16 29 -> 20 us with four ranges, f32 118 -> 34 us with eight
         if (d->dtype == UMR_BF16) {
-            want = nt >= 32 ? 2 : 1;
+            want = tiles <= 32 ? (nt / 8 < 4 ? nt / 8 : 4) : (nt >= 32 ? 2 : 1);
         } else {
             want = (int)(448 / tiles);
-            if (want > nt / 16) want = nt / 16;
+            const int per_min = tiles <= 32 ? 8 : 16;
+            if (want > nt / per_min) want = nt / per_min;
             if (want > 8) want = 8;
         }
     }

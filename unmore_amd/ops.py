@@ -565,7 +565,7 @@ _raw_gemm_nt_call = None
 
 def _gemm_nt_call(d):
     # few 128x128 tiles and a long K: hand the library its split-K scratch (include/umr.h: umr_gemm_nt_ws); the library decides
-    if d.conv == 0 and d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32):
+    if d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32):
         ws = _splitk_workspace(torch.device("cuda", torch.cuda.current_device()))
         return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
     return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())

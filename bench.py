@@ -449,15 +449,35 @@ def run_rank(a):
             peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams)
         units_per_step = 1
 
-    for _ in range(a.warmup):
+    # HIP-graph replay of the step (unmore_amd/graphs.py): 'auto' captures the small workloads (ref / cfg1 / cfg5 / tiny: their
+    # step is bound by the host's launch rate) and leaves the 384^2 / 518^2 batches eager.  A replayed step cannot carry per-kernel
+    # HIP events, so the dominant kernel is then timed in a separate eager leg AFTER the timed region (said so in the line).
+    from unmore_amd import graphs
+    if kind == "train":
+        step.set_graph_mode(a.graphs)
+    else:
+        net.set_graph_mode(a.graphs)
+    pixels = (50 if kind == "sweep" else B) * H * W
+    graphed = world == 1 and graphs.wanted(a.graphs, pixels)
+    warm = a.warmup + (graphs.WARMUP_CALLS + 1 if graphed and kind != "sweep" else 0)   # two eager calls + the capturing call, untimed
+    for _ in range(warm):
         one()
     barrier()
-    ops.set_kernel_timer(is_head_conv)
+    if not graphed:
+        ops.set_kernel_timer(is_head_conv)
+    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        th = time.perf_counter()
         one()
+        host_s += time.perf_counter() - th
     barrier()
     elapsed = time.perf_counter() - t0
+    if graphed:
+        # separate eager leg for the roofline's kernel timing (events on the launch stream around every head-conv launch)
+        ops.set_kernel_timer(is_head_conv)
+        for _ in range(2):
+            one()
     conv_ms = ops.kernel_timer_results_ms()
     ops.set_kernel_timer(None)
     own = gather_over_ranks(elapsed)
@@ -494,6 +514,11 @@ def run_rank(a):
             "collective": coll,
             "per_rank_images_per_sec": [units_per_step * a.steps / t for t in own],   # each rank's own clock between the barriers
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            # host time spent enqueueing one step (no synchronisation inside): what a HIP-graph replay removes
+            "host_enqueue_ms_per_step": 1e3 * host_s / a.steps,
+            "hip_graph": ({"mode": a.graphs, "replayed": True, "warmup_calls_untimed": warm,
+                           "roofline_timing": "separate eager leg of 2 steps after the timed region (no per-kernel events inside a replay)"}
+                          if graphed else {"mode": a.graphs, "replayed": False}),
             "roofline": {"bound": "mfma",
                          "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 of the heads ("
                                     + ("per step: 2 forward launches + the centre head's ReLU-masked data gradient; the boundary-distance head's "
@@ -681,6 +706,8 @@ def main():
     ap.add_argument("--sweep-streams", type=int, default=3, help="cfg5: HIP streams the independent 50-crop batches are dealt to")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="plain --gpus N launch: overall deadline in seconds, counted from the launch")
     ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # launcher test hook
+    ap.add_argument("--graphs", default="auto", choices=["auto", "on", "off"],
+                    help="HIP-graph replay of the step: auto = small workloads only (B*H*W <= 2^20 pixels), eager otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()

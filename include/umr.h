@@ -231,6 +231,13 @@ int umr_objectness_loss(const float* pred_center, const float* pred_sdf, const f
 /* ---- Adam on a flat f32 parameter buffer (torch.optim.Adam defaults; train_objectness_net.py:96,260) ---- */
 int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                   int step, float grad_scale, umr_stream_t stream);
+/* The same update with its scalars in DEVICE memory, for a train step captured in a HIP graph and replayed with a new learning
+ * rate / step count each iteration (the per-iteration MultiStepLR of train_objectness_net.py:261 changes lr between replays).
+ * umr_adam_set_hyper writes hyper7 = [lr, beta1, beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step), grad_scale] (one tiny launch,
+ * arguments by value: no host buffer has to outlive the call); umr_adam_step_hyper is bit-identical to umr_adam_step with the
+ * same arguments. */
+int umr_adam_set_hyper(float* hyper7_dev, float lr, float beta1, float beta2, float eps, int step, float grad_scale, umr_stream_t stream);
+int umr_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper7_dev, umr_stream_t stream);
 
 /* ---- object-reasoning glue around the net ("next" rows f1/f2) -----------------------
  * crop_resize: proposal crops [x1,y1,x2,y2) of a [3,H,W] f32 image -> [N,3,S,S], bilinear, no antialias

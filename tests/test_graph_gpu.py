@@ -1,0 +1,125 @@
+"""HIP-graph replay of the engine's launch lists (unmore_amd/graphs.py): a replayed train step / inference call produces
+bit-identical results to the eager launch list -- same kernels, same arguments, same order -- across changing inputs, a
+learning-rate milestone, an in-place parameter change, a reloaded state dict, another input shape and several streams."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+from unmore_amd import synth
+from unmore_amd.hashrng import hash_init
+
+pytestmark = pytest.mark.gpu
+ARGS = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+
+
+def _net(backbone="dpt_tiny", tag="tiny", dtype=torch.float32, size=64):
+    from unmore_amd.objectness_net import ObjectnessNet
+    net = ObjectnessNet("cuda:0", size, backbone, ARGS)
+    sd = {k: torch.from_numpy(hash_init(k, tuple(v.shape), tag)) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0")
+    net.set_compute_dtype(dtype)
+    return net, sd
+
+
+def _batch(B, H, W, seed):
+    return tuple(torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=seed))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainstep_replay_is_bit_identical_to_eager(dtype):
+    from unmore_amd.trainer import TrainStep
+    B, H, W = 2, 64, 64
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    # a milestone inside the run: the learning rate and Adam's bias corrections reach the replay through device memory
+    step_e = TrainStep(net_e, lr=1e-3, lr_milestones=(4,), lr_gamma=0.1).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=1e-3, lr_milestones=(4,), lr_gamma=0.1).set_graph_mode("on")
+    for it in range(7):
+        batch = _batch(B, H, W, seed=10 + it)       # new tensors every step: the replay reads its own input buffers
+        le = step_e.step(*batch)
+        lg = step_g.step(*batch)
+        assert torch.equal(le, lg), (it, le.tolist(), lg.tolist())
+        assert torch.equal(step_e.flat_g, step_g.flat_g), it
+        assert torch.equal(step_e.flat_p, step_g.flat_p), it
+    assert step_g.graph_replays == 7 - 2 and step_e.graph_replays == 0     # two eager warm-up steps, then capture + replays
+    assert torch.equal(step_e.m, step_g.m) and torch.equal(step_e.v, step_g.v)
+    # another shape: eager while it warms up, results still equal; the first shape's capture is kept
+    b2 = _batch(3, 64, 96, seed=99)
+    assert torch.equal(step_e.step(*b2), step_g.step(*b2))
+    b1 = _batch(B, H, W, seed=100)
+    assert torch.equal(step_e.step(*b1), step_g.step(*b1))
+    assert step_g.graph_replays == 6
+    assert torch.equal(step_e.flat_p, step_g.flat_p)
+
+
+def test_trainstep_recaptures_after_state_dict_reload():
+    from unmore_amd.trainer import TrainStep
+    net_e, sd = _net()
+    net_g, _ = _net()
+    step_e = TrainStep(net_e, lr=1e-3).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=1e-3).set_graph_mode("on")
+    batch = _batch(2, 64, 64, seed=1)
+    for _ in range(4):
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch))
+    sd2 = {k: v * 0.5 for k, v in sd.items()}
+    for net, st in ((net_e, step_e), (net_g, step_g)):
+        net.load_state_dict(sd2, strict=True)
+        st.sync_from_model()
+    n0 = step_g.graph_replays
+    for _ in range(4):
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch))
+    assert step_g.graph_replays == n0 + 2            # two eager steps (the packed weights were rebuilt), then a new capture
+    assert torch.equal(step_e.flat_p, step_g.flat_p)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_inference_replay_is_bit_identical_and_follows_parameter_changes(dtype):
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    net_e.set_graph_mode("off").eval()
+    net_g.set_graph_mode("on").eval()
+    outs = []
+    with torch.no_grad():
+        for it in range(5):
+            x = _batch(3, 64, 64, seed=it)[0]
+            oe, og = net_e.get_prediction(x), net_g.get_prediction(x)
+            for k in ("center_fields", "sdf_maps"):
+                assert torch.equal(oe[k], og[k]), (it, k)
+            outs.append(og["sdf_maps"])
+        assert not torch.equal(outs[3], outs[4])         # results are the caller's own tensors, not the capture's output buffer
+        from unmore_amd import graphs
+        caps = [v for v in net_g._inf_graphs.values() if isinstance(v, graphs.Captured)]
+        assert len(caps) == 1 and caps[0].failed is None
+        # an in-place parameter change: the capture read the packed copy of the old weight and must not be replayed
+        for net in (net_e, net_g):
+            net.sdf_prediction_head[1].weight.mul_(1.25)
+            net.backbone.pretrained.model.blocks[0].mlp.fc1.weight.add_(0.01)
+        x = _batch(3, 64, 64, seed=7)[0]
+        oe, og = net_e.get_prediction(x), net_g.get_prediction(x)
+        for k in ("center_fields", "sdf_maps"):
+            assert torch.equal(oe[k], og[k]), k
+        assert not torch.equal(og["sdf_maps"], outs[-1])
+
+
+def test_sweep_on_three_streams_with_replays_equals_eager():
+    """reasoning.sweep_proposals deals 50-crop batches to three streams: every stream replays its own capture (own scratch)."""
+    import numpy as np
+    from unmore_amd import reasoning
+    net_e, _ = _net("dpt_tiny", "tiny", size=128)
+    net_g, _ = _net("dpt_tiny", "tiny", size=128)
+    net_e.set_graph_mode("off").eval()
+    net_g.set_graph_mode("on").eval()
+    image = torch.from_numpy(synth.blob_images(1, 240, 320, seed=3)[0]).cuda()
+    rng = np.random.default_rng(0)
+    x1, y1 = rng.integers(0, 200, 600), rng.integers(0, 140, 600)
+    props = torch.from_numpy(np.stack([x1, y1, x1 + rng.integers(16, 120, 600), y1 + rng.integers(16, 100, 600)], 1).astype(np.float64))
+    for rep in range(2):
+        re = reasoning.sweep_proposals(net_e, image, props, 50, n_streams=3)
+        rg = reasoning.sweep_proposals(net_g, image, props, 50, n_streams=3)
+        for a, b in zip(re, rg):
+            assert torch.equal(a, b), rep
+    from unmore_amd import graphs
+    caps = [v for v in net_g._inf_graphs.values() if isinstance(v, graphs.Captured)]
+    assert len(caps) == 3 and all(c.failed is None for c in caps)

@@ -97,6 +97,8 @@ _SIGS = {
     "umr_loss_workspace": [],
     "umr_objectness_loss": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "umr_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "umr_adam_set_hyper": [_vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
+    "umr_adam_step_hyper": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "umr_crop_resize_bilinear": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],

@@ -838,6 +838,21 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// same update with its seven scalars read from device memory (a captured HIP graph replays this launch every step with new values)
+__global__ void adam_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                  const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5], gscale = hyper[6];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = m[i] * b1 + gi * (1.f - b1);
+        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - (lr / bc1) * (mi / denom);
+    }
+}
+
 inline int grid_for(int64_t total, int block = 256, int cap = 8192) {
     int64_t g = (total + block - 1) / block;
     if (g > cap) g = cap;
@@ -1088,12 +1103,41 @@ extern "C" int umr_objectness_loss(const float* pred_center, const float* pred_s
     return UMR_OK;
 }
 
+static void adam_hyper(float lr, float beta1, float beta2, float eps, int step, float grad_scale, float* hyper7) {
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hyper7[0] = lr; hyper7[1] = beta1; hyper7[2] = beta2; hyper7[3] = eps;
+    hyper7[4] = (float)bc1; hyper7[5] = (float)sqrt(bc2); hyper7[6] = grad_scale;
+}
+
+namespace {
+struct Hyper7 { float v[7]; };
+__global__ void adam_set_hyper_kernel(float* dst, Hyper7 h) { if (threadIdx.x < 7) dst[threadIdx.x] = h.v[threadIdx.x]; }
+}
+
+extern "C" int umr_adam_set_hyper(float* hyper7_dev, float lr, float beta1, float beta2, float eps, int step, float grad_scale, umr_stream_t stream) {
+    UMR_CHECK_ARG(hyper7_dev && step >= 1, "adam_set_hyper: bad arguments");
+    Hyper7 h;
+    adam_hyper(lr, beta1, beta2, eps, step, grad_scale, h.v);
+    hipLaunchKernelGGL(adam_set_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper7_dev, h);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
 extern "C" int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                              int step, float grad_scale, umr_stream_t stream) {
     UMR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    float h[7];
+    adam_hyper(lr, beta1, beta2, eps, step, grad_scale, h);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, p, g, m, v, n, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper7_dev, umr_stream_t stream) {
+    UMR_CHECK_ARG(p && g && m && v && n > 0 && hyper7_dev, "adam_step_hyper: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, p, g, m, v, n, hyper7_dev);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -14,6 +14,7 @@ import os
 import torch
 
 from . import _lib as L
+from . import graphs
 from . import ops
 
 CONFIGS = {
@@ -42,19 +43,34 @@ class PackCache:
         self._c = {}           # key -> [version, value, event, synced streams, recipe, param]: replayable packs
         self._o = {}           # same without a recipe: rebuilt lazily after refresh()
         self._replay = None    # (launcher, keys) of the batched refresh, built on first use
+        # A captured graph holds the ADDRESSES of the copies it read: gen_c counts changes of the replayable set (and of the batched
+        # refresh's table), gen_o changes of the rest.  A capture depends on gen_o only if it read such an entry that it did not
+        # build itself (a capture rebuilds its own on every replay): generation(store)
+        self.gen_c = 0
+        self.gen_o = 0
+        self._epoch = None     # (event, synced streams) of the last refresh that ran inside a graph replay (graphs.py)
 
     def get(self, key, param, build):
         ver = (param._version, param.data_ptr())
         hit = self._c.get(key) or self._o.get(key)
+        cap = graphs.capturing()
         if param.is_cuda:
             st = torch.cuda.current_stream(param.device)
             sid = st.cuda_stream
         else:
             st, sid = None, None
         if hit is not None and hit[0] == ver:
-            if st is not None and sid not in hit[3]:
-                st.wait_event(hit[2])
-                hit[3].add(sid)
+            if cap and key in self._o and hit[6] is not graphs.capture_store():
+                graphs.capture_store()["hit_o"] = True
+            # (inside a capture nothing from before it is pending -- graphs.Captured synchronises first -- and an event wait on
+            # work outside the capture must not be recorded into it)
+            if st is not None and not cap:
+                if hit[2] is not None and sid not in hit[3]:
+                    st.wait_event(hit[2])
+                    hit[3].add(sid)
+                if self._epoch is not None and sid not in self._epoch[1]:
+                    st.wait_event(self._epoch[0])
+                    self._epoch[1].add(sid)
             return hit[1]
         # record what the build launches: a pack that is exactly ONE permute / cast into the returned tensor can be replayed by
         # refresh() (every pack helper below is); anything else is rebuilt lazily after a refresh
@@ -64,41 +80,62 @@ class PackCache:
             val = build()
         finally:
             ops._pack_recorder = prev
-        recipe = rec[0] if (len(rec) == 1 and torch.is_tensor(val) and rec[0][1].data_ptr() == val.data_ptr()) else None
+        # replayable only if the recorded source IS the parameter's storage: a pack helper that had to make a temporary copy first
+        # (reshape of a non-contiguous parameter) would be re-packed from that stale temporary forever
+        recipe = rec[0] if (len(rec) == 1 and torch.is_tensor(val) and rec[0][1].data_ptr() == val.data_ptr()
+                            and rec[0][0].untyped_storage().data_ptr() == param.untyped_storage().data_ptr()) else None
         ev = None
-        if st is not None:
+        if st is not None and not cap:
             ev = torch.cuda.Event()
             ev.record(st)
-        entry = [ver, val, ev, {sid}, recipe, param]
-        self._c.pop(key, None)
-        self._o.pop(key, None)
+        entry = [ver, val, ev, {sid}, recipe, param, (graphs.capture_store() if cap else None)]
+        if self._c.pop(key, None) is not None:
+            self._replay = None       # the batched refresh was built over the dropped entry
+            self.gen_c += 1
+        if self._o.pop(key, None) is not None:
+            self.gen_o += 1
         if recipe is not None and st is not None:
             self._c[key] = entry
             self._replay = None
+            self.gen_c += 1
         else:
             self._o[key] = entry
+            self.gen_o += 1
         return val
+
+    def generation(self, store=None):
+        """validity stamp of a capture whose scratch dict is `store` (graphs.Captured)"""
+        return (self.gen_c, self.gen_o if (store is None or store.get("hit_o")) else None)
 
     def clear(self):
         self._c.clear()
         self._o.clear()
         self._replay = None
+        self._epoch = None
+        self.gen_c += 1
+        self.gen_o += 1
 
     def refresh(self):
         """The parameters were updated IN PLACE by a kernel torch does not see (TrainStep's Adam launch): re-run every pack into
         its existing destination in ONE launch (umr_permute4_batched) instead of dropping the copies and re-packing ~180
         weights one launch each during the next step.  Entries that are not a single permute are dropped (rebuilt lazily)."""
-        self._o.clear()
+        if self._o:
+            self._o.clear()
+            if not graphs.capturing():   # (inside a capture every such entry was built by the capture itself and is rebuilt by each replay)
+                self.gen_o += 1
         if not self._c:
             return
         if any(e[5].data_ptr() != e[0][1] for e in self._c.values()):   # a parameter's storage moved: the recipes are stale
             self.clear()
             return
         if self._replay is None:
+            assert not graphs.capturing(), "PackCache.refresh: the batched refresh must be built before a capture (warm-up steps)"
             keys = list(self._c)
             self._replay = (ops.permute4_batched([self._c[k][4] for k in keys]), keys)
         launch, keys = self._replay
         launch()
+        if graphs.capturing():
+            return                     # the replaying caller publishes the refresh with refreshed_by_replay()
         st = torch.cuda.current_stream(self._c[keys[0]][5].device)
         ev = torch.cuda.Event()
         ev.record(st)
@@ -106,6 +143,14 @@ class PackCache:
             e = self._c[k]
             e[0] = (e[5]._version, e[5].data_ptr())
             e[2], e[3] = ev, {st.cuda_stream}
+
+    def refreshed_by_replay(self, device):
+        """A graph replay on the current stream has just re-run the refresh: a consumer on another stream orders itself after it
+        (one event for the whole cache instead of one per entry)."""
+        st = torch.cuda.current_stream(device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self._epoch = (ev, {st.cuda_stream})
 
 
 def _pack_linear(w, dt):  # [N,K] -> [N,K] T

@@ -11,6 +11,7 @@ reference's names; all arithmetic runs in the hand-written HIP kernels via
 import torch
 from torch import nn
 
+from . import graphs, ops
 from .engine import CONFIGS, Engine
 
 
@@ -262,11 +263,53 @@ class ObjectnessNet(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             center, sdf = _NetFunction.apply(x, self, names, *params)
         else:
-            center, sdf, _ = self._engine().forward(dict(zip(names, params)), x, save=False)
+            center, sdf = self._forward_nograd(x, names, params)
         out_dict = {}
         out_dict["center_fields"] = center.to(in_dtype)  ## [B, 2, H, W]
         out_dict["sdf_maps"] = sdf.to(in_dtype)  ## [B, 1, H, W]
         return out_dict
+
+    def set_graph_mode(self, mode):
+        """Inference calls (no autograd) of small batches -- 'auto': B*H*W <= 2^20 pixels, the reference's [<= 50, 3, 128, 128] crops
+        (object_reasoning.py:301-337) -- are captured into a HIP graph on their third call with the same shape and replayed
+        afterwards (graphs.py); 'on' / 'off' force it.  A change of any parameter drops the captures."""
+        assert mode in ("auto", "on", "off")
+        self.graph_mode = mode
+        self._inf_graphs = {}
+        return self
+
+    def _forward_nograd(self, x, names, params):
+        eng = self._engine()
+        P = dict(zip(names, params))
+        B, _, H, W = x.shape
+        mode = getattr(self, "graph_mode", None)
+        if graphs.wanted(mode, B * H * W) and ops._timer["select"] is None and not graphs.capturing():
+            # the captures read the packed weight copies and, in fp32 mode, the parameters themselves: any in-place update bumps a
+            # version counter, a re-homed parameter changes its address
+            sig = (sum(p._version for p in params), params[0].data_ptr(), params[-1].data_ptr(), id(eng))
+            store = self.__dict__.setdefault("_inf_graphs", {})
+            if store.get("sig") != sig:
+                store.clear()
+                store["sig"] = sig
+            key = (tuple(x.shape), ops.get_f32_mode(), torch.cuda.current_stream(x.device).cuda_stream)
+            ent = store.get(key)
+            if isinstance(ent, graphs.Captured):
+                if ent.valid():
+                    center, sdf = ent.replay(x)
+                    return center.clone(), sdf.clone()
+                if ent.failed is None:
+                    ent = None
+            if not isinstance(ent, graphs.Captured):
+                n = (ent or 0) + 1
+                store[key] = n
+                if n > graphs.WARMUP_CALLS:
+                    cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation)
+                    store[key] = cap
+                    if cap.failed is None:
+                        center, sdf = cap.replay(x)
+                        return center.clone(), sdf.clone()
+        center, sdf, _ = eng.forward(P, x, save=False)
+        return center, sdf
 
     def forward(self, images):
         return self._run(images)

@@ -10,6 +10,7 @@ import ctypes
 import torch
 
 from . import _lib as L
+from . import graphs
 
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 
@@ -58,6 +59,14 @@ def _workspace(nbytes, device):
     # Streams come and go (their raw handles are the keys), so the cache is a small LRU: an evicted buffer goes back to the
     # allocator pool of the stream it was allocated (and only ever used) on, which orders its reuse after the kernels that
     # scribbled on it.
+    if graphs.capturing():
+        # a captured graph owns its scratch (allocated from the capture's private pool, kept alive by the Captured object): two
+        # graphs recorded on the same internal capture stream may be replayed on different streams at the same time
+        store = graphs.capture_store()
+        buf = store.get("ws")
+        if buf is None or buf.numel() < nbytes:
+            buf = store["ws"] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        return buf
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.pop(key, None)
     if buf is None or buf.numel() < nbytes:
@@ -73,6 +82,13 @@ _sk_cache = collections.OrderedDict()
 
 def _splitk_workspace(device):
     """Per-(device, stream) scratch of umr_gemm_nt_ws: tile counters (zeroed once here; every launch leaves them zero) + slabs."""
+    if graphs.capturing():
+        store = graphs.capture_store()   # see _workspace; the zeroing of the counters is recorded too: every replay starts clean
+        buf = store.get("sk")
+        if buf is None:
+            buf = store["sk"] = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
+            buf[:16384].zero_()
+        return buf
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _sk_cache.pop(key, None)
     if buf is None:
@@ -542,6 +558,21 @@ def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_
         assert t.dtype == torch.float32 and t.is_contiguous()
     L.check(L.lib().umr_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step, grad_scale, _stream()),
             "umr_adam_step")
+
+
+def adam_set_hyper(hyper, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """writes Adam's seven scalars for this step into the device buffer `hyper` (f32 [7]); see adam_step_hyper"""
+    _need_gpu(hyper)
+    assert hyper.dtype == torch.float32 and hyper.numel() >= 7 and hyper.is_contiguous()
+    L.check(L.lib().umr_adam_set_hyper(_p(hyper), lr, beta1, beta2, eps, step, grad_scale, _stream()), "umr_adam_set_hyper")
+
+
+def adam_step_hyper(p, g, m, v, hyper):
+    """adam_step with its scalars read from device memory (a captured graph replays this launch with new values every step)"""
+    _need_gpu(p, g, m, v, hyper)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    L.check(L.lib().umr_adam_step_hyper(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream()), "umr_adam_step_hyper")
 
 
 # ---------------------------------------------------------------- kernel timing hook (bench.py roofline leg)

@@ -13,7 +13,7 @@ import torch
 
 import os
 
-from . import ops
+from . import graphs, ops
 from .parallel import BucketedAllReduce
 
 _BATCHED_REPACK = os.environ.get("UMR_BATCHED_REPACK", "1") != "0"   # A/B switch: 0 = drop the packed copies, re-pack lazily (round 2)
@@ -85,6 +85,10 @@ class TrainStep:
         self.P = {n: p for n, p in net.named_parameters()}
         self._offs = offs
         self.comm = BucketedAllReduce(self.flat_g, bounds, group)
+        self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)   # Adam's per-step scalars (ops.adam_set_hyper)
+        self.graph_mode = graphs.DEFAULT_MODE
+        self._graphs = {}           # (input shape, dtype, f32 mode, stream) -> eager-call count, then graphs.Captured
+        self.graph_replays = 0
         net._engine().cache.clear()
 
     def current_lr(self):
@@ -94,25 +98,66 @@ class TrainStep:
                 lr *= self.gamma
         return lr
 
-    def step(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
-        """One optimisation step; returns the [total, center, sdf, grad, bce] loss tensor (device, f32)."""
-        if images.shape[0] == 0:
-            # the reference would take the mean of empty maps (NaN) and push NaN gradients into Adam; refuse instead
-            raise ValueError("TrainStep.step: empty batch (every image was filtered out); skip this iteration")
+    def _body(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
+        """forward, loss, backward, gradient exchange, Adam (scalars from self._hyper), weight-copy refresh: the launch list of one
+        step.  Runs eagerly or under a HIP-graph capture (graphs.py)."""
         eng = self.net._engine()
         center, sdf, S = eng.forward(self.P, images, save=True)
         out5, dpc, dps = ops.objectness_loss(center, sdf, gt_center_fields, gt_sdf_maps, gt_saliency_maps, *self.loss_cfg)
         eng.backward(self.P, S, dpc, dps, self.G, stage_cb=lambda s: self.comm.ready(self.stage_bucket[s]))
-        scale = self.comm.finish()
-        self.iter += 1
-        ops.adam_step(self.flat_p, self.flat_g, self.m, self.v, self.iter, self.current_lr_for_step(), self.betas[0], self.betas[1],
-                      self.eps, scale)
+        self.comm.finish()
+        ops.adam_step_hyper(self.flat_p, self.flat_g, self.m, self.v, self._hyper)
         # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
         if _BATCHED_REPACK:
             eng.cache.refresh()
         else:
             eng.cache.clear()
-        return out5
+        return (out5,)
+
+    def set_graph_mode(self, mode):
+        """'auto' (default; env UMR_GRAPHS): steps of small batches (B*H*W <= 2^20 pixels -- the reference's own recipe, 20 crops of
+        128x128, README.md:148-155) are captured into a HIP graph after two eager steps of the same shape and replayed; 'on' / 'off'
+        force it.  Data-parallel runs (world > 1) stay eager: their collectives are not captured."""
+        assert mode in ("auto", "on", "off")
+        self.graph_mode = mode
+        self._graphs.clear()
+        return self
+
+    def step(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
+        """One optimisation step; returns the [total, center, sdf, grad, bce] loss tensor (device, f32)."""
+        if images.shape[0] == 0:
+            # the reference would take the mean of empty maps (NaN) and push NaN gradients into Adam; refuse instead
+            raise ValueError("TrainStep.step: empty batch (every image was filtered out); skip this iteration")
+        self.iter += 1
+        ops.adam_set_hyper(self._hyper, self.iter, self.current_lr_for_step(), self.betas[0], self.betas[1], self.eps, 1.0 / self.comm.world)
+        ins = (images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
+        eng = self.net._engine()
+        B, _, H, W = images.shape
+        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W) and ops._timer["select"] is None:
+            key = (tuple(images.shape), eng.dt, ops.get_f32_mode(), torch.cuda.current_stream(images.device).cuda_stream)
+            ent = self._graphs.get(key)
+            if isinstance(ent, graphs.Captured):
+                if ent.valid():
+                    (out5,) = ent.replay(*ins)
+                    eng.cache.refreshed_by_replay(images.device)
+                    self.graph_replays += 1
+                    return out5.clone()
+                if ent.failed is None:
+                    ent = None            # the packed weights moved (state dict reloaded): warm up and capture again
+            if not isinstance(ent, graphs.Captured):
+                n = (ent or 0) + 1
+                self._graphs[key] = n
+                if n > graphs.WARMUP_CALLS:
+                    # the warm-up steps have packed every weight, built the batched refresh and sized the workspaces
+                    cap = graphs.Captured(self._body, ins, generation_of=eng.cache.generation)
+                    self._graphs[key] = cap
+                    if cap.failed is None:
+                        # the capture only RECORDED the step: run it
+                        (out5,) = cap.replay(*ins)
+                        eng.cache.refreshed_by_replay(images.device)
+                        self.graph_replays += 1
+                        return out5.clone()
+        return self._body(*ins)[0]
 
     # ---- checkpoint / resume (train_objectness_net.py:118-123,268-275: {'model_state_dict', 'optimizer_state_dict', 'iter'})
     def optimizer_state_dict(self):
@@ -155,7 +200,8 @@ class TrainStep:
 
     def sync_from_model(self):
         """Call after model.load_state_dict(): the flat parameter buffer is the storage of the parameters, so loading writes
-        through; only the packed kernel-layout weight copies have to be dropped."""
+        through; only the packed kernel-layout weight copies have to be dropped (captured steps notice through the cache's
+        generation and are captured again after two eager steps)."""
         self.net._engine().cache.clear()
 
     def current_lr_for_step(self):

@@ -63,7 +63,9 @@ int umr_get_f32_mode(void);
 enum umr_epi_flags {
     UMR_EPI_BIAS = 1, UMR_EPI_ADD_AUX = 2, UMR_EPI_MASK_RELU = 4, UMR_EPI_MASK_DGELU = 8,
     UMR_EPI_ADD_AUX2 = 16, UMR_EPI_OUT_F32 = 32, UMR_EPI_ROWBIAS = 64,
-    UMR_EPI_OUT_X3 = 128   /* dtype UMR_BF16X3 only: C is written as three bf16 planes [h(N) | m(N) | l(N)] per row (ldc >= 3N) */
+    UMR_EPI_OUT_X3 = 128,  /* dtype UMR_BF16X3 only: C is written as three bf16 planes [h(N) | m(N) | l(N)] per row (ldc >= 3N) */
+    /* dtype UMR_BF16X3 only: the operand is given as / written as bf16 planes ([M][3N], row stride >= 3N) instead of f32 [M][N] */
+    UMR_EPI_AUX_X3 = 256, UMR_EPI_AUX2_X3 = 512, UMR_EPI_C2_X3 = 1024
 };
 enum umr_act { UMR_ACT_NONE = 0, UMR_ACT_RELU = 1, UMR_ACT_GELU = 2, UMR_ACT_TANH = 3, UMR_ACT_SIGMOID = 5 /* 4 = sine, head_out only */ };
 
@@ -102,15 +104,22 @@ typedef struct umr_gemm_desc {
     int32_t no_store;
 } umr_gemm_desc;
 
-/* dtype UMR_BF16X3 -- the fast form of the fp32 parity mode (the reference runs in fp32, object_reasoning.py:74): both operands
- * are f32 values pre-split into bf16 planes; the product is the six-term sum of UMR_F32_X3 (same accuracy and the same range
- * caveats) computed as six bf16 K-tiles per logical K-tile on the persistent 256x256 kernel, with no split arithmetic in the
- * loop.  A: [M][3K] bf16 (lda >= 3K), or NHWC with 3*Cin bf16 per pixel [h(Cin) | m(Cin) | l(Cin)] when conv == 1;
- * B: [N][3K] bf16 (ldb >= 3K; conv: K = 9*Cin ordered (ky,kx,ci) inside each plane).  K (conv: Cin) must be a multiple of 64,
- * N of 8; epilogue: bias, ReLU, and exactly one of UMR_EPI_OUT_F32 (C f32 [M][N]) / UMR_EPI_OUT_X3 (C planes [M][3N] bf16) -- or,
- * for a plain GEMM, the fused row reduction red_* with no_store = 1 (dot products of the f32 values, C never stored);
- * optionally UMR_EPI_MASK_RELU with aux = an F32 [M][N] tensor (ldaux): v *= (aux > 0), the ReLU-masked data gradient;
- * no other aux / remap / C2.  Anything else returns UMR_ERR_UNSUPPORTED. */
+/* dtype UMR_BF16X3 -- the fast form of the fp32 parity mode (the reference runs in fp32, object_reasoning.py:74,
+ * train_objectness_net.py:81): both operands are f32 values pre-split into bf16 planes; the product is the six-term sum of
+ * UMR_F32_X3 (same accuracy and the same range caveats) computed as six bf16 K-tiles per logical K-tile on the persistent 256x256
+ * kernel, with no split arithmetic in the loop.  A: [M][3K] bf16 (lda >= 3K; no A-row remap), or NHWC with 3*Cin bf16 per pixel
+ * [h(Cin) | m(Cin) | l(Cin)] when conv == 1; B: [N][3K] bf16 (ldb >= 3K; conv: K = 9*Cin ordered (ky,kx,ci) inside each plane).
+ * K (conv: Cin) must be a multiple of 64, N of 8.  Epilogue: everything umr_gemm_desc describes except tanh / sigmoid, in f32
+ * (GELU = the exact erf form): bias, rowbias, one of ADD_AUX / MASK_RELU / MASK_DGELU, ADD_AUX2, c2_mode 1 / 2, act none / ReLU /
+ * GELU, C-row remap and aux_mod (plain GEMM).  Operand FORMATS: C is f32 [M][N] (UMR_EPI_OUT_F32) or planes [M][3N]
+ * (UMR_EPI_OUT_X3) -- exactly one of the two; aux / aux2 / C2 are f32 [M][N] unless UMR_EPI_AUX_X3 / AUX2_X3 / C2_X3 say planes
+ * (a plane operand is read back as h + m + l = the f32 value; the ReLU mask reads only h, whose sign is the value's).  Or, for a
+ * plain GEMM at inference, the fused row reduction red_* with no_store = 1 (bias / ReLU only; dot products of the f32 values, C
+ * never stored).  Anything else returns UMR_ERR_UNSUPPORTED.
+ * Small problems (the transformer at a few thousand tokens, 3x3 convs on the 4x4 ... 64x64 DPT maps: fewer tiles than CUs, or a
+ * ragged last round) are cut along K into work items whose f32 partial sums go to workspace slabs, added in slab order by a
+ * second launch that applies the epilogue (bitwise reproducible): pass umr_gemm_nt_ws a workspace of
+ * umr_gemm_nt_workspace() + umr_gemm_nt_x3_workspace(d) bytes (the latter 0 when the problem is not split). */
 int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
 /* Same, with a scratch buffer that lets small problems use split-K: plain GEMMs with few 128x128 tiles and a long K (the
  * transformer's projections at a few thousand tokens -- the reference's own recipe trains on 128x128 images, batch 20 = 1300
@@ -119,10 +128,15 @@ int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
  * umr_gemm_nt_workspace() bytes of device memory, 16-byte aligned, whose first 16 KiB are ZERO on first use (tile counters; every
  * launch leaves them zero) and which no other stream uses concurrently.  workspace == NULL is umr_gemm_nt. */
 int64_t umr_gemm_nt_workspace(void);
+int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d);   /* extra bytes a UMR_BF16X3 problem wants for its K-split slabs */
 int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
 int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);
+/* the same with a gather of source rows: destination row r is source row (r / rows_in) * rows_out + row_off + r % rows_in (rows_in
+ * == 0: identity) -- the token rows of every image without its class-token row (models/dpt/vit.py:87-88) as a compact operand */
+int umr_split3_rows(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, int rows_in, int rows_out,
+                    int row_off, umr_stream_t stream);
 /* 1 if umr_gemm_nt would run d (ignoring red_*, no_store) on the path that implements the fused row reduction */
 int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d);
 
@@ -132,7 +146,10 @@ int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d);
  * gradients of the modules listed above (train_objectness_net.py:259).
  * Split over `splits` row ranges into workspace slabs [splits][N][K] f32, then
  * reduced in fixed order (bitwise reproducible).  workspace_bytes must be
- * >= umr_gemm_tn_workspace(d). */
+ * >= umr_gemm_tn_workspace(d).
+ * dtype UMR_BF16X3: dY [M][h(N) | m(N) | l(N)] and X [M][h(K) | m(K) | l(K)] (conv == 1: NHWC pixels of [h(Cin) | m(Cin) |
+ * l(Cin)]) hold f32 values as bf16 planes (lddy >= 3N, ldx >= 3K); dW / dbias are the fp32-grade six-term products / sums (see
+ * umr_gemm_nt).  N, K (conv: Cin) multiples of 8; any map size; no row remaps, no stride-2 conv (UMR_ERR_UNSUPPORTED). */
 typedef struct umr_gemm_tn_desc {
     const void* dY;       /* [M,N] (lddy) */
     const void* X;        /* [M,K] (ldx) or NHWC input when conv != 0 */
@@ -154,6 +171,7 @@ int64_t umr_gemm_tn_workspace(const umr_gemm_tn_desc* d);
 int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream);
 
 /* ---- LayerNorm over rows of D (timm LayerNorm eps 1e-6 inside Block; vit.py:196-199) ----
+ * fwd with dtype UMR_BF16X3: x is f32, y is written as bf16 planes [M][h(D) | m(D) | l(D)] (the operand of the plane GEMMs).
  * bwd: dx = LN'(dy) (+ dres if non-null: residual-branch gradient), dgamma/dbeta (f32, =/+= per `accumulate`). */
 int umr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       int M, int D, float eps, int dtype, umr_stream_t stream);
@@ -198,6 +216,8 @@ int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int6
 typedef struct umr_perm_entry {
     const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start;
     int32_t e[4]; int32_t ord[4];
+    int64_t rowlen;   /* dtype_out == UMR_BF16X3: the destination is [rows][h(rowlen) | m(rowlen) | l(rowlen)] bf16 planes of the f32 values,
+                         row = destination element index / rowlen (the weights of the fp32-grade plane GEMMs); otherwise ignored */
 } umr_perm_entry;
 /* blk_entry_dev: optional int32[total_blocks] in device memory, the entry index of every block (saves the per-block search) */
 int umr_permute4_batched(const umr_perm_entry* table_dev, int n, int64_t total_blocks, const int32_t* blk_entry_dev, umr_stream_t stream);

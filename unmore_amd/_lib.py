@@ -10,6 +10,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, BF16X3 = 0, 1, 2
 EPI_BIAS, EPI_ADD_AUX, EPI_MASK_RELU, EPI_MASK_DGELU, EPI_ADD_AUX2, EPI_OUT_F32, EPI_ROWBIAS, EPI_OUT_X3 = 1, 2, 4, 8, 16, 32, 64, 128
+EPI_AUX_X3, EPI_AUX2_X3, EPI_C2_X3 = 256, 512, 1024
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = 0, 1, 2, 3
 ACT_SIGMOID = 5
 F32_EXACT, F32_X3, F32_X3_FAST = 0, 1, 2   # umr_f32_mode
@@ -40,7 +41,7 @@ class GemmTnDesc(ctypes.Structure):
 
 class PermEntry(ctypes.Structure):   # umr_perm_entry
     _fields_ = [("src", _vp), ("dst", _vp), ("d", _i32 * 4), ("sstride", _i64 * 4), ("soff", _i64), ("dtype_in", _i32), ("dtype_out", _i32),
-                ("blk_start", _i64), ("e", _i32 * 4), ("ord", _i32 * 4)]
+                ("blk_start", _i64), ("e", _i32 * 4), ("ord", _i32 * 4), ("rowlen", _i64)]
 
 
 def build(verbose=False, jobs=8):
@@ -109,6 +110,8 @@ _SIGS = {
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "umr_permute4_batched": [_vp, _i32, _i64, _vp, _vp],
     "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
+    "umr_split3_rows": [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _vp],
+    "umr_gemm_nt_x3_workspace": [_vp],
     "umr_set_f32_mode": [_i32],
     "umr_get_f32_mode": [],
     "umr_version": [],
@@ -137,7 +140,7 @@ def lib():
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
                    "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
-                   "umr_distance_transform_workspace", "umr_gemm_nt_workspace"):
+                   "umr_distance_transform_workspace", "umr_gemm_nt_workspace", "umr_gemm_nt_x3_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

@@ -313,7 +313,21 @@ __global__ void permute4_kernel(const TI* __restrict__ src, TO* __restrict__ dst
 // [ci][ky][kx][co] data-gradient form) read single floats 36 B / 18 KB apart in the linear shape: 11.4 GB of HBM-side traffic
 // per refresh for 0.7 GB of weights (1.7 ms); tiled: see DESIGN.md section 5.
 struct PermEntry { const void* src; void* dst; int32_t d[4]; int64_t sstride[4]; int64_t soff; int32_t dtype_in, dtype_out; int64_t blk_start;
-                   int32_t e[4]; int32_t ord[4]; };
+                   int32_t e[4]; int32_t ord[4]; int64_t rowlen; };
+// destination element di of an entry: f32 / bf16 at dst[di], or -- dtype_out UMR_BF16X3, the weights of the fp32-grade plane GEMMs --
+// the three bf16 planes of the value in row di / rowlen of [rows][h(rowlen) | m(rowlen) | l(rowlen)]
+__device__ __forceinline__ void perm_store(const PermEntry& e, int64_t di, float v) {
+    if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = v;
+    else if (e.dtype_out == UMR_BF16) ((bf16_t*)e.dst)[di] = (bf16_t)v;
+    else {
+        const int64_t row = di / e.rowlen;
+        bf16_t* q = (bf16_t*)e.dst + row * 3 * e.rowlen + (di - row * e.rowlen);
+        const bf16_t h = (bf16_t)v;
+        const float r1 = v - (float)h;
+        const bf16_t m = (bf16_t)r1;
+        q[0] = h; q[e.rowlen] = m; q[2 * e.rowlen] = (bf16_t)(r1 - (float)m);
+    }
+}
 static_assert(sizeof(PermEntry) == sizeof(umr_perm_entry), "umr_perm_entry layout");
 constexpr int PERM_TILE_MAX = 4608;
 constexpr int PERM_LDS_FLOATS = PERM_TILE_MAX;   // tile rows of e[3] floats are padded by one: e[0] e[1] e[2] (e[3] + 1) <= 4608
@@ -348,7 +362,23 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
                     const int o = (j * 256 + threadIdx.x) * 4;
                     const f32x4 v = *(const f32x4*)(sp + o);
                     if (e.dtype_out == UMR_F32) *(f32x4*)((float*)e.dst + base + o) = v;
-                    else { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)((bf16_t*)e.dst + base + o) = t; }
+                    else if (e.dtype_out == UMR_BF16) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *(bf16x4*)((bf16_t*)e.dst + base + o) = t; }
+                    else if ((e.rowlen & 3) == 0) {
+                        const int64_t di = base + o, row = di / e.rowlen;
+                        bf16_t* q = (bf16_t*)e.dst + row * 3 * e.rowlen + (di - row * e.rowlen);
+                        bf16x4 h, m2, l;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const bf16_t hh = (bf16_t)v[c];
+                            const float r1 = v[c] - (float)hh;
+                            const bf16_t mm = (bf16_t)r1;
+                            h[c] = hh; m2[c] = mm; l[c] = (bf16_t)(r1 - (float)mm);
+                        }
+                        *(bf16x4*)q = h; *(bf16x4*)(q + e.rowlen) = m2; *(bf16x4*)(q + 2 * e.rowlen) = l;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) perm_store(e, base + o + c, v[c]);
+                    }
                 }
                 continue;
             }
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
                 const int i0 = (int)(r / e.d[1]);
                 const int64_t si = e.soff + i0 * e.sstride[0] + i1 * e.sstride[1] + i2 * e.sstride[2] + i3 * e.sstride[3];
                 const float v = e.dtype_in == UMR_F32 ? ((const float*)e.src)[si] : (float)((const bf16_t*)e.src)[si];
-                if (e.dtype_out == UMR_F32) ((float*)e.dst)[idx] = v; else ((bf16_t*)e.dst)[idx] = (bf16_t)v;
+                perm_store(e, idx, v);
             }
         }
         return;
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
             if (r0 + rr < R && c0 + cc < C) {
                 const float o = tile[cc * 65 + rr];
                 const int64_t di = (int64_t)(r0 + rr) * C + c0 + cc;
-                if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = o; else ((bf16_t*)e.dst)[di] = (bf16_t)o;
+                perm_store(e, di, o);
             }
         }
         return;
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         if (i0 < e.d[0] && i1 < e.d[1] && i2 < e.d[2] && i3 < e.d[3]) {
             const int64_t di = (((int64_t)i0 * e.d[1] + i1) * e.d[2] + i2) * e.d[3] + i3;
             const float v = tile[((l0 * e.e[1] + l1) * e.e[2] + l2) * (e.e[3] + 1) + l3];
-            if (e.dtype_out == UMR_F32) ((float*)e.dst)[di] = v; else ((bf16_t*)e.dst)[di] = (bf16_t)v;
+            perm_store(e, di, v);
         }
     }
 }
@@ -487,13 +517,14 @@ __global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, in
 // ---------------------------------------------------------------- f32 -> three bf16 planes per row (UMR_BF16X3 operands)
 // one thread = 4 consecutive k of one row: 16 B read, 3 x 8 B written (a wave covers 256 consecutive k: 1 KiB read, 3 x 512 B written)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int K,
-                                                     int64_t ld_src, int64_t ld_dst) {
+                                                     int64_t ld_src, int64_t ld_dst, int rows_in, int rows_out, int row_off) {
     const int k4 = K >> 2;
     const int64_t total = rows * k4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / k4;
         const int k = (int)(i - r * k4) * 4;
-        const f32x4 x = *(const f32x4*)(src + r * ld_src + k);
+        const int64_t rs = rows_in > 0 ? (r / rows_in) * rows_out + row_off + (r % rows_in) : r;   // gather of source rows (token rows without the class tokens)
+        const f32x4 x = *(const f32x4*)(src + rs * ld_src + k);
         bf16x4 h, m, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1030,13 +1061,18 @@ extern "C" int umr_cast(const void* src, void* dst, int64_t n, float scale, int 
     return UMR_OK;
 }
 
-extern "C" int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream) {
-    UMR_CHECK_ARG(src && dst && rows > 0 && K > 0 && K % 4 == 0 && ld_src >= K && ld_src % 4 == 0 && ld_dst >= 3 * (int64_t)K && ld_dst % 4 == 0,
+extern "C" int umr_split3_rows(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, int rows_in, int rows_out,
+                               int row_off, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && rows > 0 && K > 0 && K % 4 == 0 && ld_src >= K && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_dst >= 3 * (int64_t)K && rows_in >= 0,
                   "split3: bad arguments (K, ld_src, ld_dst multiples of 4; ld_dst >= 3K)");
     hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (K / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K,
-                       ld_src, ld_dst);
+                       ld_src, ld_dst, rows_in, rows_out, row_off);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
+}
+
+extern "C" int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream) {
+    return umr_split3_rows(src, dst, rows, K, ld_src, ld_dst, 0, 0, 0, stream);
 }
 
 extern "C" int umr_head_out_fwd(const void* h, const float* w, const float* bias, float* out, int64_t M, int K, int Cout, int HW, int act,

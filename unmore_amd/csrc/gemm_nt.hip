@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip
+int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
 int umr_launch_gemm_nt128w(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt128w.hip (two workgroups per CU, short K)
 bool umr_nt128w_eligible(const umr_gemm_desc* d);
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
@@ -542,31 +543,42 @@ static void launch_nt(dim3 g, hipStream_t s, const umr_gemm_desc* d, int tiles_n
 }
 
 static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream) {
-    (void)workspace_bytes;
     UMR_CHECK_ARG(d != nullptr, "gemm_nt: null descriptor");
     UMR_CHECK_ARG(d->A && d->B && (d->C || d->no_store), "gemm_nt: null operand");
     UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_nt: empty problem");
     if (d->dtype == UMR_BF16X3) {
         // f32 values as three bf16 planes: persistent 256x256 kernel only (include/umr.h)
         UMR_CHECK_ARG(d->conv == 0 || d->conv == 1, "gemm_nt (BF16X3): plain GEMM or stride-1 3x3 conv only");
-        const bool out_f32 = (d->flags & UMR_EPI_OUT_F32) != 0, out_x3 = (d->flags & UMR_EPI_OUT_X3) != 0;
+        const int fl = d->flags;
+        const bool out_f32 = (fl & UMR_EPI_OUT_F32) != 0, out_x3 = (fl & UMR_EPI_OUT_X3) != 0;
         const int kk = d->conv == 0 ? d->K : d->Cin;
         const bool red = d->red_w != nullptr;   // fused row reduction: inference form only (C is not stored), plain GEMM
-        const bool out_ok = red ? (d->no_store && !out_f32 && !out_x3 && d->conv == 0 && d->red_out && (d->red_c == 1 || d->red_c == 2))
-                                : (!d->no_store && d->C && (out_f32 != out_x3) &&
-                                   (out_x3 ? (d->ldc % 8 == 0 && d->ldc >= 3 * (int64_t)d->N) : (d->ldc % 4 == 0)));
-        const bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && out_ok && d->c2_mode == 0 &&
-                        d->a_rows_in <= 0 && d->c_rows_in <= 0 && d->aux_mod <= 0 &&
-                        !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3 | UMR_EPI_MASK_RELU)) && (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU) &&
-                        (!(d->flags & UMR_EPI_MASK_RELU) || (d->aux && !red && d->ldaux % 4 == 0 && d->ldaux >= d->N)) &&
-                        (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) &&
-                        (d->conv == 1 ? (d->K == 9 * d->Cin && (int64_t)d->nb * d->Ho * d->Wo == d->M && d->Ho == d->H && d->Wo == d->W)
-                                      : (d->lda % 8 == 0 && d->lda >= 3 * (int64_t)d->K));
-        if (!ok) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt (BF16X3): needs K (conv: Cin) % 64 == 0, N % 8 == 0, bias / ReLU epilogue, "
-                                                           "exactly one of OUT_F32 / OUT_X3 (or red_w with no_store), no aux / remap / C2 (include/umr.h)");
-        UMR_CHECK_ARG(!(d->flags & UMR_EPI_BIAS) || d->bias, "gemm_nt: bias flag without pointer");
-        UMR_CHECK_ARG((int64_t)((d->M + 255) / 256) * ((d->N + 255) / 256) < (1ll << 31), "gemm_nt: grid too large");
-        return umr_launch_gemm_nt256p(d, (hipStream_t)stream);
+        const int n_aux = ((fl & UMR_EPI_ADD_AUX) != 0) + ((fl & UMR_EPI_MASK_RELU) != 0) + ((fl & UMR_EPI_MASK_DGELU) != 0);
+        auto ld_ok = [&](int64_t ld, bool planes) { return planes ? (ld % 8 == 0 && ld >= 3 * (int64_t)d->N) : (ld % 4 == 0 && ld >= d->N); };
+        bool ok = (kk % 64 == 0) && (d->N % 8 == 0) && d->a_rows_in <= 0 && (d->ldb % 8 == 0) && (d->ldb >= 3 * (int64_t)d->K) &&
+                  (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU || d->act == UMR_ACT_GELU) && n_aux <= 1 &&
+                  (!(fl & UMR_EPI_MASK_DGELU) || (d->act == UMR_ACT_NONE && d->c2_mode == 0 && !(fl & UMR_EPI_ADD_AUX2))) &&
+                  (d->conv == 1 ? (d->K == 9 * d->Cin && (int64_t)d->nb * d->Ho * d->Wo == d->M && d->Ho == d->H && d->Wo == d->W && d->c_rows_in <= 0)
+                                : (d->lda % 8 == 0 && d->lda >= 3 * (int64_t)d->K));
+        if (red) {
+            ok = ok && d->no_store && !out_f32 && !out_x3 && d->conv == 0 && d->red_out && (d->red_c == 1 || d->red_c == 2) && d->c2_mode == 0 &&
+                 !(fl & ~UMR_EPI_BIAS) && d->act != UMR_ACT_GELU && d->c_rows_in <= 0 && d->aux_mod <= 0;
+        } else {
+            ok = ok && !d->no_store && d->C && (out_f32 != out_x3) && ld_ok(d->ldc, out_x3) &&
+                 (d->c2_mode == 0 || ((d->c2_mode == 1 || d->c2_mode == 2) && d->C2 && ld_ok(d->ldc2, (fl & UMR_EPI_C2_X3) != 0))) &&
+                 (n_aux == 0 || (d->aux && ld_ok(d->ldaux, (fl & UMR_EPI_AUX_X3) != 0))) &&
+                 (!(fl & UMR_EPI_ADD_AUX2) || (d->aux2 && ld_ok(d->ldaux2, (fl & UMR_EPI_AUX2_X3) != 0))) &&
+                 (!(fl & UMR_EPI_ROWBIAS) || (d->rowbias && d->rows_per_batch > 0)) && (d->aux_mod <= 0 || n_aux == 1);
+        }
+        if (!ok) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt (BF16X3): needs K (conv: Cin) % 64 == 0, N % 8 == 0, no A-row remap, act in {none, ReLU, GELU}, "
+                                                           "exactly one of OUT_F32 / OUT_X3 (or red_w with no_store and a bias / ReLU epilogue), strides that "
+                                                           "fit the operand formats (include/umr.h)");
+        UMR_CHECK_ARG(!(fl & UMR_EPI_BIAS) || d->bias, "gemm_nt: bias flag without pointer");
+        UMR_CHECK_ARG((int64_t)((d->M + 191) / 192) * ((d->N + 255) / 256) * 32 < (1ll << 31), "gemm_nt: grid too large");
+        // the split-K slabs lie behind the 16 KiB of tile counters of the 128x128 kernel's split-K
+        char* xws = workspace ? (char*)workspace + (int64_t)UMR_SPLITK_COUNTERS * 4 : nullptr;
+        const int64_t xws_bytes = workspace ? workspace_bytes - (int64_t)UMR_SPLITK_COUNTERS * 4 : 0;
+        return umr_launch_gemm_nt256p_ws(d, xws, xws_bytes, (hipStream_t)stream);
     }
     UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16, "gemm_nt: dtype");
     const int epc = d->dtype == UMR_BF16 ? 8 : 4;

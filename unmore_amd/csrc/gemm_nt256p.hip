@@ -76,13 +76,16 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
 // products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
 template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false>
-__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm, int npairs = 6) {
-    // bm: output rows per tile, 256 | 224 | 192 (plain GEMMs only).  A persistent grid of G workgroups needs ceil(tiles / G) tile
-    // times however full the last round is: the transformer GEMMs at 36,928 tokens have 435 (N = 768) or 1305 (N = 2304) tiles of
-    // 256 rows for 256 CUs -- 2 resp. 6 rounds of which the last is 70 % / 10 % full.  With 224-row tiles they have 495 / 1485 tiles:
-    // the same number of rounds, each 1/8 shorter (the host picks bm, umr_launch_gemm_nt256p).  Rows >= bm of a tile are outside
-    // the A descriptor (zero-filled by the DMA), their MFMAs are skipped by the waves that own them and their stores masked.
-    static_assert(X3 == (EPI == 5), "the plane-pair K loop and the f32 / plane epilogue (EPI 5) go together");
+__global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm, int npairs = 6,
+                                                             int kt_per_arg = 0) {
+    // X3 only -- split-K along gridDim.y: the K range of every output tile is cut into gridDim.y contiguous runs of `kt_per_arg`
+    // K-tiles; the workgroups of grid row sp walk the tiles as usual, but only run sp of each, and store their raw f32 accumulators
+    // to slab sp (p.C = the slab array [gridDim.y][M][ldc], plain f32 store, no bias); x3_splitk_finish_kernel adds the slabs in
+    // order and runs the real epilogue.  The transformer's GEMMs of the reference recipe (1300 tokens: 24-96 tiles of 96-384
+    // plane-pair steps) and the DPT convolutions on 4x4 ... 64x64 maps (5-320 tiles of 216+ steps) leave most CUs idle otherwise.
+    // The run is a constant of the workgroup: the persistent loop itself is unchanged.
+    const int sp = (X3 && kt_per_arg > 0) ? (int)blockIdx.y : 0;
+    static_assert(X3 == (EPI == 5 || EPI == 6), "the plane-pair K loop and the f32 / plane epilogues (EPI 5, 6) go together");
     constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
@@ -148,7 +151,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 
     const int ktiles_per_tap = (CONV == 0) ? 0 : p.Cin / BK2;
     // X3: npairs = 6 (fp32-grade) or 3 (UMR_F32_X3_FAST: only (m,h) (h,m) (h,h), products to 2^-16)
-    const int nt = ((CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap) * (X3 ? npairs : 1);   // K % 64 == 0 guaranteed by the dispatcher
+    const int kt_total = (CONV == 0) ? p.K / BK2 : 9 * ktiles_per_tap;   // K % 64 == 0 guaranteed by the dispatcher
+    const int kb = sp * kt_per_arg;                                      // first K-tile of this workgroup's run (0 without a split)
+    const int kt_mine = (X3 && kt_per_arg > 0) ? ((kt_total - kb < kt_per_arg) ? kt_total - kb : kt_per_arg) : kt_total;
+    // X3: npairs = 6 (fp32-grade) or 3 (UMR_F32_X3_FAST: only (m,h) (h,m) (h,h), products to 2^-16)
+    const int nt = kt_mine * (X3 ? npairs : 1);
 
     // ---- staging side state
     __amdgpu_buffer_rsrc_t rsA, rsB;
@@ -162,6 +169,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
         const int v = live ? it * G + pw : 0;
         const int tm = v / tiles_n, tn = v - tm * tiles_n;
         const int m0 = tm * bm, n0 = tn * BN2;
+        // the cursor starts at the first K-tile of the workgroup's run (conv K order: channel chunk major, tap minor)
+        st_tile = 0; st_pp = 0; st_k = kb;
+        st_ci = (CONV == 0) ? 0 : kb / 9; st_tap = (CONV == 0) ? 0 : kb - st_ci * 9;
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.B + (int64_t)n0 * p.ldb * SZ), 0,
                                                 live ? clamp31((int64_t)(p.N - n0) * p.ldb * SZ) : 0, 0x00020000);
         if (CONV == 0) {
@@ -191,7 +201,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // called when group 0 (A0) of a new K-tile is about to be issued
     auto stage_prep = [&]() {
         if (st_tile == nt) {   // roll over into the next output tile of this workgroup
-            st_tile = 0; st_tap = 0; st_ci = 0; st_pp = 0; st_k = 0;
             ++s_it;
             stage_setup(s_it);
         }
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // fetched at the start of each epilogue (first tile: here): a load issued where it is needed would be waited for at once,
     // and vmcnt retires in order -- that wait drained the next tile's prefetched K-tiles (~1900 cycles per tile, measured
     // with s_memtime stamps).  Fetched there, everything issued before it has long landed when the epilogue ends.
-    constexpr bool BIAS_INIT = (EPI == 3 || EPI == 4 || EPI == 5);
+    constexpr bool BIAS_INIT = (EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6);
     f32x4 bqn[4];
     auto fetch_bias = [&](int it_) {
         const int v_ = it_ * G + pw;
@@ -752,15 +761,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             pass4(std::integral_constant<int, 0>{}); pass4(std::integral_constant<int, 1>{});
             pass4(std::integral_constant<int, 2>{}); pass4(std::integral_constant<int, 3>{});
             __syncthreads();
-        } else if (EPI == 5) {
-            // X3 class: (bias already in the accumulators), ReLU, output either as f32 rows (UMR_EPI_OUT_F32) or again as three
-            // bf16 planes [h(N) | m(N) | l(N)] per row (UMR_EPI_OUT_X3: lossless for f32 values, and what the next X3 layer
-            // stages directly).  f32-staged, 8 passes of 32 rows in a runtime loop (one copy of the store code): the K loop is
-            // six times longer than the bf16 kernel's, the epilogue's share is small.
+        } else if (EPI == 5 || EPI == 6) {
+            // X3 classes: (bias already in the accumulators); f32-staged, 8 passes of 32 rows in a runtime loop (one copy of the
+            // store code): the K loop is six times longer than the bf16 kernel's, the epilogue's share is small.
+            // EPI 5 (the head layers, every K-split work item): ReLU, optional ReLU mask (f32 tensor or the leading plane of a plane
+            // tensor), output either as f32 rows (UMR_EPI_OUT_F32) or again as three bf16 planes [h(N) | m(N) | l(N)] per row
+            // (UMR_EPI_OUT_X3: lossless for f32 values, and what the next X3 layer stages directly).
+            // EPI 6: everything else of include/umr.h (x3_epilogue_store8) in its own instantiation -- inlined into the lean
+            // class it doubled the kernel's code and cost the head conv 7 % (I-cache, register pressure around the K loop).
             fetch_bias(it + 1);
             const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
             const bool planes = (p.flags & UMR_EPI_OUT_X3) != 0;
             const bool maskf = (p.flags & UMR_EPI_MASK_RELU) != 0;
+            const bool maskp = (p.flags & UMR_EPI_AUX_X3) != 0;
             if (RED) {
                 // fused output layer (1024 -> {1,2}) of a head at inference: dot products of the f32 values with the reduction
                 // weights (brought into the staging region by LDS-DMA at the start of the tile), C itself is never stored
@@ -807,7 +820,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     default: stage_rows(std::integral_constant<int, 7>{}); break;
                 }
                 __syncthreads();
-#pragma unroll
+                constexpr int UNROLL_J = (EPI == 6) ? 1 : 2;
+#pragma clang loop unroll_count(UNROLL_J)
                 for (int j = 0; j < 2; ++j) {
                     const int lr = (tid >> 5) + j * 16, cg = tid & 31;
                     const int m = m0 + (lr >> 4) * 128 + mt * 16 + (lr & 15), n = n0 + cg * 8;
@@ -815,32 +829,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     const int sw = lr & 15;
                     f32x4 v0 = *(const f32x4*)(stg + lr * 256 + (((2 * cg) ^ sw) << 2));
                     f32x4 v1 = *(const f32x4*)(stg + lr * 256 + (((2 * cg + 1) ^ sw) << 2));
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], relu_floor); v1[e] = fmaxf(v1[e], relu_floor); }
-                    if (maskf) {   // ReLU-masked data gradient: aux = the f32 activation whose sign decides (objectness_net.py:111-115)
-                        const float* ap = (const float*)p.aux + (int64_t)m * p.ldaux + n;
-                        const f32x4 a0 = *(const f32x4*)ap, a1 = *(const f32x4*)(ap + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { v0[e] = a0[e] > 0.f ? v0[e] : 0.f; v1[e] = a1[e] > 0.f ? v1[e] : 0.f; }
-                    }
-                    if (planes) {
-                        bf16x8 h, mm, l;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float x = e < 4 ? v0[e] : v1[e - 4];
-                            const bf16_t hh = (bf16_t)x;
-                            const float r1 = x - (float)hh;
-                            const bf16_t m2 = (bf16_t)r1;
-                            h[e] = hh; mm[e] = m2; l[e] = (bf16_t)(r1 - (float)m2);
-                        }
-                        T2* cp = (T2*)p.C + (int64_t)m * p.ldc + n;
-                        *(bf16x8*)cp = h;
-                        *(bf16x8*)(cp + p.N) = mm;
-                        *(bf16x8*)(cp + 2 * p.N) = l;
+                    if constexpr (EPI == 6) {
+                        x3_epilogue_store8<false>(p, m, n, v0, v1);
                     } else {
-                        float* cp = (float*)p.C + (int64_t)m * p.ldc + n;
-                        *(f32x4*)cp = v0;
-                        *(f32x4*)(cp + 4) = v1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v0[e] = fmaxf(v0[e], relu_floor); v1[e] = fmaxf(v1[e], relu_floor); }
+                        if (maskf) {   // ReLU-masked data gradient: aux = the activation whose sign decides (objectness_net.py:111-115)
+                            f32x4 a0, a1;
+                            if (maskp) {
+                                const bf16x8 h = *(const bf16x8*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
+                                a0 = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                                a1 = f32x4{(float)h[4], (float)h[5], (float)h[6], (float)h[7]};
+                            } else {
+                                const float* ap = (const float*)p.aux + (int64_t)m * p.ldaux + n;
+                                a0 = *(const f32x4*)ap; a1 = *(const f32x4*)(ap + 4);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v0[e] = a0[e] > 0.f ? v0[e] : 0.f; v1[e] = a1[e] > 0.f ? v1[e] : 0.f; }
+                        }
+                        const int64_t mo = m + (int64_t)sp * p.M;   // a split-K workgroup writes its raw sums to slab sp
+                        if (planes) x3_planes_store8((T2*)p.C + mo * p.ldc + n, p.N, v0, v1);
+                        else { float* cp = (float*)p.C + mo * p.ldc + n; *(f32x4*)cp = v0; *(f32x4*)(cp + 4) = v1; }
                     }
                 }
             }
@@ -904,6 +913,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #undef B_FRAG
 }
 
+// second half of a split-K plane GEMM: C = epilogue(sum over the ksplit slabs, in slab order) -- bitwise reproducible, and the
+// one place where bias / aux / activation / output format of such a GEMM are applied (x3_epilogue_store8).
+// One thread = 8 consecutive columns of one row.
+__global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const umr_gemm_desc p, const float* __restrict__ slabs, int ksplit, int64_t slab_stride) {
+    const int n8 = p.N >> 3;
+    const int64_t total = (int64_t)p.M * n8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / n8);
+        const int n = (int)(idx - (int64_t)m * n8) * 8;
+        const float* q = slabs + (int64_t)m * p.N + n;
+        f32x4 v0 = *(const f32x4*)q, v1 = *(const f32x4*)(q + 4);
+        for (int s_ = 1; s_ < ksplit; ++s_) {
+            const float* qs = q + s_ * slab_stride;
+            v0 += *(const f32x4*)qs; v1 += *(const f32x4*)(qs + 4);
+        }
+        x3_epilogue_store8<true>(p, m, n, v0, v1);
+    }
+}
+
 int num_cus() {
     static const int n = [] {
         int dev = 0;
@@ -939,7 +967,43 @@ static bool umr_nt256p_gelu_epilogue(const umr_gemm_desc* d) {
 }
 
 // eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
-int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
+// K-split of a plane GEMM (see the kernel): how many runs.  Cost model in plane-pair steps: a round of work items on the chip takes
+// (steps per item + ~8 for its first loads and its store); splitting adds the slab round trip and the finish launch (~12).
+static int x3_pick_ksplit(const umr_gemm_desc* d, int64_t tiles, int cus, int npairs, int64_t ws_bytes) {
+    if (d->red_w) return 1;
+    const int kt = d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2);
+    static const int forced = umr_env_int("UMR_X3_KSPLIT", 0);   // 0 = cost model; n = at most n runs (1 disables)
+    const int64_t slab = (int64_t)d->M * d->N * 4;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int ks = 1; ks <= 32 && ks * 2 <= kt + 1; ++ks) {
+        if (forced > 0 && ks > forced) break;
+        if (ks > 1 && (int64_t)ks * slab > ws_bytes) break;
+        const int per = (kt + ks - 1) / ks;
+        const int runs = (kt + per - 1) / per;          // no empty run
+        if (runs != ks) continue;
+        const int64_t rounds = (tiles * ks + cus - 1) / cus;
+        const double cost = (double)rounds * (per * npairs + 8) + (ks > 1 ? 12.0 : 0.0);
+        if (cost < best_cost * 0.97) { best_cost = cost; best = ks; }   // a split has to pay for itself
+    }
+    return best;
+}
+
+extern "C" int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d) {
+    if (d == nullptr || d->dtype != UMR_BF16X3 || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
+    const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
+    int ks = 1;
+    for (int bm = 256; bm >= (d->conv == 0 ? 192 : 256); bm -= 32) {   // whichever tile height the launcher picks
+        const int k = x3_pick_ksplit(d, (int64_t)((d->M + bm - 1) / bm) * ((d->N + BN2 - 1) / BN2), num_cus(), npairs, (int64_t)1 << 40);
+        if (k > ks) ks = k;
+    }
+    return ks > 1 ? (int64_t)ks * d->M * d->N * 4 : 0;
+}
+
+int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
+int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) { return umr_launch_gemm_nt256p_ws(d, nullptr, 0, s); }
+
+int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s) {
     const int tiles_n = (d->N + BN2 - 1) / BN2;
     const int cus = num_cus();
     // rows per tile (see the kernel): for plain GEMMs of a few rounds, the bm in {256, 224, 192} with the smallest
@@ -949,7 +1013,7 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     const char* bm_e = getenv("UMR_NT256_BM");   // read per launch: tests switch it inside one process
     const int bm_env = bm_e ? atoi(bm_e) : 0;
     int bm = BM2;
-    if (d->conv == 0 && d->dtype == UMR_BF16) {
+    if (d->conv == 0 && (d->dtype == UMR_BF16 || d->dtype == UMR_BF16X3)) {
         if (bm_env == 256 || bm_env == 224 || bm_env == 192) bm = bm_env;
         else if ((int64_t)((d->M + BM2 - 1) / BM2) * tiles_n <= 16ll * cus) {
             double best = 1e300;
@@ -961,6 +1025,8 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
         }
     }
     const int tiles_m = (d->M + bm - 1) / bm;
+    const int npairs_x3 = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
+    const int ksplit = (d->dtype == UMR_BF16X3 && ws != nullptr) ? x3_pick_ksplit(d, (int64_t)tiles_m * tiles_n, cus, npairs_x3, ws_bytes) : 1;
     const int64_t total = (int64_t)tiles_m * tiles_n;
     // One workgroup fits a CU (160 KiB LDS).  The grid is a small multiple of the CU count, not exactly the CU count: if
     // some CUs are busy when the kernel starts (an RCCL all-reduce of the previous gradient bucket runs beside backward),
@@ -973,9 +1039,10 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     if (kf < 1) kf = 1;
     if (kf > 8) kf = 8;
     int64_t grid64 = cus * kf;
+    if (ksplit > 1) grid64 = (cus + ksplit - 1) / ksplit;   // split-K: gridDim.y = ksplit rows of workgroups, about one workgroup per CU in all
     if (total < grid64) grid64 = total;
     const int grid = (int)grid64;
-    dim3 g((unsigned)grid), b(512);
+    dim3 g((unsigned)grid, (unsigned)ksplit), b(512);
     // fast class = bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
 #define L256P(CV, EP, AX, RD)                                                                                          \
@@ -988,17 +1055,43 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) {
     if ((d->red_w || d->no_store) && !umr_nt256p_plain_epilogue(d))
         return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store needs the fast epilogue class (no aux operand with the reduction)");
     const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
-#define L256PX(CV)                                                                                                     \
+#define L256PX(CV, EP)                                                                                                 \
     do {                                                                                                               \
-        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, 5, 0, false, true>), LDS2P);                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs); \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, 0, false, true>), LDS2P);                                     \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0); \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
-        const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
+        const int npairs = npairs_x3;
         if (d->red_w) {
             UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, true, true>), LDS2P);
-            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs);
-        } else if (d->conv == 0) L256PX(0); else L256PX(1);
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0);
+        } else if (ksplit > 1) {
+            // work items write raw f32 sums to their slab; the finish kernel applies the caller's epilogue
+            umr_gemm_desc sd = *d;
+            sd.C = ws; sd.ldc = d->N; sd.C2 = nullptr; sd.c2_mode = 0; sd.bias = nullptr; sd.aux = nullptr; sd.aux2 = nullptr; sd.rowbias = nullptr;
+            sd.flags = UMR_EPI_OUT_F32; sd.act = UMR_ACT_NONE; sd.c_rows_in = 0; sd.aux_mod = 0;
+            const umr_gemm_desc* dd = &sd;
+            const int kt_all = d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2);
+            const int kt_per = (kt_all + ksplit - 1) / ksplit;
+#define L256PXS(CV)                                                                                                    \
+    do {                                                                                                               \
+        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, 5, 0, false, true>), LDS2P);                                      \
+        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *dd, tiles_n, (int)total, stagger, bm, npairs, kt_per); \
+    } while (0)
+            if (d->conv == 0) L256PXS(0); else L256PXS(1);
+#undef L256PXS
+            UMR_LAUNCH_CHECK();
+            const int64_t tasks = (int64_t)d->M * (d->N >> 3);
+            int64_t fg = (tasks + 255) / 256;
+            if (fg > 8192) fg = 8192;
+            hipLaunchKernelGGL(x3_splitk_finish_kernel, dim3((unsigned)fg), dim3(256), 0, s, *d, (const float*)ws, ksplit, (int64_t)d->M * d->N);
+        } else {
+            // lean class: bias / ReLU / ReLU mask, one output (the head layers); everything else: the generic class
+            const bool lean = !(d->flags & ~(UMR_EPI_BIAS | UMR_EPI_OUT_F32 | UMR_EPI_OUT_X3 | UMR_EPI_MASK_RELU | UMR_EPI_AUX_X3)) && d->c2_mode == 0 &&
+                              d->c_rows_in <= 0 && d->aux_mod <= 0 && d->act != UMR_ACT_GELU;
+            if (d->conv == 0) { if (lean) L256PX(0, 5); else L256PX(0, 6); }
+            else { if (lean) L256PX(1, 5); else L256PX(1, 6); }
+        }
         UMR_LAUNCH_CHECK();
         return UMR_OK;
     }

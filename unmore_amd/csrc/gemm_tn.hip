@@ -464,8 +464,14 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     UMR_CHECK_ARG(d != nullptr, "gemm_tn: null descriptor");
     UMR_CHECK_ARG(d->dY && d->X && d->dW && d->workspace, "gemm_tn: null operand");
     UMR_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, "gemm_tn: empty problem");
-    UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16, "gemm_tn: dtype");
-    const int epc = d->dtype == UMR_BF16 ? 8 : 4;
+    UMR_CHECK_ARG(d->dtype == UMR_F32 || d->dtype == UMR_BF16 || d->dtype == UMR_BF16X3, "gemm_tn: dtype");
+    const int epc = d->dtype == UMR_F32 ? 4 : 8;
+    if (d->dtype == UMR_BF16X3) {
+        // f32 values as three bf16 planes per row (include/umr.h): the 256x256 kernel only
+        if (d->dy_rows_in > 0 || d->x_rows_in > 0 || d->conv == 2)
+            return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_tn (BF16X3): no row remaps, no stride-2 conv");
+        UMR_CHECK_ARG(d->lddy >= 3 * (int64_t)d->N && (d->conv != 0 || d->ldx >= 3 * (int64_t)d->K), "gemm_tn (BF16X3): rows hold three planes (lddy >= 3N, ldx >= 3K)");
+    }
     UMR_CHECK_ARG(d->N % epc == 0 && d->lddy % epc == 0, "gemm_tn: N/lddy must be multiples of 16 bytes");
     UMR_CHECK_ARG(d->conv >= 0 && d->conv <= 2, "gemm_tn: conv mode");
     if (d->conv == 0) {
@@ -477,8 +483,8 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
         UMR_CHECK_ARG(d->Ho == (d->H - 1) / s + 1 && d->Wo == (d->W - 1) / s + 1, "gemm_tn: conv output size");
     }
     {   // paths that address with absolute 32-bit offsets from the tensor base
-        const int rows = d->dtype == UMR_BF16 ? 64 : 32;
-        const int64_t sz = d->dtype == UMR_BF16 ? 2 : 4;
+        const int rows = d->dtype == UMR_F32 ? 32 : 64;
+        const int64_t sz = d->dtype == UMR_F32 ? 4 : 2;
         const bool remap = d->dy_rows_in > 0 || (d->conv == 0 && d->x_rows_in > 0);
         const bool conv_general = d->conv != 0 && !(d->conv == 1 && d->Wo % rows == 0);
         (void)conv_general;  // both conv paths address relative to a per-stage base: no size limit

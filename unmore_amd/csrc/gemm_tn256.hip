@@ -31,11 +31,18 @@ __device__ __forceinline__ int tn_swz2(int r) { return ((r & 3) << 2) | ((r >> 2
 // sub-tile order inside a buffer = staging group order: 0 = Y0, 1 = X0, 2 = X1, 3 = Y1
 // WF (conv only): Wo % 64 == 0 -- a 64-row stage never runs over the end of an image row, so the halo test of a stage is
 // two scalar conditions and a bit test per lane instead of a per-lane pixel walk
-template <int CONV, bool PH2, bool WF>
+// X3 (dtype UMR_BF16X3): both operands are f32 values held as three bf16 planes per row -- dY [M][h(N) | m(N) | l(N)], X
+// [M][h(K) | m(K) | l(K)] (conv: per pixel [h(Cin) | m(Cin) | l(Cin)]) -- and every 64-row stage is walked once per plane pair
+// (h,h) (h,m) (h,l) (m,h) (m,m) (l,h), the six terms of the fp32-grade product (gemm_nt256p.hip): the stage loop is the bf16 loop
+// unchanged, only the staging column offsets differ.  WF: 0 = a stage runs over at most one image-row end (Wo >= 64), 1 = over
+// none (Wo % 64 == 0), 2 = any map size (per-lane pixel arithmetic; the DPT maps of 4x4 ... 32x32).
+template <int CONV, bool PH2, int WF, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_desc p, int tiles_k, int ntiles, int rows_per_split,
-                                                            float* slab, float* bslab, int mapmode) {
+                                                            float* slab, float* bslab, int mapmode, int npairs_arg = 1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
+    const int npairs = X3 ? npairs_arg : 1;
+    const int xpix = X3 ? 3 * p.Cin : p.Cin;          // conv: bf16 elements per input pixel
     constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
                     const int ky = tap / 3, kx = tap - ky * 3;  // offsets ky-1, kx-1 relative to the output pixel
                     x_t[h][i] = ky | (kx << 2);
                     x_bits[h][i] = (1u << ky) | ((r == 0 && kx == 0) ? 8u : 0u) | ((r == 63 && kx == 2) ? 16u : 0u);
-                    v = (unsigned)(((int64_t)(r + ky * p.W + kx) * p.Cin + ci) * SZ);
+                    v = (unsigned)(((int64_t)(r + ky * p.W + kx) * xpix + ci) * SZ);
                 }
             }
             vo[1 + h][i] = v;
@@ -93,11 +100,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
         }
     }
 
-    // ---- stage cursor (groups are issued Y0,X0,X1,Y1 of stage 0, then of stage 1, ...)
-    int st_tile = 0;
+    // ---- stage cursor (groups are issued Y0,X0,X1,Y1 of stage 0 -- X3: of its first plane pair, its second, ... --, then of stage 1, ...)
+    int st_tile = 0;               // 64-row stage of the cursor
+    int st_pp = 0, st_par = 0;     // X3: plane pair within the stage; LDS buffer of the step being issued
     int sb = 0, soy = 0, sox = 0;  // conv: pixel position of the cursor stage's first row
+    const int hw = (CONV != 0) ? p.Ho * p.Wo : 1;
     if (CONV != 0) {
-        const int hw = p.Ho * p.Wo;
         sb = m_begin / hw;
         const int rem = m_begin - sb * hw;
         soy = rem / p.Wo;
@@ -115,16 +123,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     const __amdgpu_buffer_rsrc_t rsX = (CONV == 0)
         ? __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + ((int64_t)m_begin * p.ldx + k0) * SZ), 0,
                                             nrec(((int64_t)rows_split * p.ldx - k0) * SZ), 0x00020000)
-        : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + ((int64_t)m_begin - (p.W + 1)) * p.Cin * SZ), 0,
+        : __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.X + ((int64_t)m_begin - (p.W + 1)) * xpix * SZ), 0,
                                             rows_split > 0 ? 0x7FFFFFFFu : 0u, 0x00020000);   // stride-1 'same' conv: pixel index == row index
-    const unsigned y_step = (unsigned)(64 * p.lddy * SZ), x_step = (unsigned)(64 * (CONV == 0 ? p.ldx : p.Cin) * SZ);
+    const unsigned y_step = (unsigned)(64 * p.lddy * SZ), x_step = (unsigned)(64 * (CONV == 0 ? p.ldx : xpix) * SZ);
     unsigned soffY = 0, soffX = 0;
     auto stage_prep = [&]() {
-        soffY = (unsigned)st_tile * y_step;
-        soffX = (unsigned)st_tile * x_step;
-        if (CONV != 0) {
+        // X3: planes of this step's pair (same order as gemm_nt256p.hip: equal dY planes consecutive)
+        const int pa = X3 ? (((npairs == 6 ? 0x940 : 0x010) >> (2 * st_pp)) & 3) : 0;   // dY planes 0,0,0,1,1,2  |  0,0,1
+        const int pb = X3 ? (((npairs == 6 ? 0x124 : 0x004) >> (2 * st_pp)) & 3) : 0;   // X  planes 0,1,2,0,1,0  |  0,1,0
+        soffY = (unsigned)st_tile * y_step + (unsigned)(pa * p.N * SZ);
+        soffX = (unsigned)st_tile * x_step + (unsigned)(pb * (CONV == 0 ? p.K : p.Cin) * SZ);
+        const bool first_pair = !X3 || st_pp == 0;
+        if (X3) { if (++st_pp == npairs) st_pp = 0; }
+        if (CONV != 0 && first_pair) {     // the halo mask of a stage serves all of its plane pairs
             const int rows_left = rows_split - st_tile * 64;   // may be <= 0 for the cursor's run-ahead stages
-            if (WF) {
+            if (WF == 2) {
+                // any map size: a 64-row stage may cover several image rows and images; addresses are linear in the pixel
+                // index, only the validity of each lane's tap is position dependent
+                const int lin0 = soy * p.Wo + sox;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int ky = x_t[h][i] & 3, kx = x_t[h][i] >> 2;
+                        const int rem = (lin0 + x_r[h][i]) % hw;
+                        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                        const bool ok = (unsigned)(oy + ky - 1) < (unsigned)p.H && (unsigned)(ox + kx - 1) < (unsigned)p.W && x_r[h][i] < rows_left;
+                        x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
+                    }
+                const int lin1 = (lin0 + 64) % hw;
+                soy = lin1 / p.Wo;
+                sox = lin1 - soy * p.Wo;
+            } else if (WF == 1) {
                 // vertical: rows above / below the image (scalar); horizontal: only pixel 0 of the first stage and pixel
                 // Wo-1 of the last stage of an image row can fall outside
                 const unsigned sw = (soy == 0 ? 1u : 0u) | (soy == p.Ho - 1 ? 4u : 0u) | (sox == 0 ? 8u : 0u) | (sox == p.Wo - 64 ? 16u : 0u);
@@ -153,20 +183,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
                         x_eff[h][i] = ok ? vo[1 + h][i] : OOB;
                     }
             }
-            sox += 64;
-            if (sox >= p.Wo) { sox -= p.Wo; if (++soy >= p.Ho) { soy = 0; ++sb; } }
+            if (WF != 2) {
+                sox += 64;
+                if (sox >= p.Wo) { sox -= p.Wo; if (++soy >= p.Ho) { soy = 0; ++sb; } }
+            }
         }
     };
     auto stage_issue = [&](auto gtag, auto itag) {
         constexpr int G = decltype(gtag)::value, I = decltype(itag)::value;
-        char* dst = smem + (st_tile & 1) * TBUF + G * TSUB + (w * 2 + I) * 1024;
+        char* dst = smem + st_par * TBUF + G * TSUB + (w * 2 + I) * 1024;
         if constexpr (G == 0 || G == 3) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, UMR_LDS_PTR(dst), 16, vo[G][I], soffY, 0, 0);
         } else {
             const unsigned v = (CONV == 0) ? vo[G][I] : x_eff[G - 1][I];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, UMR_LDS_PTR(dst), 16, v, soffX, 0, 0);
         }
-        if (G == 3 && I == 1) ++st_tile;
+        if (G == 3 && I == 1) { st_par ^= 1; if (!X3 || st_pp == 0) ++st_tile; }   // (st_pp was advanced by stage_prep: 0 = the stage's last pair)
     };
 #define STAGE_DMA(G, I) stage_issue(std::integral_constant<int, G>{}, std::integral_constant<int, I>{})
 
@@ -321,12 +353,16 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
     __builtin_amdgcn_s_barrier();
 
     int bias_next = tk;   // stages tk, tk + tiles_k, ... carry this workgroup's share of the dbias sums
+    int c_pp = 0, c_m = 0;
+    const int nsteps = nst * npairs;
 #pragma unroll 1
-    for (int t = 0; t < nst; ++t) {
+    for (int t = 0; t < nsteps; ++t) {
         par_off = lds0 + (unsigned)((t & 1) * TBUF);
-        bias_turn = (t == bias_next);
-        if (bias_turn) bias_next += tiles_k;
+        // X3: a stage's column sums are taken once per dY plane -- in the pairs whose X plane is h (0, 3, 5 | 0, 2)
+        const bool sum_pair = !X3 || ((((npairs == 6 ? 0x124 : 0x004) >> (2 * c_pp)) & 3) == 0);
+        bias_turn = (c_m == bias_next) && sum_pair;
         stage_body();
+        if (++c_pp == npairs) { c_pp = 0; if (c_m == bias_next) bias_next += tiles_k; ++c_m; }
     }
 #undef BIAS_ACC
 #undef QUADRANT
@@ -365,9 +401,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 
 // plan shared with gemm_tn.hip through these two helpers
 bool umr_tn256_eligible(const umr_gemm_tn_desc* d, bool force) {
-    if (d->dtype != UMR_BF16) return false;
+    if (d->dtype != UMR_BF16 && d->dtype != UMR_BF16X3) return false;
     if (d->dy_rows_in > 0 || d->x_rows_in > 0) return false;
     if (d->conv == 2) return false;
+    if (d->dtype == UMR_BF16X3) return true;        // the only kernel for plane operands (any map size: WF 2)
     if (d->conv == 1 && d->Wo < 64) return false;   // a 64-row stage may straddle one image-row end, not two
     if (force) return true;  // structurally supported (tails are masked); the rest is a performance heuristic
     if (d->N < 192 || d->K < 192) return false;
@@ -383,19 +420,22 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
     // so few-row problems (the transformer weight gradients: 37 k tokens) want ONE round of long splits -- 4 rounds cost
     // +50 % there (tools/vit_block_bench.py) -- while the pixel-sized ones (>= 64 stages per split even at 4 rounds) keep
     // 4 rounds for the tail balance.
-    int64_t rounds = (int64_t)d->M * tiles / (256ll * 4096);
+    const int x3 = d->dtype == UMR_BF16X3 ? 6 : 1;   // plane pairs: steps per 64-row stage
+    int64_t rounds = (int64_t)d->M * tiles * x3 / (256ll * 4096);
     if (rounds < 1) rounds = 1;
     if (rounds > 4) rounds = 4;
     if (rounds_env > 0) rounds = rounds_env;
     int64_t want = rounds * 256 / tiles;
     if (want < 1) want = 1;
-    const int64_t max_by_rows = ((int64_t)d->M + 64 * 16 - 1) / (64 * 16);
+    const int64_t min_stages = x3 == 6 ? 2 : 16;      // >= 16 (X3: 12) steps per split
+    const int64_t max_by_rows = ((int64_t)d->M + 64 * min_stages - 1) / (64 * min_stages);
     if (want > max_by_rows) want = max_by_rows;
     int64_t rps = ((int64_t)d->M + want - 1) / want;
     rps = (rps + 63) / 64 * 64;
     {   // the kernel addresses a split with 32-bit offsets from its first row
-        const int64_t rowb = 2 * (int64_t)(d->conv ? (d->Cin > d->lddy ? d->Cin : d->lddy) : (d->ldx > d->lddy ? d->ldx : d->lddy));
-        const int64_t halo = d->conv ? (2 * (int64_t)d->W + 4) * d->Cin * 2 : 0;
+        const int64_t cpix = (int64_t)d->Cin * (d->dtype == UMR_BF16X3 ? 3 : 1);
+        const int64_t rowb = 2 * (int64_t)(d->conv ? (cpix > d->lddy ? cpix : d->lddy) : (d->ldx > d->lddy ? d->ldx : d->lddy));
+        const int64_t halo = d->conv ? (2 * (int64_t)d->W + 4) * cpix * 2 : 0;
         int64_t cap = ((1ll << 31) - halo - 65536) / rowb / 64 * 64;
         if (cap < 64) cap = 64;
         if (rps > cap) rps = cap;
@@ -413,12 +453,24 @@ int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_sp
     do {                                                                                                               \
         UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, false, WFV>), TLDS); \
         UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, true, WFV>), TLDS);                                                                                                              \
-        if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode); \
-        else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode);   \
+        if (ph2) hipLaunchKernelGGL((gemm_tn256_kernel<CV, true, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode, 1); \
+        else hipLaunchKernelGGL((gemm_tn256_kernel<CV, false, WFV>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode, 1);   \
     } while (0)
-    if (d->conv == 0) LT(0, false);
-    else if (d->Wo % 64 == 0) LT(1, true);
-    else LT(1, false);
+#define LTX(CV, WFV)                                                                                                   \
+    do {                                                                                                               \
+        UMR_SET_MAX_LDS_ONCE((gemm_tn256_kernel<CV, true, WFV, true>), TLDS);                                          \
+        hipLaunchKernelGGL((gemm_tn256_kernel<CV, true, WFV, true>), g, b, TLDS, s, *d, tiles_k, tiles_n * tiles_k, rows_per_split, slab, bslab, mapmode, npairs); \
+    } while (0)
+    if (d->dtype == UMR_BF16X3) {
+        const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
+        if (d->conv == 0) LTX(0, 0);
+        else if (d->Wo % 64 == 0) LTX(1, 1);
+        else if (d->Wo >= 64) LTX(1, 0);
+        else LTX(1, 2);
+    } else if (d->conv == 0) LT(0, 0);
+    else if (d->Wo % 64 == 0) LT(1, 1);
+    else LT(1, 0);
+#undef LTX
 #undef LT
     UMR_LAUNCH_CHECK();
     return UMR_OK;

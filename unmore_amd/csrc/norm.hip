@@ -8,7 +8,9 @@ namespace {
 
 constexpr int LN_MAXV = 8;  // up to 8 x 4 elements per lane -> D <= 2048
 
-template <typename T>
+// PLANES (T = float): y is written as three bf16 planes per row [h(D) | m(D) | l(D)] (UMR_BF16X3, include/umr.h) -- the operand
+// format of the fp32-grade plane GEMMs; the normalised rows feed only GEMMs (qkv / fc1 and their weight gradients)
+template <typename T, bool PLANES = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
@@ -41,7 +43,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             const f32x4 g = *(const f32x4*)(gamma + c * 4), b = *(const f32x4*)(beta + c * 4);
             f32x4 o;
             for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
-            Vec4<T>::store(yr + c * 4, o);
+            if constexpr (PLANES) {
+                bf16x4 h, m2, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16_t hh = (bf16_t)o[j];
+                    const float r1 = o[j] - (float)hh;
+                    const bf16_t mm = (bf16_t)r1;
+                    h[j] = hh; m2[j] = mm; l[j] = (bf16_t)(r1 - (float)mm);
+                }
+                bf16_t* yp = (bf16_t*)y + (int64_t)row * 3 * D + c * 4;
+                *(bf16x4*)yp = h; *(bf16x4*)(yp + D) = m2; *(bf16x4*)(yp + 2 * D) = l;
+            } else {
+                Vec4<T>::store(yr + c * 4, o);
+            }
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
@@ -347,6 +362,7 @@ extern "C" int umr_layernorm_fwd(const void* x, const float* gamma, const float*
         hipLaunchKernelGGL(ln_fwd_bf16x8_kernel<4>, dim3((M + 7) / 8), b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
     else if (dtype == UMR_BF16) hipLaunchKernelGGL(ln_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps);
     else if (dtype == UMR_F32) hipLaunchKernelGGL(ln_fwd_kernel<float>, g, b, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
+    else if (dtype == UMR_BF16X3) hipLaunchKernelGGL((ln_fwd_kernel<float, true>), g, b, 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, M, D, eps);
     else return umr_set_error(UMR_ERR_INVALID, "layernorm_fwd: dtype");
     UMR_LAUNCH_CHECK();
     return UMR_OK;

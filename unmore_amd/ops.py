@@ -181,24 +181,76 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     return (out, out2) if c2_mode else out
 
 
-def split3(x, out=None):
-    """f32 [..., K] (rows contiguous) -> bf16 planes [..., 3K] = [h(K) | m(K) | l(K)] per row (include/umr.h, UMR_BF16X3)."""
+def split3(x, out=None, remap=None):
+    """f32 [..., K] (rows contiguous) -> bf16 planes [..., 3K] = [h(K) | m(K) | l(K)] per row (include/umr.h, UMR_BF16X3).
+    remap = (rows_in, rows_out, row_off) with a 2-D x: output row r is source row (r // rows_in) * rows_out + row_off + r % rows_in
+    (the token rows without the class-token rows), rows = x.shape[0] // rows_out * rows_in."""
     _need_gpu(x)
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     K = x.shape[-1]
     x2 = x.reshape(-1, K) if x.is_contiguous() else x
     assert x2.dim() == 2
     rows = x2.shape[0]
+    ri, ro, off = (0, 0, 0)
+    if remap is not None:
+        ri, ro, off = remap
+        assert rows % ro == 0 and off + ri <= ro
+        rows = rows // ro * ri
+        if out is None:
+            out = torch.empty((rows, 3 * K), dtype=torch.bfloat16, device=x.device)
     if out is None:
         out = torch.empty(x.shape[:-1] + (3 * K,), dtype=torch.bfloat16, device=x.device)
-    L.check(L.lib().umr_split3(_p(x2), _p(out), rows, K, x2.stride(0), 3 * K, _stream()), "umr_split3")
+    L.check(L.lib().umr_split3_rows(_p(x2), _p(out), rows, K, x2.stride(0), 3 * K, ri, ro, off, _stream()), "umr_split3")
     return out
 
 
-def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, red_w=None, mask=None):
-    """fp32-grade C = act(A . B^T + bias) from operands held as three bf16 planes per f32 value (split3): Ap [M, 3K] (or NHWC
-    [nb,H,W,3*Cin] when conv == 1), Bp [N, 3K].  Returns f32 [M, N], or planes [M, 3N] bf16 with out_planes=True (what the next
-    gemm_nt_x3 layer takes).  Persistent 256x256 bf16 kernel, six plane pairs per K-tile (csrc/gemm_nt256p.hip, X3)."""
+def _x3_operand(t, N):
+    """(pointer, row stride, is_planes) of an [M, N] epilogue operand given as f32 [M, N] or as bf16 planes [M, 3N]"""
+    if t.dtype == torch.bfloat16:
+        t2 = t.reshape(-1, 3 * N)
+        assert t2.stride(1) == 1
+        return t2, t2.stride(0), True
+    assert t.dtype == torch.float32
+    t2 = t.reshape(-1, N)
+    assert t2.stride(1) == 1
+    return t2, t2.stride(0), False
+
+
+_x3_ws_cache = collections.OrderedDict()
+
+
+def _x3_workspace(d, device):
+    """split-K scratch of a plane GEMM: the 128x128 kernel's counters + slabs (umr_gemm_nt_workspace) followed by this problem's
+    K-split slabs; one grow-only buffer per (device, stream), private to a capture in progress"""
+    extra = int(L.lib().umr_gemm_nt_x3_workspace(ctypes.byref(d)))
+    if extra == 0:
+        return None
+    need = int(L.lib().umr_gemm_nt_workspace()) + extra
+    if graphs.capturing():
+        store = graphs.capture_store()
+        buf = store.get("x3ws")
+        if buf is None or buf.numel() < need:
+            buf = store["x3ws"] = torch.empty(need, dtype=torch.uint8, device=device)
+        return buf
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _x3_ws_cache.pop(key, None)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
+    _x3_ws_cache[key] = buf
+    while len(_x3_ws_cache) > _WS_MAX_ENTRIES:
+        _x3_ws_cache.pop(next(iter(_x3_ws_cache)))
+    return buf
+
+
+def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, out=None, red_w=None, mask=None, dgelu=None, aux=None,
+               aux2=None, rowbias=None, rows_per_batch=0, c2_mode=0, c2_planes=False, c_remap=None, aux_mod=0):
+    """fp32-grade C = epi(A . B^T) from operands held as three bf16 planes per f32 value (split3): Ap [M, 3K] (or NHWC
+    [nb,H,W,3*Cin] when conv == 1), Bp [N, 3K].  Persistent 256x256 bf16 kernel, six plane pairs per K-tile (csrc/gemm_nt256p.hip,
+    X3), split along K for small problems.  Epilogue as umr_gemm_desc (include/umr.h), all in f32: bias, rowbias, ONE of
+    mask (keep where > 0) / dgelu (times GELU'(.)) / aux (add), aux2 (add), c2_mode 1 (second output = relu) / 2 (second output =
+    pre-activation), act.  Every [M, N] operand may be f32 [M, N] or planes [M, 3N] (told apart by dtype); C is f32, or planes
+    with out_planes=True; the second output is planes with c2_planes=True.  Returns C, or (C, C2), or the row-reduction
+    partials [ceil(N/64), M, c] with red_w (inference form: C is not stored)."""
     _need_gpu(Ap, Bp)
     assert Ap.dtype == torch.bfloat16 and Bp.dtype == torch.bfloat16 and Bp.dim() == 2 and Bp.is_contiguous()
     d = L.GemmDesc()
@@ -216,57 +268,92 @@ def gemm_nt_x3(Ap, Bp, bias=None, *, act=L.ACT_NONE, conv=0, out_planes=False, r
         assert A2.stride(1) == 1 and A2.shape[1] == 3 * K
         M_ = A2.shape[0]
         d.lda = A2.stride(0)
-    partials = None
+    rows_out = M_
+    if c_remap is not None:
+        d.c_rows_in, d.c_rows_out, d.c_row_off = c_remap
+        rows_out = None   # the caller supplies `out`
+    partials, out2 = None, None
+    flags = 0
     if red_w is not None:
         # fused row reduction (the 1024 -> {1,2} output layer of a head): returns partials [ceil(N/64), M, c] for head_out_finish
         assert red_w.dtype == torch.float32 and red_w.is_contiguous() and red_w.shape[1] == N and red_w.shape[0] in (1, 2) and not conv
         partials = torch.empty(((N + 63) // 64, M_, red_w.shape[0]), dtype=torch.float32, device=Ap.device)
         d.red_w, d.red_out, d.red_c, d.no_store = _p(red_w), _p(partials), red_w.shape[0], 1
-        out, flags = None, 0
-    elif out_planes:
-        out = torch.empty((M_, 3 * N), dtype=torch.bfloat16, device=Ap.device)
-        flags = L.EPI_OUT_X3
+        out = None
     else:
-        out = torch.empty((M_, N), dtype=torch.float32, device=Ap.device)
-        flags = L.EPI_OUT_F32
+        if out is None:
+            assert rows_out is not None
+            out = torch.empty((rows_out, 3 * N if out_planes else N), dtype=torch.bfloat16 if out_planes else torch.float32, device=Ap.device)
+        else:
+            out_planes = out.dtype == torch.bfloat16
+        flags |= L.EPI_OUT_X3 if out_planes else L.EPI_OUT_F32
+        o2 = out if out.dim() == 2 else out.reshape(-1, out.shape[-1])
+        assert o2.stride(1) == 1 and o2.shape[1] == (3 * N if out_planes else N)
+        d.ldc = o2.stride(0)
     if bias is not None:
         assert bias.dtype == torch.float32
         flags |= L.EPI_BIAS
-    if mask is not None:   # ReLU-masked data gradient: keep the result where the f32 tensor `mask` [M, N] is > 0
-        m2 = mask.reshape(-1, N)
-        assert mask.dtype == torch.float32 and m2.stride(1) == 1 and m2.shape[0] == M_ and red_w is None
-        flags |= L.EPI_MASK_RELU
-        d.aux, d.ldaux = _p(m2), m2.stride(0)
+    if rowbias is not None:
+        assert rowbias.dtype == torch.float32 and rowbias.is_contiguous() and rows_per_batch > 0
+        flags |= L.EPI_ROWBIAS
+        d.rowbias, d.rows_per_batch = _p(rowbias), rows_per_batch
+    a_t, a_flag = None, 0
+    for t, fl in ((mask, L.EPI_MASK_RELU), (dgelu, L.EPI_MASK_DGELU), (aux, L.EPI_ADD_AUX)):
+        if t is not None:
+            assert a_t is None, "one of mask / dgelu / aux"
+            a_t, a_flag = t, fl
+    keep = []
+    if a_t is not None:
+        t2, ld, pl = _x3_operand(a_t, N)
+        flags |= a_flag | (L.EPI_AUX_X3 if pl else 0)
+        d.aux, d.ldaux = _p(t2), ld
+        keep.append(t2)
+    if aux2 is not None:
+        t2, ld, pl = _x3_operand(aux2, N)
+        flags |= L.EPI_ADD_AUX2 | (L.EPI_AUX2_X3 if pl else 0)
+        d.aux2, d.ldaux2 = _p(t2), ld
+        keep.append(t2)
+    if c2_mode:
+        assert red_w is None and c_remap is None
+        out2 = torch.empty((M_, 3 * N if c2_planes else N), dtype=torch.bfloat16 if c2_planes else torch.float32, device=Ap.device)
+        flags |= L.EPI_C2_X3 if c2_planes else 0
+        d.C2, d.ldc2, d.c2_mode = _p(out2), out2.stride(0), c2_mode
+    d.aux_mod = aux_mod
     d.A, d.B, d.C, d.bias = _p(Ap), _p(Bp), _p(out), _p(bias)
-    d.ldb, d.ldc = Bp.stride(0), (out.stride(0) if out is not None else N)
+    d.ldb = Bp.stride(0)
     d.M, d.N, d.K, d.dtype = M_, N, K, L.BF16X3
     d.flags, d.act, d.conv = flags, act, conv
     L.check(_timed_call(d), "umr_gemm_nt")
-    return partials if red_w is not None else out
+    if red_w is not None:
+        return partials
+    return (out, out2) if c2_mode else out
 
 
-def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_remap=None, x_remap=None, lddy=None, ldx=None):
+def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_remap=None, x_remap=None, lddy=None, ldx=None, x3=False):
     """dW[N,K] f32 = sum_m dY[m,N]^T X[m,K]; X is NHWC [nb,H,W,Cin] when conv != 0
-    (dY then is [nb*Ho*Wo, N] and dW is [N, 9*Cin] packed (ky,kx,ci))."""
+    (dY then is [nb*Ho*Wo, N] and dW is [N, 9*Cin] packed (ky,kx,ci)).
+    x3=True: both operands are f32 values as bf16 planes (split3): dY [M, 3N], X [M, 3K] / NHWC [nb,H,W,3*Cin] -- fp32-grade."""
     _need_gpu(dY, X)
-    dt = _DT[X.dtype]
-    assert dY.dtype == X.dtype
+    dt = L.BF16X3 if x3 else _DT[X.dtype]
+    assert dY.dtype == X.dtype and (not x3 or X.dtype == torch.bfloat16)
+    pl = 3 if x3 else 1
     d = L.GemmTnDesc()
     dY2 = dY.reshape(-1, dY.shape[-1]) if dY.is_contiguous() else dY
-    N = dY2.shape[-1]
+    N = dY2.shape[-1] // pl
     M = dY2.shape[0] if M is None else M
     if conv:
         nb, H, W, Cin = X.shape
+        Cin //= pl
         assert X.is_contiguous()
         s = 2 if conv == 2 else 1
         Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
         assert M == nb * Ho * Wo
         K = 9 * Cin
         d.nb, d.H, d.W, d.Cin, d.Ho, d.Wo = nb, H, W, Cin, Ho, Wo
-        d.ldx = Cin
+        d.ldx = Cin * pl
     else:
         X2 = X.reshape(-1, X.shape[-1]) if X.is_contiguous() else X
-        K = X2.shape[-1]
+        K = X2.shape[-1] // pl
         d.ldx = X2.stride(0) if ldx is None else ldx
     if dW is None:
         dW = torch.empty((N, K), dtype=torch.float32, device=X.device)
@@ -288,14 +375,21 @@ def gemm_tn(dY, X, *, dW=None, dbias=None, accumulate=False, conv=0, M=None, dy_
     return dW
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-6):
+def layernorm_fwd(x, gamma, beta, eps=1e-6, planes=False):
+    """planes=True (x f32): the normalised rows are written as bf16 planes [M, 3D] (the operand format of the plane GEMMs)"""
     _need_gpu(x)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     M = x2.shape[0]
-    y = torch.empty_like(x2)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    if planes:
+        assert x.dtype == torch.float32
+        y = torch.empty((M, 3 * D), dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().umr_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, L.BF16X3, _stream()),
+                "umr_layernorm_fwd")
+        return y, mean, rstd
+    y = torch.empty_like(x2)
     L.check(L.lib().umr_layernorm_fwd(_p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), M, D, eps, _DT[x.dtype], _stream()),
             "umr_layernorm_fwd")
     return y.view(x.shape), mean, rstd
@@ -423,12 +517,15 @@ def permute4_batched(recipes):
     arr = (L.PermEntry * n)()
     blk = 0
     counts = []
-    for i, (src, dst, dims, strides, off) in enumerate(recipes):
+    for i, rec in enumerate(recipes):
+        src, dst, dims, strides, off = rec[:5]
+        rowlen = rec[5] if len(rec) > 5 else 0     # > 0: dst holds bf16 PLANES of the f32 values, rows of `rowlen` values
         e = arr[i]
         e.src, e.dst = src.data_ptr(), dst.data_ptr()
         for k in range(4):
             e.d[k], e.sstride[k] = dims[k], strides[k]
-        e.soff, e.dtype_in, e.dtype_out, e.blk_start = off, _DT[src.dtype], _DT[dst.dtype], blk
+        e.soff, e.dtype_in, e.blk_start = off, _DT[src.dtype], blk
+        e.dtype_out, e.rowlen = (L.BF16X3, rowlen) if rowlen else (_DT[dst.dtype], 0)
         tile = _perm_tile(dims, strides)
         if tile is None:
             for k in range(4):
@@ -595,6 +692,11 @@ _raw_gemm_nt_call = None
 
 
 def _gemm_nt_call(d):
+    if d.dtype == L.BF16X3:
+        ws = _x3_workspace(d, torch.device("cuda", torch.cuda.current_device()))
+        if ws is not None:
+            return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
+        return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
     # few 128x128 tiles and a long K: hand the library its split-K scratch (include/umr.h: umr_gemm_nt_ws); the library decides
     if d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32):
         ws = _splitk_workspace(torch.device("cuda", torch.cuda.current_device()))

@@ -133,6 +133,8 @@ int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_by
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
 int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);
+/* the inverse: rows x [h(K) | m(K) | l(K)] bf16 -> rows x K f32, x = (h + m) + l (exact) */
+int umr_unsplit3(const void* src, float* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);
 /* the same with a gather of source rows: destination row r is source row (r / rows_in) * rows_out + row_off + r % rows_in (rows_in
  * == 0: identity) -- the token rows of every image without its class-token row (models/dpt/vit.py:87-88) as a compact operand */
 int umr_split3_rows(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, int rows_in, int rows_out,

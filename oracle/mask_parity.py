@@ -12,6 +12,8 @@ from . import objectness_oracle as orc
 
 
 def _nchw_mask(t, B, H, W):
+    if hasattr(t, "mask_source"):   # the fp32 mode saves activations as bf16 planes: the leading plane has the value's sign
+        t = t.mask_source()
     return (t.reshape(B, H, W, -1) > 0).permute(0, 3, 1, 2).cpu()
 
 

@@ -110,6 +110,7 @@ _SIGS = {
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "umr_permute4_batched": [_vp, _i32, _i64, _vp, _vp],
     "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
+    "umr_unsplit3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "umr_split3_rows": [_vp, _vp, _i64, _i32, _i64, _i64, _i32, _i32, _i32, _vp],
     "umr_gemm_nt_x3_workspace": [_vp],
     "umr_set_f32_mode": [_i32],

@@ -540,6 +540,23 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     }
 }
 
+// planes -> f32: x = (h + m) + l, exact (the inverse of split3 for every value split3 represents)
+__global__ __launch_bounds__(256) void unsplit3_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t rows, int K,
+                                                       int64_t ld_src, int64_t ld_dst) {
+    const int k4 = K >> 2;
+    const int64_t total = rows * k4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / k4;
+        const int k = (int)(i - r * k4) * 4;
+        const bf16_t* q = src + r * ld_src + k;
+        const bf16x4 h = *(const bf16x4*)q, m = *(const bf16x4*)(q + K), l = *(const bf16x4*)(q + 2 * K);
+        f32x4 x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = ((float)h[e] + (float)m[e]) + (float)l[e];
+        *(f32x4*)(dst + r * ld_dst + k) = x;
+    }
+}
+
 // ---------------------------------------------------------------- head output layer: 1024 -> {1,2} (+ activation), NCHW f32 out
 // one wave per pixel row: lanes split K, wave reduction.  out[b][c][hw]
 template <typename T>
@@ -1067,6 +1084,15 @@ extern "C" int umr_split3_rows(const float* src, void* dst, int64_t rows, int K,
                   "split3: bad arguments (K, ld_src, ld_dst multiples of 4; ld_dst >= 3K)");
     hipLaunchKernelGGL(split3_kernel, dim3(grid_for(rows * (K / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, rows, K,
                        ld_src, ld_dst, rows_in, rows_out, row_off);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_unsplit3(const void* src, float* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream) {
+    UMR_CHECK_ARG(src && dst && rows > 0 && K > 0 && K % 4 == 0 && ld_src >= 3 * (int64_t)K && ld_src % 4 == 0 && ld_dst >= K && ld_dst % 4 == 0,
+                  "unsplit3: bad arguments (K, ld_src, ld_dst multiples of 4; ld_src >= 3K)");
+    hipLaunchKernelGGL(unsplit3_kernel, dim3(grid_for(rows * (K / 4), 256, 16384)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, rows, K,
+                       ld_src, ld_dst);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -16,6 +16,7 @@ import torch
 from . import _lib as L
 from . import graphs
 from . import ops
+from .engine_x3 import X3Path
 
 CONFIGS = {
     # reference wiring: models/dpt/models.py:43-47, blocks.py:24-54, vit.py:515-543
@@ -50,7 +51,9 @@ class PackCache:
         self.gen_o = 0
         self._epoch = None     # (event, synced streams) of the last refresh that ran inside a graph replay (graphs.py)
 
-    def get(self, key, param, build):
+    def get(self, key, param, build, recipe_fn=None):
+        """recipe_fn(recorded launches, value) -> replay recipe or None: for packs whose replayable form is not the launch that
+        built them (the bf16-plane weights: built as f32 pack + split, refreshed as one permute straight into planes)"""
         ver = (param._version, param.data_ptr())
         hit = self._c.get(key) or self._o.get(key)
         cap = graphs.capturing()
@@ -82,8 +85,13 @@ class PackCache:
             ops._pack_recorder = prev
         # replayable only if the recorded source IS the parameter's storage: a pack helper that had to make a temporary copy first
         # (reshape of a non-contiguous parameter) would be re-packed from that stale temporary forever
-        recipe = rec[0] if (len(rec) == 1 and torch.is_tensor(val) and rec[0][1].data_ptr() == val.data_ptr()
-                            and rec[0][0].untyped_storage().data_ptr() == param.untyped_storage().data_ptr()) else None
+        if recipe_fn is not None:
+            recipe = recipe_fn(rec, val)
+            if recipe is not None and recipe[0].untyped_storage().data_ptr() != param.untyped_storage().data_ptr():
+                recipe = None
+        else:
+            recipe = rec[0] if (len(rec) == 1 and torch.is_tensor(val) and rec[0][1].data_ptr() == val.data_ptr()
+                                and rec[0][0].untyped_storage().data_ptr() == param.untyped_storage().data_ptr()) else None
         ev = None
         if st is not None and not cap:
             ev = torch.cuda.Event()
@@ -203,6 +211,7 @@ def _rep_bias(b, reps):
 
 _FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch for benchmarking
 _X3_HEADS = os.environ.get("UMR_X3_HEADS", "1") != "0"            # A/B switch: fp32-mode inference heads on the bf16-plane kernel
+_X3_ALL = os.environ.get("UMR_X3_ALL", "1") != "0"            # A/B switch: 0 = fp32 mode as in round 3 (only the heads on the plane kernels)
 _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: one GEMM for the feature-map gradient of both heads
 # Backward of a head without non-linearities between its convs (objectness_net.py:119-142): "algebraic" (default) = exact
 # gradients of all eight factored tensors from three pixel reductions (no 512/1024-channel tensor is stored, read or
@@ -210,7 +219,7 @@ _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: on
 _LINEAR_HEAD_BWD = os.environ.get("UMR_LINEAR_HEAD_BWD", "algebraic")
 
 
-class Engine:
+class Engine(X3Path):
     def __init__(self, cfg, head_layouts, compute_dtype=torch.float32, collapse_linear_heads=False, linear_head_backward=None):
         self.cfg = cfg
         self.linear_head_backward = linear_head_backward or _LINEAR_HEAD_BWD
@@ -307,17 +316,37 @@ class Engine:
         }[kind]())
 
     def _wx3(self, P, name, kind):
-        """f32 weights as three bf16 planes per value ([N, 3K]; conv: K = (ky,kx,ci) inside each plane) for ops.gemm_nt_x3"""
+        """f32 weights as three bf16 planes per value ([rows, 3K]; conv: K = (ky,kx,ci) inside each plane) for ops.gemm_nt_x3.
+        kinds: the layouts of _w plus 'lin_a' / 'lin_b' (/ 'lin_t_a' / 'lin_t_b'): the token / class-token column halves of the
+        readout projection [D, 2D] (models/dpt/vit.py:84-88).  Refreshed after an optimizer step by the batched permute, straight
+        from the parameter into the planes (PackCache.refresh)."""
         p = P[name]
-        if kind == "lin":
-            build = lambda: ops.split3(p.detach().reshape(p.shape[0], -1).contiguous())
-        elif kind == "lin_t":
-            build = lambda: ops.split3(_pack_linear_t(p.detach().reshape(p.shape[0], -1), torch.float32))
-        elif kind == "c3_d":
-            build = lambda: ops.split3(_pack_conv3_dgrad(p, torch.float32))
-        else:
-            build = lambda: ops.split3(_pack_conv3(p, torch.float32))
-        return self.cache.get((name, kind + "_x3"), p, build)
+
+        def pack_f32():
+            w = p.detach()
+            if kind == "lin":
+                return w.reshape(w.shape[0], -1).contiguous()
+            if kind == "lin_t":
+                return _pack_linear_t(w.reshape(w.shape[0], -1), torch.float32)
+            if kind in ("lin_a", "lin_b", "lin_t_a", "lin_t_b"):
+                D = w.shape[1] // 2
+                half = w[:, :D] if kind.endswith("a") else w[:, D:]
+                if kind.startswith("lin_t"):
+                    return _pack_linear_t(half, torch.float32)
+                out = torch.empty((w.shape[0], D), dtype=torch.float32, device=w.device)
+                return ops.permute4(w, out, (1, 1, w.shape[0], D), (0, 0, w.stride(0), 1), src_offset=(0 if kind.endswith("a") else D))
+            return {"c3": _pack_conv3, "c3_d": _pack_conv3_dgrad, "ct": _pack_convT, "ct_d": _pack_convT_dgrad}[kind](w, torch.float32)
+
+        def build():
+            return ops.split3(pack_f32())
+
+        def recipe(rec, val):
+            rowlen = val.shape[1] // 3
+            if kind == "lin":          # no launch recorded: the pack is the parameter itself
+                return (p.detach(), val, (1, 1, 1, p.numel()), (0, 0, 0, 1), 0, rowlen) if p.is_contiguous() else None
+            return (rec[0][0], val, rec[0][2], rec[0][3], rec[0][4], rowlen) if len(rec) == 1 else None
+
+        return self.cache.get((name, kind + "_x3"), p, build, recipe)
 
     def _f32(self, P, name):
         p = P[name].detach()
@@ -329,6 +358,8 @@ class Engine:
         """P: dict name -> fp32 parameter tensor on the GPU (reference state-dict names).
         images: [B,3,H,W] fp32 on the GPU.  Returns (center [B,2,H,W] f32, sdf [B,1,H,W] f32, saved)."""
         cfg, dt = self.cfg, self.dt
+        if _X3_ALL and dt == torch.float32 and ops.get_f32_mode() in ("x3", "x3_fast"):
+            return self.forward_x3(P, images, save)      # fp32 parity mode on the bf16-plane kernels (engine_x3.py)
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
         images = images.contiguous()
         B, _, H, W = images.shape
@@ -574,6 +605,8 @@ class Engine:
         """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
         Parameters that receive no gradient are left untouched."""
         cfg, dt = self.cfg, self.dt
+        if S.get("x3"):
+            return self.backward_x3(P, S, d_center, d_sdf, G, stage_cb)
         B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
         D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
         g, Nt = gh * gw, gh * gw + 1

@@ -204,6 +204,17 @@ def split3(x, out=None, remap=None):
     return out
 
 
+def unsplit3(pl):
+    """bf16 planes [..., 3K] -> f32 [..., K] (exact inverse of split3)"""
+    _need_gpu(pl)
+    assert pl.dtype == torch.bfloat16 and pl.is_contiguous() and pl.shape[-1] % 3 == 0
+    K = pl.shape[-1] // 3
+    out = torch.empty(pl.shape[:-1] + (K,), dtype=torch.float32, device=pl.device)
+    rows = pl.numel() // (3 * K)
+    L.check(L.lib().umr_unsplit3(_p(pl), _p(out), rows, K, 3 * K, K, _stream()), "umr_unsplit3")
+    return out
+
+
 def _x3_operand(t, N):
     """(pointer, row stride, is_planes) of an [M, N] epilogue operand given as f32 [M, N] or as bf16 planes [M, 3N]"""
     if t.dtype == torch.bfloat16:

@@ -199,22 +199,28 @@ def cpu_baseline(wl, hip_peaks=None):
                       f"median {med:.2f} s/iteration"}
 
 
-def measured_traffic(a):
+def measured_traffic(a, M_head):
     """HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is the
     figure of the committed rocprofv3 passes (tools/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH doubled for gfx950; profiles/rNN_pmc_traffic.json).  null when no profile matches the run."""
-    if a.workload != "cfg2" or a.dtype != "bf16" or a.batch is not None:
+    same command, FETCH doubled for gfx950; profiles/rNN_pmc_traffic[_<workload>].json).  null when no profile matches the run
+    (another batch size, or a workload / precision that was never profiled)."""
+    if a.batch is not None or a.workload not in ("cfg2", "cfg4", "cfg5"):
+        return {"traffic": None}
+    if a.dtype != ("fp32" if a.workload == "cfg5" else "bf16"):
         return {"traffic": None}
     import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    suffix = "" if a.workload == "cfg2" else "_" + a.workload
+    # the head conv runs as <conv, epilogue class 3> (bf16: forward, sdf data gradient; <1, 3, 2>: the ReLU-masked data gradient)
+    # or <conv, 5> (fp32 parity mode: bf16-plane operands)
+    prefix = "gemm_nt256p_kernel<1, 5" if a.dtype == "fp32" else "gemm_nt256p_kernel<1, 3, 0"
+    # algorithmic bytes: one read of the input map + one write of the output map, 512 channels each; bf16 = 2 B per value, planes = 6 B
+    per_value = 6.0 if a.dtype == "fp32" else 2.0
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")), reverse=True):
         try:
-            ks = json.load(open(f))["kernels"]
-            # the head conv runs as <conv, epilogue class 3> (forward, sdf data gradient) and <conv, 0> (ReLU-masked data gradient)
-            ks = sorted(ks, key=lambda k: 0 if k["kernel"].startswith("gemm_nt256p_kernel<1, 3") else 1)
-            for k in ks:
-                if k["kernel"].startswith(("gemm_nt256p_kernel<1, 3", "gemm_nt256p_kernel<1, 0")) and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
+            for k in json.load(open(f))["kernels"]:
+                if k["kernel"].startswith(prefix) and k.get("class") == "large" and "hbm_bytes_per_launch" in k:
                     return {"traffic": k["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE)",
-                            "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes_per_launch": 2.0 * 64 * 384 * 384 * 512 * 2}
+                            "traffic_source": os.path.relpath(f, ROOT), "algorithmic_bytes_per_launch": 2.0 * M_head * 512 * per_value}
         except (OSError, ValueError, KeyError):
             continue
     return {"traffic": None}
@@ -257,6 +263,7 @@ def spawn_ranks(n, timeout_s):
     env0["MASTER_PORT"] = env0.get("MASTER_PORT") or str(_free_port())
     env0["WORLD_SIZE"] = str(n)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env0.setdefault("NCCL_DEBUG", "WARN")   # RCCL's own warnings land in the ranks' stderr: rank 0 live, the others in the failure tail
     env0.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     logdir = tempfile.mkdtemp(prefix="umr_bench_ranks_")
     t_start = time.time()
@@ -527,7 +534,7 @@ def run_rank(a):
                                                                           "f32 product; peak = 2500 / 6" if x3 else ") f32 MFMA"))),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,
-                         **measured_traffic(a)},
+                         **measured_traffic(a, M_head)},
         }
         if kind == "train":
             res["config"].update({"optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"})
@@ -659,11 +666,13 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_rank
     from argparse import Namespace
     from unmore_amd.objectness_net import ObjectnessNet
     from unmore_amd.parallel import BucketedAllReduce
-    # the gradient buffer's size: parameters of the workload's model (the module only HOLDS parameters; nothing is computed)
-    n = sum(p.numel() for p in ObjectnessNet("cpu", wl["H"], wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")).parameters())
+    # the step's real exchange: the flat gradient buffer of the workload's model (parameters that receive gradients, 256-byte
+    # aligned views) in its backward-completion buckets -- 115.4 M elements in 16 buckets for ViT-B (unmore_amd/trainer.py); the
+    # module only HOLDS parameters, nothing is computed
+    from unmore_amd.trainer import flat_layout
+    _, bounds, _ = flat_layout(ObjectnessNet("cpu", wl["H"], wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")))
+    n, nb = bounds[-1], len(bounds) - 1
     flat = torch.full((n,), float(rank + 1))
-    nb = 8
-    bounds = [n * i // nb for i in range(nb + 1)]
     comm = BucketedAllReduce(flat, bounds)
     for _ in range(a.warmup):
         for k in range(nb):
@@ -683,7 +692,7 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_rank
     ok = bool(torch.all(flat == expect)) and scale == 1.0 / world
     if rank == 0:
         print(json.dumps({"rehearsal": True, "metric": "distributed plumbing only (no model)", "value": None, "n_gpus": world, "steps": a.steps,
-                          "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "collective": coll, "allreduce_elements": n,
+                          "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "collective": coll, "allreduce_elements": n, "allreduce_buckets": nb,
                           "allreduce_correct": ok, "per_rank_ms_per_step": [1e3 * t / a.steps for t in own], "config": {"workload": wl["name"], "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
         dist.barrier()

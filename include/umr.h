@@ -127,7 +127,15 @@ int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
  * workgroup that arrives last at a tile adds them in split order (bitwise reproducible) and runs the epilogue.  workspace:
  * umr_gemm_nt_workspace() bytes of device memory, 16-byte aligned, whose first 16 KiB are ZERO on first use (tile counters; every
  * launch leaves them zero) and which no other stream uses concurrently.  workspace == NULL is umr_gemm_nt. */
+/* HARD PRECONDITIONS of the workspace (the split-K hand-over is a ticket counter per tile; csrc/gemm_nt.hip documents the memory
+ * ordering it relies on): (1) its first 16 KiB are zero before the first launch that uses it; (2) it belongs to ONE stream -- two
+ * launches that may run concurrently must not share it (results would be silently wrong); (3) a launch that was enqueued and then
+ * aborted (device fault, reset) leaves counters undefined: zero them again before reuse (umr_gemm_nt_ws does so itself when the
+ * launch call reports an error).  libumr_fence.so (make fence) is the same library with the textbook agent-scope release / acquire
+ * hand-over and a trap on an out-of-range ticket: the slow reference form the default build is tested against.
+ * umr_gemm_nt_splits: the number of K ranges umr_gemm_nt_ws would use for d with a workspace of that size (1 = not split). */
 int64_t umr_gemm_nt_workspace(void);
+int umr_gemm_nt_splits(const umr_gemm_desc* d, int64_t workspace_bytes);
 int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d);   /* extra bytes a UMR_BF16X3 problem wants for its K-split slabs */
 int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):

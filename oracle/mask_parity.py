@@ -38,18 +38,41 @@ def hip_relu_masks(S, head_layouts):
     return masks
 
 
+class FlipCounts(dict):
+    """{site: number of decisions where the oracle's own x > 0 differs from the imposed mask}, plus
+    .sites  = total number of decisions, and
+    .margin = the largest |pre-activation| among the flipped elements, in units of its tensor's rms: a flip is legitimate only where
+              the pre-activation is within rounding of zero -- a wrong mask far from zero would show up here as O(1)."""
+    sites = 0
+    margin = 0.0
+
+
 def masked_forward(sd, images, cfg, masks, **kw):
-    """orc.forward with the given ReLU decisions imposed (relu(x) := x * mask); returns (out dict, {site: number of elements
-    where the oracle's own decision x > 0 differs from the imposed one})."""
-    flips = {}
+    """orc.forward with the given ReLU decisions imposed (relu(x) := x * mask); returns (out dict, FlipCounts)."""
+    flips = FlipCounts()
 
     def hook(x, site):
         m = masks[site]
         assert m.shape == x.shape, (site, tuple(m.shape), tuple(x.shape))
-        flips[site] = int(((x.detach() > 0) != m).sum())
+        xd = x.detach()
+        diff = (xd > 0) != m
+        flips[site] = int(diff.sum())
+        flips.sites += m.numel()
+        if flips[site]:
+            rms = xd.double().pow(2).mean().sqrt().item() + 1e-300
+            flips.margin = max(flips.margin, xd[diff].abs().max().item() / rms)
         return x * m.to(x.dtype)
 
     with orc.relu_hook(hook):
         out = orc.forward(sd, images, cfg, **kw)
     assert set(flips) == set(masks), (sorted(set(masks) ^ set(flips)))
     return out, flips
+
+
+def assert_flips_are_rounding(flips, max_share=1e-5, max_margin=1e-4):
+    """the hypothesis the masked comparison rests on, asserted: only a vanishing share of the decisions differs from float64's own
+    (measured 5 of 17.5 M, 40 of 69.9 M), and every one of them sits within rounding of the kink (fp32 rounding of a
+    pre-activation of rms 1 is ~1e-6; 1e-4 leaves two orders of margin and still rejects a genuinely wrong mask)"""
+    n = sum(flips.values())
+    assert n <= max(1.0, max_share * flips.sites), (n, flips.sites)
+    assert flips.margin <= max_margin, flips.margin

@@ -25,6 +25,7 @@ def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, grads_
     torch.cuda.synchronize()
     sdo = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
     out_o, flips = mask_parity.masked_forward(sdo, img.double(), orc.CONFIGS[cfg_name], masks, **head_kw)
+    mask_parity.assert_flips_are_rounding(flips)
     for k, t in (("center_fields", c_hip), ("sdf_maps", s_hip)):
         assert (out_o[k].detach() - t.cpu().double()).abs().max().item() < 1e-4, k
     loss_o, _ = orc.loss_terms(out_o, cf.double(), sdf.double(), sal.double())

@@ -86,3 +86,27 @@ def test_a_hung_launch_hits_the_overall_deadline():
                         "--warmup", "1", "--launch-timeout", "3"], env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
     assert time.time() - t0 < 40 and "deadline of 3 s passed" in r.stderr
+
+
+def test_eight_rank_rehearsal_exchanges_the_full_gradient_buffer():
+    """The first 8-GPU run's plumbing, on CPU: 8 ranks (gloo), the ViT-B workload's whole flat gradient buffer (115.4 M elements)
+    in its 16 backward-completion buckets, correct sums on every element, ONE line with 8 per-rank entries."""
+    env = dict(_env(), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--rehearse", "--workload", "cfg2", "--steps", "2",
+                        "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = _one_json_line(r.stdout)
+    assert res["n_gpus"] == 8 and res["collective"] == {"backend": "gloo", "world": 8}
+    assert res["allreduce_correct"] is True and res["allreduce_buckets"] == 16
+    assert 115_000_000 < res["allreduce_elements"] < 116_000_000
+    assert len(res["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in res["per_rank_ms_per_step"])
+
+
+def test_a_dying_rank_five_of_eight_ends_the_launch_within_seconds():
+    t0 = time.time()
+    env = dict(_env(), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--rehearse", "--workload", "tiny", "--steps", "2",
+                        "--warmup", "1", "--fail-rank", "5"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 30
+    assert "rank 5 exited with status 3" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -29,7 +29,8 @@ def test_two_ranks_spawned_by_bench_itself():
     assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
 
 
-@pytest.mark.parametrize("workload,extra", [("tiny", []), ("cfg1", []), ("cfg5", ["--steps", "1", "--warmup", "1"])])
+@pytest.mark.parametrize("workload,extra", [("tiny", []), ("cfg1", []), ("cfg5", ["--steps", "1", "--warmup", "1"]),
+                                            ("cfg4", ["--steps", "1", "--warmup", "1", "--no-alt"])])
 def test_single_gpu_lines_carry_the_contract(workload, extra):
     res = _run("--workload", workload, "--no-cpu-baseline", *(extra or ["--steps", "2", "--warmup", "1"]))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
@@ -38,6 +39,10 @@ def test_single_gpu_lines_carry_the_contract(workload, extra):
     assert res["n_gpus"] == 1 and res["value"] > 0 and "workload" in res["config"]
     rf = res["roofline"]
     assert rf["bound"] == "mfma" and rf["launches_timed"] > 0 and 0 < rf["frac"] < 1
+    if workload == "cfg4":
+        # BASELINE configs[3] at workload size: ViT-L/14 518x518 batch 16 (1370 tokens per image, 4.3 M pixels)
+        assert res["config"]["per_gpu_batch"] == 16 and res["config"]["image"] == [518, 518] and res["dtype"] == "bf16"
+        assert res["final_loss"] == res["final_loss"] and 0 < res["final_loss"] < 100      # finite
     if workload == "cfg5":
         assert res["config"]["proposals_per_image"] == 1225 and res["crops_per_sec"] > 0
         # BASELINE configs[4] ("peak-picking bit-exact vs CPU"): the headline is the fp32 parity mode on a net whose score maps are

@@ -533,40 +533,6 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
     torch.testing.assert_close(res[224][0].float(), ref, atol=3e-2, rtol=3e-2)
 
 
-@pytest.mark.parametrize("M,N,K", [(64 * 577, 768, 768), (40000 + 77, 1024, 512), (3 * 128 + 5, 512, 256), (9000, 520, 1024), (128 * 300, 256, 64)])
-def test_two_workgroups_per_cu_kernel_equals_persistent_kernel(M, N, K, monkeypatch):
-    """gemm_nt128w.hip (128x256 tiles / two 256-thread workgroups per CU, and 128x512 tiles / one 512-thread workgroup; BK = 32
-    three-stage ring) against the persistent 256x256 kernel on the same problems: every K sum is the same MFMA sequence (k ascending in steps of 32), so plain / ReLU / residual /
-    ReLU-mask / fused-reduction results must be BIT-IDENTICAL; and both match torch.  Ragged M and N tails included."""
-    from unmore_amd import ops, _lib as L
-    dev = _dev()
-    x = _rnd((M, K), torch.bfloat16, dev, 81)
-    w = _rnd((N, K), torch.bfloat16, dev, 82, K ** -0.5)
-    bias = _rnd((N,), torch.float32, dev, 83)
-    aux = _rnd((M, N), torch.bfloat16, dev, 84)
-    redw = _rnd((2, N), torch.float32, dev, 85)
-    monkeypatch.setenv("UMR_GEMM_TILE", "256")
-
-    def run():
-        outs = [ops.gemm_nt(x, w, bias), ops.gemm_nt(x, w, bias, act=L.ACT_RELU), ops.gemm_nt(x, w, bias, aux=aux),
-                ops.gemm_nt(x, w, None, aux=aux, mask_relu=True)]
-        outs += list(ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw))
-        outs.append(ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw[:1].contiguous(), no_store=True)[1])
-        torch.cuda.synchronize()
-        return outs
-
-    monkeypatch.setenv("UMR_NT128W", "0")
-    ref = run()
-    for mode in ("2", "3"):        # 2 = 128x256 tiles, two workgroups per CU; 3 = 128x512 tiles, eight waves
-        monkeypatch.setenv("UMR_NT128W", mode)
-        new = run()
-        for i, (a, b) in enumerate(zip(ref, new)):
-            assert torch.equal(a, b), (mode, i)
-    gold = x.float() @ w.float().t() + bias
-    torch.testing.assert_close(new[0].float(), gold, atol=3e-2, rtol=3e-2)
-    torch.testing.assert_close(new[2].float(), gold + aux.float(), atol=5e-2, rtol=3e-2)
-
-
 def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
     """40 random plain-GEMM problems (ragged M and N, K a multiple of 64, every epilogue class) through the persistent 256x256
     kernel -- every tile height it may choose -- against the 128x128 kernel (the one the fixture tests exercise): bf16 results
@@ -631,7 +597,7 @@ def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K,force", [(1300, 1024, 4096, None), (1300, 1024, 1024, None), (300, 200, 1096, "3"), (129, 136, 520, "8"),
+@pytest.mark.parametrize("M,N,K,force", [(1300, 1024, 4096, None), (1300, 1024, 1024, None), (300, 200, 1096, "3"), (129, 136, 776, "8"),
                                          (700, 3072, 1024, "2")])
 def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
     """Split-K of the 128x128 kernel (umr_gemm_nt_ws: few tiles, long K -- the reference recipe's 1300-token projections): against
@@ -659,6 +625,12 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
     for mode in (("x3", "exact") if dtype == torch.float32 else (None,)):
         if mode:
             ops.set_f32_mode(mode)
+        # the launch really runs split: the library reports the number of K ranges it will use
+        nsplit = ops.gemm_nt(A, B, bias, query_splits=True)
+        if force:
+            assert 1 < nsplit <= int(force), (nsplit, force)      # (no range is left empty: 13 K-tiles in 8 ranges run as 7)
+        elif K >= 4096 or dtype == torch.float32:
+            assert nsplit > 1, nsplit
         first = run()
         second = run()
         for a, b in zip(first, second):
@@ -677,8 +649,72 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
             torch.testing.assert_close(first[1].double(), F.gelu(ref), **_tol(dtype))
         for a, b in zip(first, unsplit):     # same products, another f32 summation order: a rounding apart at most
             torch.testing.assert_close(a.float(), b.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)
-        # the split launch really ran split (or the shape is one the heuristic leaves alone): results differ somewhere, or are equal
     assert ops._sk_cache, "the split-K workspace was never requested"
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_split_k_back_to_back_with_different_operands(dtype, monkeypatch):
+    """Two split launches in a row on the SAME workspace with different A, each checked against float64: a last arriver that read a
+    slab of the previous launch (stale line, counter not back at zero) would reproduce the first result or mix the two."""
+    from unmore_amd import ops
+    dev = _dev()
+    monkeypatch.setenv("UMR_NT_SPLITK", "4")
+    M, N, K = 300, 264, 2048
+    B = _rnd((N, K), dtype, dev, 2, K ** -0.5)
+    outs, refs = [], []
+    As = [_rnd((M, K), dtype, dev, 10 + i) for i in range(6)]
+    assert ops.gemm_nt(As[0], B, query_splits=True) == 4
+    for A in As:          # enqueued back to back, no synchronisation in between
+        outs.append(ops.gemm_nt(A, B))
+    for A, o in zip(As, outs):
+        torch.testing.assert_close(o.double(), A.double() @ B.double().t(), **_tol(dtype))
+    assert not torch.equal(outs[0], outs[1])
+
+
+def test_split_k_equals_the_fence_build(tmp_path):
+    """The default hand-over (sc1 slab traffic + acknowledged stores + relaxed ticket: hardware ordering, csrc/gemm_nt.hip) against
+    libumr_fence.so (agent-scope release / acquire fences around the ticket: the textbook protocol, and a trap on a bad ticket),
+    run in a child process on the same seeded problems: results must be bit-identical."""
+    import os
+    import subprocess
+    import sys
+    from unmore_amd import _lib as L
+    fence = os.path.join(os.path.dirname(L.LIB_PATH), "libumr_fence.so")
+    assert os.path.exists(fence), "libumr_fence.so missing: build() makes it (make -C unmore_amd/csrc)"
+    script = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from unmore_amd import ops
+import os
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).cuda().to(dtype)
+outs = []
+for dtype in (torch.float32, torch.bfloat16):
+    for (M, N, K, force) in ((1300, 1024, 4096, None), (300, 200, 1096, "3"), (129, 136, 776, "8")):
+        if force: os.environ["UMR_NT_SPLITK"] = force
+        else: os.environ.pop("UMR_NT_SPLITK", None)
+        A, B, bias, aux = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5), rnd((N,), torch.float32, 3), rnd((M, N), dtype, 4)
+        assert ops.gemm_nt(A, B, bias, query_splits=True) > 1
+        for rep in range(3):
+            outs.append(ops.gemm_nt(A, B, bias).float().cpu())
+            outs.append(ops.gemm_nt(A, B, None, aux=aux, mask_relu=True).float().cpu())
+    os.environ["UMR_NT_SPLITK"] = "5"
+    x, w = rnd((2, 14, 9, 128), dtype, 5), rnd((200, 9 * 128), dtype, 6, 0.03)
+    outs.append(ops.gemm_nt(x, w, None, conv=1).float().cpu())
+torch.save(outs, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(L.__file__)))
+    res = {}
+    for tag, lib in (("default", L.LIB_PATH), ("fence", fence)):
+        env = dict(os.environ, UMR_LIB=lib)
+        env.pop("UMR_NT_SPLITK", None)
+        out = tmp_path / f"{tag}.pt"
+        r = subprocess.run([sys.executable, "-c", script, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = torch.load(out)
+    assert len(res["default"]) == len(res["fence"]) > 30
+    for a, b in zip(res["default"], res["fence"]):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

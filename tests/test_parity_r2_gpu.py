@@ -203,6 +203,7 @@ def test_backward_fp32_dpt_base_matches_oracle_autograd():
     eng.backward(P, S, dpc, dps, G)
     torch.cuda.synchronize()
     out_m, flips = mask_parity.masked_forward(sdo, img.double(), orc.CONFIGS["dpt_base"], masks)
+    mask_parity.assert_flips_are_rounding(flips)
     assert (out_m["center_fields"].detach() - c_hip.cpu().double()).abs().max().item() < 1e-4
     cot = [dpc.cpu().double(), dps.cpu().double()]
     ref_m = torch.autograd.grad([out_m["center_fields"], out_m["sdf_maps"]], [sdo[n] for n in names], grad_outputs=cot, allow_unused=True)
@@ -277,28 +278,22 @@ def test_backward_fp32_patch14_odd_grid_matches_oracle(backbone, H, W):
           f"worst relative L2 {w_l2:.2e}")
 
 
-@pytest.mark.parametrize("B", [4, 64])
-def test_bf16_vs_fp32_hip_at_benchmark_shape(B):
-    """dpt_base 384x384, B = 4 and B = 64 (the benchmark's exact configuration, BASELINE configs[1]; ~150 GB in fp32):
-    B=4: 1024 tiles of 256 rows -> gemm_nt256p<conv / 1x1 / fused reduction>, gemm_tn256, merged dfeat GEMM.
-    bf16 step vs fp32 step of the same HIP engine on the same weights and batch: loss within 2e-2, every parameter gradient
-    with cosine > 0.99 and relative L2 error < 0.12 (bf16 has 8 mantissa bits: ~4e-3 per rounding, accumulated over ~60 layers),
-    global cosine > 0.999."""
+def _bf16_vs_fp32_step(backbone, tag, H, W, B):
+    """bf16 step vs fp32 step of the same HIP engine on the same weights and batch: (losses, global gradient cosine, worst
+    per-tensor cosine and its name, worst per-tensor relative L2 error)"""
     from unmore_amd.trainer import TrainStep
-    H, W = 384, 384
-    img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=9))
+    _, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=9))
     img = torch.from_numpy(synth.blob_images(B, H, W, seed=9)).cuda()
     grads, losses = {}, {}
     for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        net, _ = _net("dpt_base", tag="base", dtype=dt, size=384)
+        net, _ = _net(backbone, tag=tag, dtype=dt, size=H)
         net.train()
-        step = TrainStep(net, lr=0.0)     # lr 0: the step leaves the weights alone, the flat gradient buffer is what we read
+        step = TrainStep(net, lr=0.0).set_graph_mode("off")   # lr 0: the step leaves the weights alone, the flat gradient buffer is what we read
         out5 = step.step(img, cf, sdf, sal)
         losses[name] = out5.cpu()
         grads[name] = {n: t.clone() for n, t in step.G.items()}
         del step, net
         torch.cuda.empty_cache()
-    assert abs(losses["bf16"][0].item() - losses["fp32"][0].item()) < 2e-2, (losses["bf16"], losses["fp32"])
     a = torch.cat([grads["bf16"][n].flatten() for n in grads["fp32"]]).double()
     b = torch.cat([grads["fp32"][n].flatten() for n in grads["fp32"]]).double()
     cos_all = (torch.dot(a, b) / (a.norm() * b.norm())).item()
@@ -313,6 +308,30 @@ def test_bf16_vs_fp32_hip_at_benchmark_shape(B):
         if c < worst_cos:
             worst_cos, wn = c, n
         worst_rel = max(worst_rel, r)
-    print(f"bf16 vs fp32 at dpt_base 384x384 B={B}: loss {losses['bf16'][0].item():.5f} vs {losses['fp32'][0].item():.5f}; global cosine "
+    print(f"bf16 vs fp32 at {backbone} {H}x{W} B={B}: loss {losses['bf16'][0].item():.5f} vs {losses['fp32'][0].item():.5f}; global cosine "
           f"{cos_all:.6f}; worst per-tensor cosine {worst_cos:.4f} ({wn}); worst relative L2 error {worst_rel:.3f}")
+    return losses, cos_all, worst_cos, wn, worst_rel
+
+
+@pytest.mark.parametrize("B", [4, 64])
+def test_bf16_vs_fp32_hip_at_benchmark_shape(B):
+    """dpt_base 384x384, B = 4 and B = 64 (the benchmark's exact configuration, BASELINE configs[1]; ~150 GB in fp32):
+    B=4: 1024 tiles of 256 rows -> gemm_nt256p<conv / 1x1 / fused reduction>, gemm_tn256, merged dfeat GEMM.
+    bf16 step vs fp32 step of the same HIP engine on the same weights and batch: loss within 2e-2, every parameter gradient
+    with cosine > 0.99 and relative L2 error < 0.12 (bf16 has 8 mantissa bits: ~4e-3 per rounding, accumulated over ~60 layers),
+    global cosine > 0.999."""
+    losses, cos_all, worst_cos, wn, worst_rel = _bf16_vs_fp32_step("dpt_base", "base", 384, 384, B)
+    assert abs(losses["bf16"][0].item() - losses["fp32"][0].item()) < 2e-2, (losses["bf16"], losses["fp32"])
     assert cos_all > 0.999 and worst_cos > 0.99 and worst_rel < 0.12
+
+
+@pytest.mark.parametrize("backbone,tag,H,W,B", [("dpt_large14", "large14", 518, 518, 2), ("dpt_large", "large", 128, 128, 20)])
+def test_bf16_vs_fp32_hip_at_the_other_workload_shapes(backbone, tag, H, W, B):
+    """The single-step evidence at the two shapes the B = 64 test does not reach, with ITS bars:
+    dpt_large14 518x518 (BASELINE configs[3]: 1370 tokens per image -- the attention tail tiles, the tile-height choice, the
+    256x256 kernels at 0.5 M pixels) and the reference's own recipe (dpt_large, 128x128, batch 20: README.md:148-155,
+    train_objectness_net.py:815-817 -- 1300 tokens, split-K active in both precisions).  Two optimisation TRAJECTORIES in different
+    precisions part exponentially (tools/probe/chaos_ref.py); one step from identical weights is the comparable quantity."""
+    losses, cos_all, worst_cos, wn, worst_rel = _bf16_vs_fp32_step(backbone, tag, H, W, B)
+    assert abs(losses["bf16"][0].item() - losses["fp32"][0].item()) < 2e-2, (losses["bf16"], losses["fp32"])
+    assert cos_all > 0.999 and worst_cos > 0.99 and worst_rel < 0.12, (cos_all, worst_cos, wn, worst_rel)

@@ -63,6 +63,7 @@ _SIGS = {
     "umr_gemm_nt": [_vp, _vp],
     "umr_gemm_nt_ws": [_vp, _vp, _i64, _vp],
     "umr_gemm_nt_workspace": [],
+    "umr_gemm_nt_splits": [_vp, _i64],
     "umr_gemm_nt_rowreduce_ok": [_vp],
     "umr_label_synthesis_workspace": [_i32, _i32, _i32],
     "umr_label_synthesis": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp],

@@ -289,11 +289,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         // Every workgroup leaves its partial accumulators in its slab (register-major: 16 x [256 threads] x 16 B, coalesced);
         // the one that arrives last at the tile's counter adds the slabs IN SPLIT ORDER (so the result does not depend on
         // arrival order: bitwise reproducible), resets the counter for the next launch and runs the epilogue.
-        // Slab traffic uses agent-scope relaxed atomic 8-byte stores / loads (sc1: written through to / read from the memory
-        // side, whichever XCD's L2 the workgroups sit behind) and the hand-over is "my stores have been acknowledged"
-        // (s_waitcnt vmcnt(0)) + the agent-scope counter atomic.  An agent-scope FENCE would be correct too, but on this
-        // chip it writes back and invalidates the XCD's whole L2 -- twice per workgroup: measured 27.5 -> 31.7 ms on the
-        // reference recipe's step, slower than not splitting at all.
+        //
+        // Hand-over (default build).  What it rests on, by name -- cdna_hip_programming.md section 5 "Projection GEMM at M = 256",
+        // item 2 ("Equally valid and cheaper per episode") and section 6 Guideline 16 R1:
+        //   * slab stores are agent-scope atomic stores, i.e. `global_store ... sc1`: WRITE-THROUGH to the memory side shared by
+        //     all eight XCD L2s, and their vmcnt credit returns only when that write is acknowledged -- after
+        //     `s_waitcnt vmcnt(0)` this wave's partial sums are visible to any agent-scope (sc1) load, whichever XCD issues it;
+        //   * the barrier makes that true for every wave of the workgroup before lane 0 draws its ticket; the ticket is an
+        //     agent-scope RMW (performed at the same memory side), relaxed: it orders nothing by itself, the vmcnt waits do;
+        //   * the reducer reads the slabs with agent-scope atomic loads, i.e. `global_load ... sc1`, EVERY one of them: an sc1
+        //     load is served from the memory side, never from a stale line of the reducer's own XCD L2.
+        // So no cache write-back / invalidate is needed: the agent-scope FENCE of the textbook protocol is correct too, but on
+        // this chip it writes back and invalidates the XCD's whole L2 -- twice per workgroup: measured 27.5 -> 31.7 ms on the
+        // reference recipe's step, slower than not splitting at all.  This is hardware behaviour documented in the guide, not
+        // something the HIP memory model promises for relaxed atomics; -DUMR_SPLITK_FENCE builds the textbook release / acquire
+        // form (libumr_fence.so), and tests/test_gemm_gpu.py::test_split_k_equals_the_fence_build requires bit-identical results.
+        // The workgroup-scope fences around the ticket cost nothing (no cache action) and keep the COMPILER from moving memory
+        // operations across it.
         int* counters = (int*)skws;
         unsigned long long* slabs = (unsigned long long*)(skws + UMR_SPLITK_COUNTERS);
         constexpr int64_t SLAB = (int64_t)BM * BN / 2;      // in 8-byte units
@@ -307,7 +319,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // every thread's slab stores are acknowledged; the K loop's LDS reads are done
         if (tid == 0) {
+#ifdef UMR_SPLITK_FENCE
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
             const int old = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef UMR_SPLITK_FENCE
+            if (old < 0 || old >= splits) __builtin_trap();   // a counter that was not zero on first use / was left by an aborted launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
             const int last = old == splits - 1;
             if (last) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *(int*)smem = last;
@@ -460,8 +485,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256.hip
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt256p.hip
 int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
-int umr_launch_gemm_nt128w(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt128w.hip (two workgroups per CU, short K)
-bool umr_nt128w_eligible(const umr_gemm_desc* d);
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
 static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch
@@ -488,7 +511,6 @@ static bool uses_256(const umr_gemm_desc* d) {
 
 extern "C" int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d) {
     if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-    if (umr_nt128w_eligible(d)) return 1;
     return (uses_256(d) && umr_nt256_rowreduce_path(d)) ? 1 : 0;
 }
 
@@ -497,6 +519,18 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
 extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) { return gemm_nt_impl(d, nullptr, 0, stream); }
 
 extern "C" int64_t umr_gemm_nt_workspace(void) { return (int64_t)UMR_SPLITK_COUNTERS * 4 + (int64_t)512 * BM * BN * 4; }   // 16 KiB + 32 MiB
+
+static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws);
+static bool uses_256(const umr_gemm_desc* d);
+int umr_x3_ksplit_of(const umr_gemm_desc* d, int64_t ws_bytes);   // gemm_nt256p.hip
+
+extern "C" int umr_gemm_nt_splits(const umr_gemm_desc* d, int64_t workspace_bytes) {
+    if (d == nullptr || d->M <= 0 || d->N <= 0 || d->K <= 0 || workspace_bytes <= 0) return 1;
+    if (d->dtype == UMR_BF16X3) return umr_x3_ksplit_of(d, workspace_bytes - (int64_t)UMR_SPLITK_COUNTERS * 4);
+    if (d->dtype != UMR_BF16 && d->dtype != UMR_F32) return 1;
+    if (uses_256(d)) return 1;
+    return pick_splits(d, (int64_t)((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN), true);
+}
 
 extern "C" int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream) {
     UMR_CHECK_ARG(workspace == nullptr || (workspace_bytes >= umr_gemm_nt_workspace() && ((uintptr_t)workspace & 15) == 0),
@@ -604,7 +638,6 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
         UMR_CHECK_ARG(umr_gemm_nt_rowreduce_ok(d) == 1, "gemm_nt: fused row reduction / no_store requested on a path that does not implement it (umr_gemm_nt_rowreduce_ok)");
         UMR_CHECK_ARG(!d->red_w || (d->red_out && (d->red_c == 1 || d->red_c == 2)), "gemm_nt: red_out / red_c");
     }
-    if (umr_nt128w_eligible(d)) return umr_launch_gemm_nt128w(d, s);
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     const int splits = pick_splits(d, grid, workspace != nullptr);
     float* skws = (float*)workspace;
@@ -635,6 +668,14 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
     }
 #undef LAUNCH_X3
 #undef LAUNCH
-    UMR_LAUNCH_CHECK();
+    {
+        const hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) {
+            // a launch that did not happen leaves the tile counters as they were (zero); one that was enqueued and then failed may
+            // not: put them back so that the NEXT launch on this workspace does not pick a wrong last arriver
+            if (splits > 1) (void)hipMemsetAsync(workspace, 0, (size_t)UMR_SPLITK_COUNTERS * 4, s);
+            return umr_set_error(UMR_ERR_HIP - (int)e_, hipGetErrorString(e_));
+        }
+    }
     return UMR_OK;
 }

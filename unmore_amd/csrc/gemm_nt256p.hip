@@ -1000,6 +1000,22 @@ extern "C" int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d) {
     return ks > 1 ? (int64_t)ks * d->M * d->N * 4 : 0;
 }
 
+// the number of K runs umr_launch_gemm_nt256p_ws would use for this plane problem with `ws_bytes` of slab space
+int umr_x3_ksplit_of(const umr_gemm_desc* d, int64_t ws_bytes) {
+    if (d->red_w || ws_bytes <= 0) return 1;
+    const int tiles_n = (d->N + BN2 - 1) / BN2, cus = num_cus();
+    int bm = BM2;
+    if (d->conv == 0 && (int64_t)((d->M + BM2 - 1) / BM2) * tiles_n <= 16ll * cus) {
+        double best = 1e300;
+        for (int c = 256; c >= 192; c -= 32) {
+            const int64_t t = (int64_t)((d->M + c - 1) / c) * tiles_n;
+            const double cost = (double)((t + cus - 1) / cus) * (0.25 + 0.75 * c / 256.0);
+            if (cost < best - 1e-9) { best = cost; bm = c; }
+        }
+    }
+    return x3_pick_ksplit(d, (int64_t)((d->M + bm - 1) / bm) * tiles_n, cus, umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6, ws_bytes);
+}
+
 int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
 int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s) { return umr_launch_gemm_nt256p_ws(d, nullptr, 0, s); }
 

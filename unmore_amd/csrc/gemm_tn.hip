@@ -420,9 +420,9 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
 int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s);
 namespace {
 
-static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking)
-    static const int v = umr_env_int("UMR_GEMM_TILE", 0);
-    return v;
+static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch, as umr_gemm_nt does
+    const char* e = getenv("UMR_GEMM_TILE");
+    return e ? atoi(e) : 0;
 }
 
 TnPlan tn_plan(const umr_gemm_tn_desc* d) {

@@ -102,7 +102,8 @@ def _splitk_workspace(device):
 
 def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbias=None, rows_per_batch=0,
             act=L.ACT_NONE, mask_relu=False, mask_dgelu=False, c2_mode=0, out_f32=False,
-            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False, _stamps=None):
+            conv=0, M=None, lda=None, a_remap=None, c_remap=None, aux_mod=0, red_w=None, no_store=False, query_rowreduce=False,
+            query_splits=False, _stamps=None):
     """C[M,N] = epi(A[M,K] . B[N,K]^T).  A: [M,K] (2-D, row stride lda) or NHWC
     [nb,H,W,Cin] when conv != 0 (B then is [N, 9*Cin] packed (ky,kx,ci)).
     red_w ([c, N] f32, c in {1,2}): fused row reduction (umr_gemm_desc.red_*) -> returns (C, partials [ceil(N/64), M, c]);
@@ -127,7 +128,7 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
         d.lda = A2.stride(0) if lda is None else lda
         assert A2.stride(1) == 1
     odt = torch.float32 if out_f32 else A.dtype
-    skip_c = no_store or query_rowreduce
+    skip_c = no_store or query_rowreduce or query_splits
     if out is None and not skip_c:
         out = torch.empty((M_, N), dtype=odt, device=A.device)
     assert skip_c or (out.dtype == odt and out.stride(-1) == 1)
@@ -167,6 +168,8 @@ def gemm_nt(A, B, bias=None, *, out=None, out2=None, aux=None, aux2=None, rowbia
     d.aux_mod = aux_mod
     if query_rowreduce:
         return bool(L.lib().umr_gemm_nt_rowreduce_ok(ctypes.byref(d)))
+    if query_splits:   # how many K ranges this call would run as (1 = not split); launches nothing
+        return int(L.lib().umr_gemm_nt_splits(ctypes.byref(d), int(L.lib().umr_gemm_nt_workspace()) if _wants_splitk_ws(d) else 0))
     partials = None
     if red_w is not None:
         assert red_w.dtype == torch.float32 and red_w.is_contiguous() and red_w.shape[1] == N and red_w.shape[0] in (1, 2)
@@ -702,6 +705,10 @@ def kernel_timer_results_ms():
 _raw_gemm_nt_call = None
 
 
+def _wants_splitk_ws(d):
+    return d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32)
+
+
 def _gemm_nt_call(d):
     if d.dtype == L.BF16X3:
         ws = _x3_workspace(d, torch.device("cuda", torch.cuda.current_device()))
@@ -709,7 +716,7 @@ def _gemm_nt_call(d):
             return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
         return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
     # few 128x128 tiles and a long K: hand the library its split-K scratch (include/umr.h: umr_gemm_nt_ws); the library decides
-    if d.K >= 768 and ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 170 and d.dtype in (L.BF16, L.F32):
+    if _wants_splitk_ws(d):
         ws = _splitk_workspace(torch.device("cuda", torch.cuda.current_device()))
         return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
     return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())

@@ -32,6 +32,28 @@ def _stage_of(name, cfg):
     return "embed"
 
 
+def flat_layout(net):
+    """The flat gradient / parameter buffer of a net: {name: element offset}, bucket boundaries [0, ..., total] and
+    {stage: bucket index}, in backward-completion order (heads, refinenets, reassemble, blocks last..first, embeddings); every
+    view 256-byte aligned.  Device-independent (bench.py --rehearse builds the same 16 buckets on the CPU)."""
+    cfg = net.cfg
+    named = dict(net.named_parameters())
+    nograd = net.nograd_names()
+    order = ["heads", "refine", "reassemble"] + [f"block{i}" for i in range(max(cfg["hooks"]), -1, -1)] + ["embed"]
+    by_stage = {s: [] for s in order}
+    for n in named:
+        if n not in nograd:
+            by_stage[_stage_of(n, cfg)].append(n)
+    offs, bounds, off, stage_bucket = {}, [0], 0, {}
+    for bi, s in enumerate(order):
+        for n in by_stage[s]:
+            offs[n] = off
+            off += (named[n].numel() + 63) // 64 * 64
+        bounds.append(off)
+        stage_bucket[s] = bi
+    return offs, bounds, stage_bucket
+
+
 def filter_batch(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
     """The reference's per-step batch filter (train_objectness_net.py:190-207): drop images whose pseudo-mask is all
     background or all foreground, so every remaining image has both.  Host-side boolean indexing (tensor plumbing,
@@ -50,26 +72,11 @@ class TrainStep:
         self.loss_cfg = (center_field_loss_type == "l2", sdf_loss_type == "l2", bool(use_sdf_gradient_loss),
                          bool(use_sdf_binary_mask_loss))
         self.iter = 0
-        cfg = net.cfg
         named = dict(net.named_parameters())
         dev = next(iter(named.values())).device
         assert dev.type == "cuda", "TrainStep needs the model on the GPU"
-        nograd = net.nograd_names()
-        order = ["heads", "refine", "reassemble"] + [f"block{i}" for i in range(max(cfg["hooks"]), -1, -1)] + ["embed"]
-        by_stage = {s: [] for s in order}
-        for n, p in named.items():
-            if n in nograd:
-                continue
-            by_stage[_stage_of(n, cfg)].append(n)
-        # flat layout, every view 256-byte aligned
-        offs, bounds, off = {}, [0], 0
-        self.stage_bucket = {}
-        for bi, s in enumerate(order):
-            for n in by_stage[s]:
-                offs[n] = off
-                off += (named[n].numel() + 63) // 64 * 64
-            bounds.append(off)
-            self.stage_bucket[s] = bi
+        offs, bounds, self.stage_bucket = flat_layout(net)
+        off = bounds[-1]
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)

@@ -456,8 +456,8 @@ def run_rank(a):
             peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams)
         units_per_step = 1
 
-    # HIP-graph replay of the step (unmore_amd/graphs.py): 'auto' captures the small workloads (ref / cfg1 / cfg5 / tiny: their
-    # step is bound by the host's launch rate) and leaves the 384^2 / 518^2 batches eager.  A replayed step cannot carry per-kernel
+    # HIP-graph replay (unmore_amd/graphs.py): 'auto' captures the small INFERENCE workloads (cfg1 / cfg5) and leaves train steps
+    # eager (GPU-bound; the eager two-stream schedule is faster than a replay, graphs.wanted).  A replayed step cannot carry per-kernel
     # HIP events, so the dominant kernel is then timed in a separate eager leg AFTER the timed region (said so in the line).
     from unmore_amd import graphs
     if kind == "train":
@@ -465,7 +465,7 @@ def run_rank(a):
     else:
         net.set_graph_mode(a.graphs)
     pixels = (50 if kind == "sweep" else B) * H * W
-    graphed = world == 1 and graphs.wanted(a.graphs, pixels)
+    graphed = world == 1 and graphs.wanted(a.graphs, pixels, train=(kind == "train"))
     warm = a.warmup + (graphs.WARMUP_CALLS + 1 if graphed and kind != "sweep" else 0)   # two eager calls + the capturing call, untimed
     for _ in range(warm):
         one()
@@ -716,7 +716,7 @@ def main():
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="plain --gpus N launch: overall deadline in seconds, counted from the launch")
     ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # launcher test hook
     ap.add_argument("--graphs", default="auto", choices=["auto", "on", "off"],
-                    help="HIP-graph replay of the step: auto = small workloads only (B*H*W <= 2^20 pixels), eager otherwise")
+                    help="HIP-graph replay: auto = small inference workloads only (B*H*W <= 2^20 pixels), on = also train steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()

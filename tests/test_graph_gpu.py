@@ -123,3 +123,26 @@ def test_sweep_on_three_streams_with_replays_equals_eager():
     from unmore_amd import graphs
     caps = [v for v in net_g._inf_graphs.values() if isinstance(v, graphs.Captured)]
     assert len(caps) == 3 and all(c.failed is None for c in caps)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("graph", ["off", "on"])
+def test_weight_gradient_stream_does_not_change_results(dtype, graph, monkeypatch):
+    """engine.WgradStream: the weight-gradient GEMMs of a small problem run on a second stream beside the data-gradient chain
+    (as graph edges under capture).  Same kernels on the same operands: bit-identical to the one-stream schedule, step after step."""
+    from unmore_amd import engine
+    from unmore_amd.trainer import TrainStep
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(engine, "_WGRAD_STREAM", mode)
+        net, _ = _net(dtype=dtype)
+        step = TrainStep(net, lr=1e-3).set_graph_mode(graph)
+        losses = []
+        for it in range(5):
+            losses.append(step.step(*_batch(2, 64, 96, seed=40 + it)))
+        torch.cuda.synchronize()
+        res[mode] = (torch.stack(losses), step.flat_p.clone(), step.flat_g.clone())
+        if graph == "on":
+            assert step.graph_replays == 3
+    for a, b in zip(res["0"], res["1"]):
+        assert torch.equal(a, b)

@@ -219,6 +219,51 @@ _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: on
 _LINEAR_HEAD_BWD = os.environ.get("UMR_LINEAR_HEAD_BWD", "algebraic")
 
 
+_WGRAD_STREAM = os.environ.get("UMR_WGRAD_STREAM", "auto")   # weight gradients on a second stream: auto (small problems) | 0 | 1
+_side_streams = {}
+
+
+class WgradStream:
+    """Weight gradients are leaves of the backward pass: nothing in it reads them.  For small problems (the reference's recipe:
+    20 crops of 128x128, README.md:148-155 -- GEMMs of 24-264 tiles on 256 CUs) they run on a second HIP stream, beside the data-
+    gradient chain instead of inside it; under a HIP-graph capture the fork and join are graph edges and cost the host nothing.
+    Same kernels, same operands, same order per stream: results are bit-identical to the one-stream schedule.  Large problems
+    fill the chip with every launch and keep one stream (and their memory: a tensor read on the side stream cannot be reused by
+    the allocator until that stream has passed it)."""
+
+    def __init__(self, dev, on):
+        self.on = bool(on)
+        if self.on:
+            self.main = torch.cuda.current_stream(dev)
+            key = (dev.index, self.main.cuda_stream)
+            if key not in _side_streams:
+                if len(_side_streams) > 16:
+                    _side_streams.clear()
+                _side_streams[key] = torch.cuda.Stream(device=dev)
+            self.side = _side_streams[key]
+
+    def run(self, fn, *used):
+        """fn: launches on the current stream; used: tensors (allocated on the main stream) those launches read"""
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.main)       # the producers of `used` are enqueued on main
+        with torch.cuda.stream(self.side):
+            fn()
+        for t in used:
+            if t is not None:
+                t.record_stream(self.side)
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.side)
+
+    @staticmethod
+    def wanted(pixels):
+        if _WGRAD_STREAM in ("0", "1"):
+            return _WGRAD_STREAM == "1"
+        return pixels <= graphs.AUTO_MAX_PIXELS
+
+
 class Engine(X3Path):
     def __init__(self, cfg, head_layouts, compute_dtype=torch.float32, collapse_linear_heads=False, linear_head_backward=None):
         self.cfg = cfg
@@ -601,25 +646,36 @@ class Engine(X3Path):
         return outs[0], outs[1], S
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P, S, d_center, d_sdf, G, stage_cb=None):
+    def backward(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
         """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
-        Parameters that receive no gradient are left untouched."""
+        Parameters that receive no gradient are left untouched.
+        stage_cb(name) is called when a stage's gradients are complete (the data-parallel exchange launches its bucket there);
+        join_at_stages: the caller reads the gradients inside stage_cb (so the weight-gradient stream is joined before each call)."""
         cfg, dt = self.cfg, self.dt
         if S.get("x3"):
-            return self.backward_x3(P, S, d_center, d_sdf, G, stage_cb)
+            return self.backward_x3(P, S, d_center, d_sdf, G, stage_cb, join_at_stages)
         B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
         D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
         g, Nt = gh * gw, gh * gw + 1
         dev = d_center.device
-        cb = stage_cb if stage_cb is not None else (lambda name: None)
+        wg = WgradStream(dev, WgradStream.wanted(B * H * W))
+
+        def cb(name):
+            if join_at_stages:
+                wg.join()
+            if stage_cb is not None:
+                stage_cb(name)
 
         def wgrad_lin(name, dy, x, bias_name=None, **kw):
-            ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw)
+            wg.run(lambda: ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw), dy, x)
 
         def wgrad_c3(name, dy, x_nhwc, bias_name=None, conv=1):
             co = G[name].shape[0]
-            dwp = ops.gemm_tn(dy.reshape(-1, co), x_nhwc, dbias=(G[bias_name] if bias_name else None), conv=conv)
-            _unpack_conv3_grad(dwp, G[name])
+
+            def launch():
+                dwp = ops.gemm_tn(dy.reshape(-1, co), x_nhwc, dbias=(G[bias_name] if bias_name else None), conv=conv)
+                _unpack_conv3_grad(dwp, G[name])
+            wg.run(launch, dy, x_nhwc)
 
         # ---- heads
         dfeat = None
@@ -827,4 +883,5 @@ class Engine(X3Path):
             tmp = ops.gemm_tn(dx, patches, dbias=G[m + "patch_embed.proj.bias"], dy_remap=(g, Nt, 1), M=B * g)
             gwp.copy_(tmp[:, :K])
         cb("embed")
+        wg.join()
         S.clear()

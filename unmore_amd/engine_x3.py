@@ -131,13 +131,26 @@ class X3Path:
             return self.cache.get((name, kind, torch.float32), P[name], lambda: _pack_linear_t(half, torch.float32))
         return self._w(P, name, kind)
 
-    def _wgrad(self, dY, X, dW, dbias=None, *, conv=0, accumulate=False):
-        """dW (+)= dY^T X (X NHWC with conv); plane kernel where it applies (N, K multiples of 8, no stride-2 conv)"""
+    def _wgrad(self, dY, X, dW, dbias=None, *, conv=0, accumulate=False, wg=None, then=None):
+        """dW (+)= dY^T X (X NHWC with conv); plane kernel where it applies (N, K multiples of 8, no stride-2 conv).
+        wg: engine.WgradStream -- the launch (and `then(dW)`, e.g. the unpacking of a conv gradient) goes to the weight-gradient
+        stream; the operand conversions stay on the main stream, where the data-gradient GEMMs share them."""
         N = dY.shape[-1]
         Kc = X.shape[-1]
-        if conv in (0, 1) and N % 8 == 0 and Kc % 8 == 0:
-            return ops.gemm_tn(dY.P().reshape(-1, 3 * N), X.P(), dW=dW, dbias=dbias, conv=conv, accumulate=accumulate, x3=True)
-        return ops.gemm_tn(dY.F().reshape(-1, N), X.F(), dW=dW, dbias=dbias, conv=conv, accumulate=accumulate)
+        x3 = conv in (0, 1) and N % 8 == 0 and Kc % 8 == 0
+        a, b = (dY.P().reshape(-1, 3 * N), X.P()) if x3 else (dY.F().reshape(-1, N), X.F())
+        res = []
+
+        def launch():
+            r = ops.gemm_tn(a, b, dW=dW, dbias=dbias, conv=conv, accumulate=accumulate, x3=x3)
+            if then is not None:
+                then(r)
+            res.append(r)
+        if wg is None or not wg.on:
+            launch()
+            return res[0]
+        wg.run(launch, a, b)
+        return None
 
     # ------------------------------------------------------------------ forward
     def forward_x3(self, P, images, save):
@@ -335,23 +348,29 @@ class X3Path:
         return outs[0], outs[1], S
 
     # ------------------------------------------------------------------ backward
-    def backward_x3(self, P, S, d_center, d_sdf, G, stage_cb=None):
-        from .engine import _ACT, _unpack_conv3_grad
+    def backward_x3(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
+        from .engine import _ACT, _unpack_conv3_grad, WgradStream
         cfg = self.cfg
         B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
         D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
         g, Nt = gh * gw, gh * gw + 1
         dev = d_center.device
-        cb = stage_cb if stage_cb is not None else (lambda name: None)
+        wg = WgradStream(dev, WgradStream.wanted(B * H * W))
         mm = lambda *a, **k: self._mm(P, *a, **k)
 
+        def cb(name):
+            if join_at_stages:
+                wg.join()
+            if stage_cb is not None:
+                stage_cb(name)
+
         def wgrad_lin(name, dy, x, bias_name=None):
-            self._wgrad(dy, x, G[name].view(G[name].shape[0], -1), (G[bias_name] if bias_name else None))
+            self._wgrad(dy, x, G[name].view(G[name].shape[0], -1), (G[bias_name] if bias_name else None), wg=wg)
 
         def wgrad_c3(name, dy, x_nhwc, bias_name=None, conv=1):
             co = G[name].shape[0]
-            dwp = self._wgrad(dy.view(-1, co), x_nhwc, None, (G[bias_name] if bias_name else None), conv=conv)
-            _unpack_conv3_grad(dwp, G[name])
+            self._wgrad(dy.view(-1, co), x_nhwc, None, (G[bias_name] if bias_name else None), conv=conv, wg=wg,
+                        then=lambda dwp: _unpack_conv3_grad(dwp, G[name]))
 
         # ---- heads
         M = B * H * W
@@ -537,4 +556,5 @@ class X3Path:
             tmp = self._wgrad(dxp, patches, None, G[m + "patch_embed.proj.bias"])
             gwp.copy_(tmp[:, :K])
         cb("embed")
+        wg.join()
         S.clear()

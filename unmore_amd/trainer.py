@@ -111,7 +111,7 @@ class TrainStep:
         eng = self.net._engine()
         center, sdf, S = eng.forward(self.P, images, save=True)
         out5, dpc, dps = ops.objectness_loss(center, sdf, gt_center_fields, gt_sdf_maps, gt_saliency_maps, *self.loss_cfg)
-        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=lambda s: self.comm.ready(self.stage_bucket[s]))
+        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=lambda s: self.comm.ready(self.stage_bucket[s]), join_at_stages=self.comm.enabled)
         self.comm.finish()
         ops.adam_step_hyper(self.flat_p, self.flat_g, self.m, self.v, self._hyper)
         # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
@@ -122,9 +122,10 @@ class TrainStep:
         return (out5,)
 
     def set_graph_mode(self, mode):
-        """'auto' (default; env UMR_GRAPHS): steps of small batches (B*H*W <= 2^20 pixels -- the reference's own recipe, 20 crops of
-        128x128, README.md:148-155) are captured into a HIP graph after two eager steps of the same shape and replayed; 'on' / 'off'
-        force it.  Data-parallel runs (world > 1) stay eager: their collectives are not captured."""
+        """'on': the step is captured into a HIP graph after two eager steps of the same shape and replayed (bit-identical; host
+        enqueue 18.3 -> 0.36 ms per step on the reference recipe).  'auto' (default; env UMR_GRAPHS) and 'off' run eagerly: the step
+        is GPU-bound and the eager two-stream schedule is faster than a replay (graphs.wanted).  Data-parallel runs (world > 1)
+        always run eagerly: their collectives are not captured."""
         assert mode in ("auto", "on", "off")
         self.graph_mode = mode
         self._graphs.clear()
@@ -140,7 +141,7 @@ class TrainStep:
         ins = (images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
         eng = self.net._engine()
         B, _, H, W = images.shape
-        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W) and ops._timer["select"] is None:
+        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W, train=True) and ops._timer["select"] is None:
             key = (tuple(images.shape), eng.dt, ops.get_f32_mode(), torch.cuda.current_stream(images.device).cuda_stream)
             ent = self._graphs.get(key)
             if isinstance(ent, graphs.Captured):

@@ -401,7 +401,8 @@ def test_batched_repack_equals_lazy_repack(dtype, monkeypatch):
         losses = [step.step(img, cf, sdf, sal).clone() for _ in range(4)]
         if mode:
             eng = net._engine()
-            assert eng.cache._replay is not None and len(eng.cache._replay[1]) > 40 and not eng.cache._o
+            # (one launch for all copies, or -- small problems -- one per stage behind the weight-gradient stream)
+            assert eng.cache._replay and sum(len(keys) for _, keys in eng.cache._replay.values()) > 40 and not eng.cache._o
         res[mode] = (torch.stack(losses).cpu(), step.flat_p.clone().cpu())
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])

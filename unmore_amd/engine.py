@@ -43,7 +43,7 @@ class PackCache:
     def __init__(self):
         self._c = {}           # key -> [version, value, event, synced streams, recipe, param]: replayable packs
         self._o = {}           # same without a recipe: rebuilt lazily after refresh()
-        self._replay = None    # (launcher, keys) of the batched refresh, built on first use
+        self._replay = {}      # tag -> (launcher, keys) of a batched refresh (None: all entries), built on first use
         # A captured graph holds the ADDRESSES of the copies it read: gen_c counts changes of the replayable set (and of the batched
         # refresh's table), gen_o changes of the rest.  A capture depends on gen_o only if it read such an entry that it did not
         # build itself (a capture rebuilds its own on every replay): generation(store)
@@ -57,24 +57,21 @@ class PackCache:
         ver = (param._version, param.data_ptr())
         hit = self._c.get(key) or self._o.get(key)
         cap = graphs.capturing()
-        if param.is_cuda:
-            st = torch.cuda.current_stream(param.device)
-            sid = st.cuda_stream
-        else:
-            st, sid = None, None
+        sid = ops._stream_id(param.device.index) if param.is_cuda else None    # raw handle: no Stream object on the hit path
         if hit is not None and hit[0] == ver:
             if cap and key in self._o and hit[6] is not graphs.capture_store():
                 graphs.capture_store()["hit_o"] = True
             # (inside a capture nothing from before it is pending -- graphs.Captured synchronises first -- and an event wait on
             # work outside the capture must not be recorded into it)
-            if st is not None and not cap:
+            if sid is not None and not cap:
                 if hit[2] is not None and sid not in hit[3]:
-                    st.wait_event(hit[2])
+                    torch.cuda.current_stream(param.device).wait_event(hit[2])
                     hit[3].add(sid)
                 if self._epoch is not None and sid not in self._epoch[1]:
-                    st.wait_event(self._epoch[0])
+                    torch.cuda.current_stream(param.device).wait_event(self._epoch[0])
                     self._epoch[1].add(sid)
             return hit[1]
+        st = torch.cuda.current_stream(param.device) if param.is_cuda else None
         # record what the build launches: a pack that is exactly ONE permute / cast into the returned tensor can be replayed by
         # refresh() (every pack helper below is); anything else is rebuilt lazily after a refresh
         rec = []
@@ -98,13 +95,13 @@ class PackCache:
             ev.record(st)
         entry = [ver, val, ev, {sid}, recipe, param, (graphs.capture_store() if cap else None)]
         if self._c.pop(key, None) is not None:
-            self._replay = None       # the batched refresh was built over the dropped entry
+            self._replay = {}         # the batched refreshes were built over the dropped entry
             self.gen_c += 1
         if self._o.pop(key, None) is not None:
             self.gen_o += 1
         if recipe is not None and st is not None:
             self._c[key] = entry
-            self._replay = None
+            self._replay = {}
             self.gen_c += 1
         else:
             self._o[key] = entry
@@ -118,29 +115,31 @@ class PackCache:
     def clear(self):
         self._c.clear()
         self._o.clear()
-        self._replay = None
+        self._replay = {}
         self._epoch = None
         self.gen_c += 1
         self.gen_o += 1
 
-    def refresh(self):
+    def refresh(self, tag=None, select=None):
         """The parameters were updated IN PLACE by a kernel torch does not see (TrainStep's Adam launch): re-run every pack into
         its existing destination in ONE launch (umr_permute4_batched) instead of dropping the copies and re-packing ~180
-        weights one launch each during the next step.  Entries that are not a single permute are dropped (rebuilt lazily)."""
-        if self._o:
-            self._o.clear()
-            if not graphs.capturing():   # (inside a capture every such entry was built by the capture itself and is rebuilt by each replay)
-                self.gen_o += 1
+        weights one launch each during the next step.  Entries that are not a single permute are dropped (rebuilt lazily).
+        tag / select(key): refresh only the entries select() accepts (one launch per tag: TrainStep updates and refreshes stage
+        by stage, beside the rest of backward); the caller ends the round of partial refreshes with refresh_done()."""
+        if tag is None:
+            self.refresh_done()
         if not self._c:
             return
-        if any(e[5].data_ptr() != e[0][1] for e in self._c.values()):   # a parameter's storage moved: the recipes are stale
+        if tag not in self._replay:
+            assert not graphs.capturing(), "PackCache.refresh: the batched refresh must be built before a capture (warm-up steps)"
+            keys = [k for k in self._c if select is None or select(k)]
+            self._replay[tag] = (ops.permute4_batched([self._c[k][4] for k in keys]) if keys else None, keys)
+        launch, keys = self._replay[tag]
+        if launch is None:
+            return
+        if any(self._c[k][5].data_ptr() != self._c[k][0][1] for k in keys):   # a parameter's storage moved: the recipes are stale
             self.clear()
             return
-        if self._replay is None:
-            assert not graphs.capturing(), "PackCache.refresh: the batched refresh must be built before a capture (warm-up steps)"
-            keys = list(self._c)
-            self._replay = (ops.permute4_batched([self._c[k][4] for k in keys]), keys)
-        launch, keys = self._replay
         launch()
         if graphs.capturing():
             return                     # the replaying caller publishes the refresh with refreshed_by_replay()
@@ -151,6 +150,19 @@ class PackCache:
             e = self._c[k]
             e[0] = (e[5]._version, e[5].data_ptr())
             e[2], e[3] = ev, {st.cuda_stream}
+
+    def refresh_done(self):
+        """after the last (partial) refresh of a round: the copies that cannot be replayed are dropped (rebuilt on next use)"""
+        if self._o:
+            self._o.clear()
+            if not graphs.capturing():   # (inside a capture every such entry was built by the capture itself and is rebuilt by each replay)
+                self.gen_o += 1
+
+    def synced_with(self, stream):
+        """`stream` has waited for the stream(s) the refreshes ran on (a join): its later launches need no per-entry event wait"""
+        sid = stream.cuda_stream
+        for e in self._c.values():
+            e[3].add(sid)
 
     def refreshed_by_replay(self, device):
         """A graph replay on the current stream has just re-run the refresh: a consumer on another stream orders itself after it
@@ -649,7 +661,8 @@ class Engine(X3Path):
     def backward(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
         """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
         Parameters that receive no gradient are left untouched.
-        stage_cb(name) is called when a stage's gradients are complete (the data-parallel exchange launches its bucket there);
+        stage_cb(name, wg) is called when a stage's gradients are complete or enqueued behind wg (the WgradStream of this pass):
+        the data-parallel exchange launches its bucket there, a single-GPU step enqueues the stage's Adam update behind wg;
         join_at_stages: the caller reads the gradients inside stage_cb (so the weight-gradient stream is joined before each call)."""
         cfg, dt = self.cfg, self.dt
         if S.get("x3"):
@@ -664,7 +677,7 @@ class Engine(X3Path):
             if join_at_stages:
                 wg.join()
             if stage_cb is not None:
-                stage_cb(name)
+                stage_cb(name, wg)
 
         def wgrad_lin(name, dy, x, bias_name=None, **kw):
             wg.run(lambda: ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw), dy, x)

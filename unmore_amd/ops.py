@@ -15,8 +15,18 @@ from . import graphs
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 
 
+# the current device / stream as raw handles: torch.cuda.current_stream() builds a Stream object through several Python layers
+# (~6 us), and a step asks for it ~1500 times -- a third of the host time of the reference recipe's step
+_cur_dev = torch._C._cuda_getDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
+def _stream_id(device_index=None):
+    return _raw_stream(_cur_dev() if device_index is None else device_index)
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_raw_stream(_cur_dev()))
 
 
 def _p(t):
@@ -67,7 +77,7 @@ def _workspace(nbytes, device):
         if buf is None or buf.numel() < nbytes:
             buf = store["ws"] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         return buf
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_id(device.index))
     buf = _ws_cache.pop(key, None)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -89,7 +99,7 @@ def _splitk_workspace(device):
             buf = store["sk"] = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
             buf[:16384].zero_()
         return buf
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_id(device.index))
     buf = _sk_cache.pop(key, None)
     if buf is None:
         buf = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
@@ -246,7 +256,7 @@ def _x3_workspace(d, device):
         if buf is None or buf.numel() < need:
             buf = store["x3ws"] = torch.empty(need, dtype=torch.uint8, device=device)
         return buf
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _stream_id(device.index))
     buf = _x3_ws_cache.pop(key, None)
     if buf is None or buf.numel() < need:
         buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
@@ -711,13 +721,13 @@ def _wants_splitk_ws(d):
 
 def _gemm_nt_call(d):
     if d.dtype == L.BF16X3:
-        ws = _x3_workspace(d, torch.device("cuda", torch.cuda.current_device()))
+        ws = _x3_workspace(d, torch.device("cuda", _cur_dev()))
         if ws is not None:
             return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
         return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
     # few 128x128 tiles and a long K: hand the library its split-K scratch (include/umr.h: umr_gemm_nt_ws); the library decides
     if _wants_splitk_ws(d):
-        ws = _splitk_workspace(torch.device("cuda", torch.cuda.current_device()))
+        ws = _splitk_workspace(torch.device("cuda", _cur_dev()))
         return L.lib().umr_gemm_nt_ws(ctypes.byref(d), _p(ws), ws.numel(), _stream())
     return L.lib().umr_gemm_nt(ctypes.byref(d), _stream())
 

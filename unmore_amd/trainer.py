@@ -111,14 +111,46 @@ class TrainStep:
         eng = self.net._engine()
         center, sdf, S = eng.forward(self.P, images, save=True)
         out5, dpc, dps = ops.objectness_loss(center, sdf, gt_center_fields, gt_sdf_maps, gt_saliency_maps, *self.loss_cfg)
-        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=lambda s: self.comm.ready(self.stage_bucket[s]), join_at_stages=self.comm.enabled)
+        bounds = self.comm.bounds
+        updated = set()
+
+        def update(k):
+            lo, hi = bounds[k], bounds[k + 1]
+            if hi > lo:
+                ops.adam_step_hyper(self.flat_p[lo:hi], self.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], self._hyper)
+
+        def stage_done(stage, wg):
+            k = self.stage_bucket[stage]
+            self.comm.ready(k)
+            # (not the reassemble stage: the readout projections are read again when the transformer's backward reaches a hooked
+            # block -- the token gradient goes through them, models/dpt/vit.py:86-90 -- so they are updated after backward)
+            if wg.on and not self.comm.enabled and _BATCHED_REPACK and stage != "reassemble":
+                # small problems: this stage's Adam update and the refresh of its packed weight copies go behind its weight
+                # gradients on the second stream -- HBM-bound work beside the (latency-bound) rest of backward.  Nothing later in
+                # this step reads the stage's weights again; the final join of backward orders the next step after them.
+                def launch():
+                    update(k)
+                    eng.cache.refresh(tag=stage, select=lambda key, stage=stage: _stage_of(key[0], self.net.cfg) == stage)
+                wg.run(launch)
+                updated.add(k)
+
+        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=stage_done, join_at_stages=self.comm.enabled)
         self.comm.finish()
-        ops.adam_step_hyper(self.flat_p, self.flat_g, self.m, self.v, self._hyper)
-        # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
-        if _BATCHED_REPACK:
-            eng.cache.refresh()
+        if not updated:
+            ops.adam_step_hyper(self.flat_p, self.flat_g, self.m, self.v, self._hyper)
+            # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
+            if _BATCHED_REPACK:
+                eng.cache.refresh()
+            else:
+                eng.cache.clear()
         else:
-            eng.cache.clear()
+            for stage, k in self.stage_bucket.items():
+                if k not in updated:
+                    update(k)
+                    eng.cache.refresh(tag=stage, select=lambda key, stage=stage: _stage_of(key[0], self.net.cfg) == stage)
+            eng.cache.refresh_done()
+            if not graphs.capturing():
+                eng.cache.synced_with(torch.cuda.current_stream(images.device))
         return (out5,)
 
     def set_graph_mode(self, mode):

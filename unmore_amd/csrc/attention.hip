@@ -261,8 +261,14 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     const bf16_t* vb = qb + 2 * D;
     const int q0 = blockIdx.x * (64 * QB) + w * (16 * QB) + li;   // query of block qi: q0 + 16 qi
     RowFrag<bf16_t> qf[QB];
+    // Q carries hd^-0.5 AND log2(e): the scores come off the matrix pipe in log2 units, and the running maximum is subtracted by
+    // STARTING the score accumulators from -m (the C operand of the first QK^T MFMA) -- exp2 applies to the accumulator as it is.
+    // One fused multiply-add per score (16 per query block and tile, of ~52 vector instructions) disappears from a loop whose
+    // issue port is the bound (profiles/r03_attention_sq_counters.txt: 5.6 VALU per MFMA, 97 % busy).  The price is a second bf16
+    // rounding of Q (q * 0.18034 instead of the exact q / 8): 2^-9 relative on the scores, the size of Q's own bf16 rounding.
+    constexpr float LOG2E = 1.4426950408889634f;
 #pragma unroll
-    for (int qi = 0; qi < QB; ++qi) qf[qi] = rowfrag_global<bf16_t>(q0 + 16 * qi < N ? qb + (int64_t)(q0 + 16 * qi) * ld : nullptr, g, 0.125f);
+    for (int qi = 0; qi < QB; ++qi) qf[qi] = rowfrag_global<bf16_t>(q0 + 16 * qi < N ? qb + (int64_t)(q0 + 16 * qi) * ld : nullptr, g, 0.125f * LOG2E);
 
     // ---- staging: wave w, instruction i fills LDS rows (w*2+i)*8 .. +8 of a tile (1 KiB); lane -> (row, slot), and
     // the swizzle is applied on the global side (slot s of row r holds chunk s ^ kswz(r))
@@ -308,12 +314,11 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         lacc[qi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m_run[qi] = -INFINITY;
+        m_run[qi] = 0.f;         // log2 units; the first tile always sets it (see below)
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[qi][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    constexpr float LOG2E = 1.4426950408889634f;
-    constexpr float DEFER = 8.0f / LOG2E;   // raise the running max only when a tile tops it by 2^8
+    constexpr float DEFER = 8.0f;           // log2 units: raise the running max only when a tile tops it by 2^8
 
     const int ntiles = (N + TK - 1) / TK;
     issue_tile(0);
@@ -330,7 +335,8 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
             const bf16x8 k1 = *(const bf16x8*)(kad1 + sb + sub * 2048);
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) {
-                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                // scores relative to the running maximum: s = q.k * log2(e) / 8 - m_run
+                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{-m_run[qi], -m_run[qi], -m_run[qi], -m_run[qi]}, 0, 0, 0);
                 s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][sub], 0, 0, 0);
             }
         }
@@ -344,7 +350,6 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
                         for (int qi = 0; qi < QB; ++qi) s[qi][sub][e] = -INFINITY;
                     }
         }
-        float nmc[QB];
         bool any_up = false;
         float mxs[QB];
 #pragma unroll
@@ -361,22 +366,25 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
             mx = max2f(mx, s[qi][3][3]);
             mx = xor16_max(mx);
             mx = xor32_max(mx);
-            mxs[qi] = mx;
-            any_up = any_up || (mx > m_run[qi] + DEFER);     // first tile: m_run = -inf -> true
+            mxs[qi] = mx;                                    // the tile's maximum RELATIVE to the running one
+            any_up = any_up || (mx > DEFER);
         }
-        if (__builtin_amdgcn_ballot_w64(any_up) != 0ull) {
+        if (j == 0 || __builtin_amdgcn_ballot_w64(any_up) != 0ull) {
+            // the rare path (always the first tile: its maximum becomes the reference, whatever its sign): move the reference by d,
+            // rescale what was accumulated against the old one, and shift this tile's scores -- after which the common path below
+            // exponentiates the accumulators as they are
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) {
-                const float m_new = (mxs[qi] > m_run[qi] + DEFER) ? mxs[qi] : m_run[qi];
-                const float alpha = __builtin_amdgcn_exp2f((m_run[qi] - m_new) * LOG2E);   // exp2(-inf) = 0 on the first tile
-                m_run[qi] = m_new;
+                const float d = (j == 0 || mxs[qi] > DEFER) ? mxs[qi] : 0.f;
+                const float alpha = j == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);   // (nothing accumulated yet on the first tile)
+                m_run[qi] += d;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
                 lacc[qi] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) s[qi][sub] -= d;
             }
         }
-#pragma unroll
-        for (int qi = 0; qi < QB; ++qi) nmc[qi] = -m_run[qi] * LOG2E;
         const unsigned vb0 = (unsigned)sb;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
             for (int qi = 0; qi < QB; ++qi)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pb[qi][e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][2 * half][e], LOG2E, nmc[qi]));
-                    pb[qi][4 + e] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][2 * half + 1][e], LOG2E, nmc[qi]));
+                    pb[qi][e] = (bf16_t)__builtin_amdgcn_exp2f(s[qi][2 * half][e]);
+                    pb[qi][4 + e] = (bf16_t)__builtin_amdgcn_exp2f(s[qi][2 * half + 1][e]);
                 }
             // the wait names the registers the transposing reads fill, so that no consumer can be scheduled above it
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
             bf16_t* orow = out + ((int64_t)b * N + q) * D + h * HD;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) Vec4<bf16_t>::store(orow + dt * 16 + 4 * g, o[qi][dt] * inv);
-            if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run[qi] + logf(l_run);
+            if (g == 0 && lse) lse[(int64_t)bh * N + q] = m_run[qi] * 0.69314718055994531f + logf(l_run);   // m_run is in log2 units
         }
     }
 }
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     for (int qi = 0; qi < QB; ++qi) {
         const int q = q0 + 16 * qi;
         const bool qok = q < N;
-        qf[qi] = rowfrag_global<bf16_t>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
+        qf[qi] = rowfrag_global<bf16_t>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f * 1.4426950408889634f);   // as in the forward kernel
         dof[qi] = rowfrag_global<bf16_t>(qok ? dout + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
         nl2q[qi] = qok ? nl2_b[q] : 0.f;
         d_q[qi] = qok ? dsum_b[q] : 0.f;
@@ -562,7 +570,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                 const bf16x8 v0 = *(const bf16x8*)(kad0 + off + OPB), v1 = *(const bf16x8*)(kad1 + off + OPB);
 #pragma unroll
                 for (int qi = 0; qi < QB; ++qi) {
-                    s[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    // log2-unit scores starting from -lse * log2 e: the accumulator IS log2 of the probability
+                    s[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{nl2q[qi], nl2q[qi], nl2q[qi], nl2q[qi]}, 0, 0, 0);
                     s[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][su], 0, 0, 0);      // S^T[key][query]
                     dp[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, dof[qi].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     dp[qi][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, dof[qi].v[1], dp[qi][su], 0, 0, 0);   // dP^T[key][query]
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                 for (int su = 0; su < 2; ++su)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qi][su][e], LOG2E, nl2q[qi]));
+                        const float pe = __builtin_amdgcn_exp2f(s[qi][su][e]);
                         dsb[qi][4 * su + e] = (bf16_t)(pe * (dp[qi][su][e] - d_q[qi]));
                     }
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
 #pragma unroll
     for (int ki = 0; ki < KB; ++ki) {
         const int key = key0 + 16 * ki;
-        kf[ki] = rowfrag_global<bf16_t>(key < N ? kb + (int64_t)key * ld : nullptr, g, 0.125f);
+        kf[ki] = rowfrag_global<bf16_t>(key < N ? kb + (int64_t)key * ld : nullptr, g, 0.125f * 1.4426950408889634f);   // hd^-0.5 and log2 e on K here
         vf[ki] = rowfrag_global<bf16_t>(key < N ? vb + (int64_t)key * ld : nullptr, g, 1.0f);
     }
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (unsigned)(((int64_t)(N - 1) * ld + HD) * 2), 0x00020000);
@@ -698,7 +707,8 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
                 const bf16x8 o0 = *(const bf16x8*)(rad0 + off + OPB), o1 = *(const bf16x8*)(rad1 + off + OPB);
 #pragma unroll
                 for (int ki = 0; ki < KB; ++ki) {
-                    s[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[ki].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    // (the query is on the accumulator rows here: the four rows' -lse * log2 e are exactly the C operand)
+                    s[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, kf[ki].v[0], nl2v[su], 0, 0, 0);
                     s[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, kf[ki].v[1], s[ki][su], 0, 0, 0);      // S[query][key]
                     dp[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o0, vf[ki].v[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     dp[ki][su] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(o1, vf[ki].v[1], dp[ki][su], 0, 0, 0);    // dP[query][key]
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
                 for (int su = 0; su < 2; ++su)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[ki][su][e], LOG2E, nl2v[su][e]));
+                        const float pe = __builtin_amdgcn_exp2f(s[ki][su][e]);
                         pb[ki][4 * su + e] = (bf16_t)pe;
                         dsb[ki][4 * su + e] = (bf16_t)(pe * (dp[ki][su][e] - dsv[su][e]));
                     }

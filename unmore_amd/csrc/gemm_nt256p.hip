@@ -563,15 +563,44 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // products of a row are summed over the 4 lanes that share it (fq) and written per 64-column wave slice
             // They were brought into the (idle) staging region by LDS-DMA at the start of the tile -- a global load here would
             // be waited for on the spot, behind the next tile's prefetched K-tiles -- and are read out before pass 0 reuses it.
-            f32x4 rw[2][4];
+            // Round 4: the dot products run on the MATRIX pipe.  Per 16-row block the wave's 16 x 64 slice of C (bf16, as stored) is the
+            // B operand of two 16x16x32 MFMAs -- a lane holds row frow, columns ntl*16 + 4 fq + e: eight values per pair of ntl, a
+            // permutation of the k index that the weight fragment simply shares -- against A = the reduction weights, row c = lane & 15
+            // (rows >= red_c are zero), as hi + lo bf16 halves (16 significant bits).  D[c][row] lands in the lanes fq == 0, registers
+            // 0 / 1 = outputs 0 / 1: no shuffles.  32 MFMAs per wave and tile instead of ~100 conversions + FMAs per lane and pass:
+            // the VALU form made this epilogue 26.5 k cycles of a 55 k-cycle tile (s_memtime stamps, profiles/r04_ts_probe_head_1x1.txt).
+            bf16x8 rwh[2], rwl[2];
             if (RED) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c)
+                for (int pr = 0; pr < 2; ++pr) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+                    if (frow < 2) {
+                        a = *(const f32x4*)(smem + STG_OFF + frow * 1024 + (wc * 64 + (2 * pr) * 16 + fq * 4) * 4);
+                        b = *(const f32x4*)(smem + STG_OFF + frow * 1024 + (wc * 64 + (2 * pr + 1) * 16 + fq * 4) * 4);
+                    }
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl)
-                        rw[c][ntl] = *(const f32x4*)(smem + STG_OFF + c * 1024 + (wc * 64 + ntl * 16 + fq * 4) * 4);
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = e < 4 ? a[e] : b[e - 4];
+                        const bf16_t hi = (bf16_t)x;
+                        rwh[pr][e] = hi;
+                        rwl[pr][e] = (bf16_t)(x - (float)hi);
+                    }
+                }
                 __syncthreads();
             }
+            // partial dot products of one 16-row block: t01 / t23 = the lane's bf16 values of column blocks (0,1) / (2,3)
+            auto row_reduce = [&](const bf16x8& t01, const bf16x8& t23, int mt_) {
+                f32x4 red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[0], t01, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[0], t01, red, 0, 0, 0);
+                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[1], t23, red, 0, 0, 0);
+                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[1], t23, red, 0, 0, 0);
+                const int m = m0 + wr * 128 + mt_ * 16 + frow;
+                if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
+                    float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
+                    ro[0] = red[0];
+                    if (p.red_c == 2) ro[1] = red[1];
+                }
+            };
             // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
             // 512-byte row segments (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per
             // instruction, and the epilogue of a residual-add GEMM took 25 k cycles against 6.7 k without aux).  Loads are issued
@@ -602,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
                     const int lr = wr * 32 + mh * 16 + frow;
-                    float rs0 = 0.f, rs1 = 0.f;
+                    bf16x8 tq[2];     // the values AS STORED (bf16-rounded), column blocks (0,1) and (2,3)
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
                         f32x4 v = acc[PS * 2 + mh][ntl];
@@ -614,21 +643,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
                         const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
                         *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
-                        if (RED) {   // dot products with the values AS STORED (bf16-rounded)
+                        if (RED) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { rs0 += (float)t[e] * rw[0][ntl][e]; rs1 += (float)t[e] * rw[1][ntl][e]; }
+                            for (int e = 0; e < 4; ++e) tq[ntl >> 1][(ntl & 1) * 4 + e] = t[e];
                         }
                     }
-                    if (RED) {
-                        rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
-                        rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
-                        const int m = m0 + wr * 128 + (PS * 2 + mh) * 16 + frow;
-                        if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
-                            float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
-                            ro[0] = rs0;
-                            if (p.red_c == 2) ro[1] = rs1;
-                        }
-                    }
+                    if (RED) row_reduce(tq[0], tq[1], PS * 2 + mh);
                 }
                 __syncthreads();
 #pragma unroll
@@ -660,25 +680,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 // through LDS and no barrier is needed -- the dot products are taken on the bf16-rounded values in registers
 #pragma unroll
                 for (int mt = 0; mt < 8; ++mt) {
-                    float rs0 = 0.f, rs1 = 0.f;
+                    bf16x8 tq[2];
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
-                        f32x4 v = acc[mt][ntl];
+                        const f32x4 v = acc[mt][ntl];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float t = (float)(bf16_t)fmaxf(v[e], relu_floor);
-                            rs0 += t * rw[0][ntl][e];
-                            rs1 += t * rw[1][ntl][e];
-                        }
+                        for (int e = 0; e < 4; ++e) tq[ntl >> 1][(ntl & 1) * 4 + e] = (bf16_t)fmaxf(v[e], relu_floor);
                     }
-                    rs0 += __shfl_xor(rs0, 16, 64); rs0 += __shfl_xor(rs0, 32, 64);
-                    rs1 += __shfl_xor(rs1, 16, 64); rs1 += __shfl_xor(rs1, 32, 64);
-                    const int m = m0 + wr * 128 + mt * 16 + frow;
-                    if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
-                        float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
-                        ro[0] = rs0;
-                        if (p.red_c == 2) ro[1] = rs1;
-                    }
+                    row_reduce(tq[0], tq[1], mt);
                 }
             } else {
                 pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});

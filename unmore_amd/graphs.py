@@ -27,6 +27,7 @@ DEFAULT_MODE = os.environ.get("UMR_GRAPHS", "auto")
 # the 384^2 / 518^2 batches (9.4 M / 4.3 M: < 0.1 % of the step is launch gaps) are above
 AUTO_MAX_PIXELS = int(os.environ.get("UMR_GRAPHS_AUTO_MAX_PIXELS", str(1 << 20)))
 WARMUP_CALLS = 2
+MAX_CAPTURES = 8     # per net (inference): shapes x streams
 
 
 def capturing():

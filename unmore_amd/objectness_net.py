@@ -303,6 +303,11 @@ class ObjectnessNet(nn.Module):
                 n = (ent or 0) + 1
                 store[key] = n
                 if n > graphs.WARMUP_CALLS:
+                    # every capture keeps its own pool of temporaries alive: a caller that cycles through many shapes gets at most
+                    # MAX_CAPTURES of them (then all are dropped and the current shapes are captured again as they recur)
+                    if sum(isinstance(v, graphs.Captured) for v in store.values()) >= graphs.MAX_CAPTURES:
+                        for k in [k for k, v in store.items() if isinstance(v, graphs.Captured)]:
+                            del store[k]
                     cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation)
                     store[key] = cap
                     if cap.failed is None:

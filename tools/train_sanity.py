@@ -3,7 +3,7 @@ flags, Adam 1e-4, N steps on a small pool of synthetic batches (images: structur
 five loss values and the allocator's current / peak bytes every 20 steps and checks that the total falls in 50-step averages (no
 rise above 2 %) and stays finite.
     python tools/train_sanity.py [steps=200] [batches=4] [fp32_steps=0]
-TRAIN_SANITY_CFG=ref runs the reference's own recipe instead (dpt_large, 128 x 128, batch 20: the small-problem kernels, split-K).
+TRAIN_SANITY_DTYPE=fp32 trains in the fp32 parity mode instead of bf16.  TRAIN_SANITY_CFG=ref runs the reference's own recipe instead (dpt_large, 128 x 128, batch 20: the small-problem kernels, split-K).
 With fp32_steps > 0 the first steps are repeated in fp32 parity mode from the same initial weights on the same batches and the two
 loss trajectories are compared (bf16 storage must track fp32 within a few 1e-3 per step)."""
 import os
@@ -27,7 +27,8 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = ObjectnessNet(dev, SIZE, BACKBONE, Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
 init = {k: v.detach().clone() for k, v in net.state_dict().items()}
-net.set_compute_dtype(torch.bfloat16)
+DT = torch.float32 if os.environ.get("TRAIN_SANITY_DTYPE") == "fp32" else torch.bfloat16   # fp32: the parity mode on the bf16-plane kernels
+net.set_compute_dtype(DT)
 net.train()
 step = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
 pool = []

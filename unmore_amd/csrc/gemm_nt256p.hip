@@ -976,53 +976,52 @@ static bool umr_nt256p_gelu_epilogue(const umr_gemm_desc* d) {
 }
 
 // eligibility: plain NT GEMM without A-row remap, or stride-1 3x3 conv (checked by the caller, gemm_nt256.hip)
-// K-split of a plane GEMM (see the kernel): how many runs.  Cost model in plane-pair steps: a round of work items on the chip takes
-// (steps per item + ~8 for its first loads and its store); splitting adds the slab round trip and the finish launch (~12).
-static int x3_pick_ksplit(const umr_gemm_desc* d, int64_t tiles, int cus, int npairs, int64_t ws_bytes) {
-    if (d->red_w) return 1;
+// Tile height and K-split of a plane GEMM (see the kernel), chosen together.  Cost model in plane-pair steps of a 256-row tile
+// (~1.5 us): a round of work items on the chip takes (steps per item x bm / 256 + ~8 for its first loads and its store); splitting adds
+// the finish launch (~8) and its slab traffic (ks x M x N x 4 bytes at ~3 TB/s).  Checked against a sweep of forced caps at the
+// reference recipe's shapes (profiles/r04_x3_ksplit_sweep.txt): within 4 % of the best cap in every column.
+static void x3_plan(const umr_gemm_desc* d, int cus, int npairs, int64_t ws_bytes, int* bm_out, int* ks_out) {
+    const int tiles_n = (d->N + BN2 - 1) / BN2;
     const int kt = d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2);
     static const int forced = umr_env_int("UMR_X3_KSPLIT", 0);   // 0 = cost model; n = at most n runs (1 disables)
+    const char* bm_e = getenv("UMR_NT256_BM");                   // read per launch: tests switch it inside one process
+    const int bm_env = bm_e ? atoi(bm_e) : 0;
     const int64_t slab = (int64_t)d->M * d->N * 4;
-    int best = 1;
+    int best_ks = 1, best_bm = BM2;
     double best_cost = 1e300;
-    for (int ks = 1; ks <= 32 && ks * 2 <= kt + 1; ++ks) {
-        if (forced > 0 && ks > forced) break;
-        if (ks > 1 && (int64_t)ks * slab > ws_bytes) break;
-        const int per = (kt + ks - 1) / ks;
-        const int runs = (kt + per - 1) / per;          // no empty run
-        if (runs != ks) continue;
-        const int64_t rounds = (tiles * ks + cus - 1) / cus;
-        const double cost = (double)rounds * (per * npairs + 8) + (ks > 1 ? 12.0 : 0.0);
-        if (cost < best_cost * 0.97) { best_cost = cost; best = ks; }   // a split has to pay for itself
+    for (int bm = BM2; bm >= (d->conv == 0 ? 192 : BM2); bm -= 32) {
+        if (d->conv == 0 && (bm_env == 256 || bm_env == 224 || bm_env == 192) && bm != bm_env) continue;
+        const int64_t tiles = (int64_t)((d->M + bm - 1) / bm) * tiles_n;
+        for (int ks = 1; ks <= 32 && ks * 2 <= kt + 1; ++ks) {
+            if (d->red_w && ks > 1) break;
+            if (forced > 0 && ks > forced) break;
+            if (ks > 1 && ((int64_t)ks * slab > ws_bytes)) break;
+            const int per = (kt + ks - 1) / ks;
+            if ((kt + per - 1) / per != ks) continue;            // no empty run
+            const int64_t rounds = (tiles * ks + cus - 1) / cus;
+            const double cost = (double)rounds * (per * npairs * (bm / 256.0) + 8.0) + (ks > 1 ? 8.0 + (double)ks * slab / 4.5e6 : 0.0);
+            // ties go to the larger tile; MORE runs have to buy 10 % (measured: the 64x64-map conv is flat within 3 % from 2 to 8
+            // runs, and 3 runs -- 1.33 channel chunks each -- are 20 % slower than 2)
+            if (cost < best_cost * (ks > best_ks ? 0.90 : 0.98)) { best_cost = cost; best_ks = ks; best_bm = bm; }
+        }
     }
-    return best;
+    *bm_out = best_bm;
+    *ks_out = best_ks;
 }
 
 extern "C" int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d) {
     if (d == nullptr || d->dtype != UMR_BF16X3 || d->M <= 0 || d->N <= 0 || d->K <= 0) return 0;
-    const int npairs = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
-    int ks = 1;
-    for (int bm = 256; bm >= (d->conv == 0 ? 192 : 256); bm -= 32) {   // whichever tile height the launcher picks
-        const int k = x3_pick_ksplit(d, (int64_t)((d->M + bm - 1) / bm) * ((d->N + BN2 - 1) / BN2), num_cus(), npairs, (int64_t)1 << 40);
-        if (k > ks) ks = k;
-    }
+    int bm, ks;
+    x3_plan(d, num_cus(), umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6, (int64_t)1 << 40, &bm, &ks);
     return ks > 1 ? (int64_t)ks * d->M * d->N * 4 : 0;
 }
 
 // the number of K runs umr_launch_gemm_nt256p_ws would use for this plane problem with `ws_bytes` of slab space
 int umr_x3_ksplit_of(const umr_gemm_desc* d, int64_t ws_bytes) {
-    if (d->red_w || ws_bytes <= 0) return 1;
-    const int tiles_n = (d->N + BN2 - 1) / BN2, cus = num_cus();
-    int bm = BM2;
-    if (d->conv == 0 && (int64_t)((d->M + BM2 - 1) / BM2) * tiles_n <= 16ll * cus) {
-        double best = 1e300;
-        for (int c = 256; c >= 192; c -= 32) {
-            const int64_t t = (int64_t)((d->M + c - 1) / c) * tiles_n;
-            const double cost = (double)((t + cus - 1) / cus) * (0.25 + 0.75 * c / 256.0);
-            if (cost < best - 1e-9) { best = cost; bm = c; }
-        }
-    }
-    return x3_pick_ksplit(d, (int64_t)((d->M + bm - 1) / bm) * tiles_n, cus, umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6, ws_bytes);
+    if (ws_bytes <= 0) return 1;
+    int bm, ks;
+    x3_plan(d, num_cus(), umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6, ws_bytes, &bm, &ks);
+    return ks;
 }
 
 int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
@@ -1038,7 +1037,7 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     const char* bm_e = getenv("UMR_NT256_BM");   // read per launch: tests switch it inside one process
     const int bm_env = bm_e ? atoi(bm_e) : 0;
     int bm = BM2;
-    if (d->conv == 0 && (d->dtype == UMR_BF16 || d->dtype == UMR_BF16X3)) {
+    if (d->conv == 0 && d->dtype == UMR_BF16) {
         if (bm_env == 256 || bm_env == 224 || bm_env == 192) bm = bm_env;
         else if ((int64_t)((d->M + BM2 - 1) / BM2) * tiles_n <= 16ll * cus) {
             double best = 1e300;
@@ -1049,9 +1048,10 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
             }
         }
     }
-    const int tiles_m = (d->M + bm - 1) / bm;
     const int npairs_x3 = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
-    const int ksplit = (d->dtype == UMR_BF16X3 && ws != nullptr) ? x3_pick_ksplit(d, (int64_t)tiles_m * tiles_n, cus, npairs_x3, ws_bytes) : 1;
+    int ksplit = 1;
+    if (d->dtype == UMR_BF16X3) x3_plan(d, cus, npairs_x3, ws != nullptr ? ws_bytes : 0, &bm, &ksplit);
+    const int tiles_m = (d->M + bm - 1) / bm;
     const int64_t total = (int64_t)tiles_m * tiles_n;
     // One workgroup fits a CU (160 KiB LDS).  The grid is a small multiple of the CU count, not exactly the CU count: if
     // some CUs are busy when the kernel starts (an RCCL all-reduce of the previous gradient bucket runs beside backward),

@@ -86,3 +86,50 @@ def test_argument_errors_are_reported_without_a_gpu():
     buf = ctypes.create_string_buffer(64)
     assert lib.umr_gemm_nt_ws(ctypes.byref(d), ctypes.cast(buf, ctypes.c_void_p), 64, None) != 0
     assert b"workspace" in lib.umr_last_error_string()
+
+
+def test_flat_layout_buckets_follow_backward_completion_order():
+    """trainer.flat_layout (shared by TrainStep and bench.py --rehearse): every grad-receiving parameter has a 256-byte aligned
+    slot, parameters the reference never back-propagates into have none, and the bucket boundaries follow the order in which
+    backward completes the stages (heads, refinenets, reassemble, blocks last..first, embeddings)."""
+    from argparse import Namespace
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd.trainer import flat_layout
+    net = ObjectnessNet("cpu", 64, "dpt_base", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    offs, bounds, stage_bucket = flat_layout(net)
+    named = dict(net.named_parameters())
+    assert set(offs) == set(named) - net.nograd_names()
+    assert all(o % 64 == 0 for o in offs.values()) and bounds[0] == 0 and bounds == sorted(bounds)
+    assert len(bounds) - 1 == 16 and list(stage_bucket)[:3] == ["heads", "refine", "reassemble"] and list(stage_bucket)[-1] == "embed"
+    assert list(stage_bucket)[3] == "block11" and stage_bucket["block0"] == 14
+    assert 115_000_000 < bounds[-1] < 116_000_000          # SURVEY 8e: 115,400,899 elements + alignment padding
+    for n, o in offs.items():                               # every slot lies inside its stage's bucket
+        k = [i for i in range(16) if bounds[i] <= o < bounds[i + 1]]
+        assert len(k) == 1 and o + named[n].numel() <= bounds[k[0] + 1]
+
+
+def test_graph_and_stream_policies():
+    """graphs.wanted / WgradStream.wanted: 'auto' captures small inference calls only, train steps never; the second stream serves
+    small problems only (the 384x384 batches fill the chip and keep one stream)."""
+    from unmore_amd import engine, graphs
+    small, big = 20 * 128 * 128, 64 * 384 * 384
+    assert graphs.wanted("auto", small) and not graphs.wanted("auto", big) and not graphs.wanted("auto", small, train=True)
+    assert graphs.wanted("on", big, train=True) and not graphs.wanted("off", small)
+    assert engine.WgradStream.wanted(small) and not engine.WgradStream.wanted(big)
+
+
+def test_xt_views_share_one_cell():
+    """engine_x3.XT: a value held as f32 and / or bf16 planes; views share the cell, so a conversion made through one view is
+    visible through every other (no second split pass)."""
+    import torch
+    from unmore_amd.engine_x3 import XT
+    f = torch.arange(24, dtype=torch.float32).view(2, 3, 4)
+    x = XT(f=f)
+    v = x.view(6, 4)
+    assert v.shape == (6, 4) and x.shape == (2, 3, 4) and v.f.data_ptr() == f.data_ptr() and v.p is None
+    planes = torch.zeros((6, 12), dtype=torch.bfloat16)
+    v.cell[1] = planes                       # what P() stores after split3 on the GPU
+    assert x.p.shape == (2, 3, 12) and x.p.data_ptr() == planes.data_ptr() and x.n == 4
+    assert x.mask_source().data_ptr() == f.data_ptr()
+    x.drop_f()
+    assert v.f is None and v.any().data_ptr() == planes.data_ptr() and v.mask_source().shape == (6, 4)

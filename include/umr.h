@@ -210,6 +210,17 @@ int umr_attention_bwd(const void* qkv, const void* out, const void* dout, const 
 int umr_patchify(const float* images, void* out, int B, int H, int W, int patch, int ldk, int dtype, umr_stream_t stream);
 int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, umr_stream_t stream);
 int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype, umr_stream_t stream);
+/* The same resizes on maps that are column slices of wider row-major buffers: ldx / ldy (lddy / lddx) = elements between consecutive
+ * pixels, 0 = C.  flags (forward): UMR_BILINEAR_RELU = max(., 0) on the result (a ReLU that follows the resize: the heads' first
+ * layer runs BEFORE the final x2 interpolation of models.py:70-72 -- a 1x1 convolution and a bilinear resize commute exactly -- and
+ * objectness_net.py:111's ReLU after it); UMR_BILINEAR_OUT_X3 (dtype f32, C and ldy multiples of 8) = the result as three bf16
+ * planes per pixel [h(C) | m(C) | l(C)], ldy in bf16 elements (>= 3 C): the operand format of the UMR_BF16X3 GEMMs. */
+#define UMR_BILINEAR_RELU 1
+#define UMR_BILINEAR_OUT_X3 2
+int umr_bilinear_fwd_ex(const void* x, int64_t ldx, void* y, int64_t ldy, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                        int flags, int dtype, umr_stream_t stream);
+int umr_bilinear_bwd_ex(const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                        int align_corners, int dtype, umr_stream_t stream);
 int umr_pixel_shuffle(const void* src, void* dst, int B, int H, int W, int s, int C, int inverse, int dtype, umr_stream_t stream);
 int umr_zero_stuff2(const void* dy, void* out, int B, int H, int W, int Ho, int Wo, int C, int dtype, umr_stream_t stream);
 int umr_permute4(const void* src, void* dst, const int32_t* dst_dims, const int64_t* src_strides, int64_t src_offset,
@@ -297,6 +308,12 @@ int umr_linear_head_bwd_data(const float* dout, const float* yout, const float* 
 int64_t umr_linear_head_bwd_weight_workspace(int64_t M, int C);
 int umr_linear_head_bwd_weight(const void* x, const float* dout, const float* yout, float* out, void* workspace,
                                int64_t workspace_bytes, int B, int H, int W, int C, int act, int dtype, umr_stream_t stream);
+/* shift9: s9[q][t] = g(q - off_t) (t < 9; zero outside the image and for 9 <= t < 16), a [B*H*W][16] map of `dtype`; nd[16] f32 =
+ * n[0..8], D, zeros.  G[t] = sum_q s9[q][t] x(q) and dx(q) = sum_t s9[q][t] kw[t] are then ordinary TN / NT products -- and when x is
+ * a bilinear resize of a smaller map (models.py:70-72), products on THAT map after umr_bilinear_bwd_ex of s9 (16 channels). */
+int64_t umr_linear_head_shift9_workspace(int64_t M);
+int umr_linear_head_shift9(const float* dout, const float* yout, void* s9, float* nd, void* workspace, int64_t workspace_bytes,
+                           int B, int H, int W, int act, int dtype, umr_stream_t stream);
 /* C[i*sc_m + j*sc_n] (=|+=) sum_k A[i*sa_m + k*sa_k] * B[k*sb_k + j*sb_n]  (tiny f32 products, arbitrary strides) */
 int umr_small_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sa_m, int64_t sa_k, int64_t sb_k,
                        int64_t sb_n, int64_t sc_m, int64_t sc_n, int accumulate, umr_stream_t stream);

@@ -86,6 +86,8 @@ _SIGS = {
     "umr_patchify": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_bilinear_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_bilinear_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_bilinear_fwd_ex": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_bilinear_bwd_ex": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_pixel_shuffle": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_zero_stuff2": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_permute4": [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -108,6 +110,8 @@ _SIGS = {
     "umr_linear_head_bwd_data": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_linear_head_bwd_weight_workspace": [_i64, _i32],
     "umr_linear_head_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_linear_head_shift9_workspace": [_i64],
+    "umr_linear_head_shift9": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "umr_permute4_batched": [_vp, _i32, _i64, _vp, _vp],
     "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
@@ -141,7 +145,7 @@ def lib():
         _lib.umr_last_error_string.restype = ctypes.c_char_p
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
-                   "umr_linear_head_bwd_weight_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
+                   "umr_linear_head_bwd_weight_workspace", "umr_linear_head_shift9_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
                    "umr_distance_transform_workspace", "umr_gemm_nt_workspace", "umr_gemm_nt_x3_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib

@@ -5,6 +5,7 @@
 // All are coalesced over the channel (innermost) dimension with 16-byte accesses
 // where the layout allows; no atomics (every reduction is a fixed-order two-stage sum).
 #include "umr_common.h"
+#include "gemm_epilogue.h"   // x3_planes_store8
 
 namespace {
 
@@ -46,37 +47,49 @@ __device__ __forceinline__ float area_scale(int in, int out, int align) {
 }
 
 // NV f32x4 vectors (4*NV channels) per thread: NV = 2 gives 16-byte bf16 accesses and half the index arithmetic
-template <typename T, int NV>
-__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+// ldx / ldy: elements between consecutive pixels of x / y (>= C: the maps may be column slices of wider row-major buffers);
+// relu: max(., 0) on the result; PLANES (T = float, NV = 2): the result is written as three bf16 planes [h(C) | m(C) | l(C)] per pixel
+// (ldy counts bf16 elements), the operand format of the plane GEMMs
+template <typename T, int NV, bool PLANES = false>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, void* __restrict__ yv, int B, int Hi, int Wi, int Ho, int Wo, int C, int align,
+                                    int64_t ldx, int64_t ldy, int relu) {
     // grid.y = (b, oy) pairs (strided), grid.x x 256 threads = the (ox, channel-vector) pairs of one output row: the
     // per-thread index arithmetic is one 32-bit division (the flat 64-bit form spent more time dividing than loading)
     const int cv = C / (4 * NV);
     const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
+    const float floor_ = relu ? 0.f : -INFINITY;
     for (int by = blockIdx.y; by < B * Ho; by += gridDim.y) {
         const int b = by / Ho, oy = by - b * Ho;
         int y0, y1;
         float ly0, ly1;
         src_index(oy, sh, align, Hi, y0, y1, ly0, ly1);
-        const T* r0 = x + ((int64_t)b * Hi + y0) * Wi * C;
-        const T* r1 = x + ((int64_t)b * Hi + y1) * Wi * C;
-        T* yr = y + (int64_t)by * Wo * C;
+        const T* r0 = x + ((int64_t)b * Hi + y0) * Wi * ldx;
+        const T* r1 = x + ((int64_t)b * Hi + y1) * Wi * ldx;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
             const int ox = i / cv, c = (i - ox * cv) * 4 * NV;
             int x0, x1;
             float lx0, lx1;
             src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
-            const T* p00 = r0 + (int64_t)x0 * C + c;
-            const T* p01 = r0 + (int64_t)x1 * C + c;
-            const T* p10 = r1 + (int64_t)x0 * C + c;
-            const T* p11 = r1 + (int64_t)x1 * C + c;
+            const T* p00 = r0 + (int64_t)x0 * ldx + c;
+            const T* p01 = r0 + (int64_t)x1 * ldx + c;
+            const T* p10 = r1 + (int64_t)x0 * ldx + c;
+            const T* p11 = r1 + (int64_t)x1 * ldx + c;
+            f32x4 o[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 const f32x4 v00 = Vec4<T>::load(p00 + 4 * v), v01 = Vec4<T>::load(p01 + 4 * v);
                 const f32x4 v10 = Vec4<T>::load(p10 + 4 * v), v11 = Vec4<T>::load(p11 + 4 * v);
-                f32x4 o;
-                for (int j = 0; j < 4; ++j) o[j] = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
-                Vec4<T>::store(yr + (int64_t)ox * C + c + 4 * v, o);
+                for (int j = 0; j < 4; ++j)
+                    o[v][j] = fmaxf(ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]), floor_);
+            }
+            if constexpr (PLANES) {
+                static_assert(NV == 2, "plane output works on 8 channels per thread");
+                x3_planes_store8((bf16_t*)yv + ((int64_t)by * Wo + ox) * ldy + c, C, o[0], o[1]);
+            } else {
+                T* yr = (T*)yv + ((int64_t)by * Wo + ox) * ldy + c;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) Vec4<T>::store(yr + 4 * v, o[v]);
             }
         }
     }
@@ -92,7 +105,8 @@ __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, 
 }
 
 template <typename T, int NV>
-__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align,
+                                    int64_t lddy, int64_t lddx) {
     // same 2-D decomposition as the forward: grid.y = (b, iy), grid.x covers the (ix, channel-vector) pairs of one input row
     const int cv = C / (4 * NV);
     const int rowlen = Wi * cv;
@@ -101,8 +115,8 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
         const int b = by / Hi, iy = by - b * Hi;
         int ylo, yhi;
         out_range(iy, sh, Ho, ylo, yhi);
-        const T* base = dy + (int64_t)b * Ho * Wo * C;
-        T* xr = dx + (int64_t)by * Wi * C;
+        const T* base = dy + (int64_t)b * Ho * Wo * lddy;
+        T* xr = dx + (int64_t)by * Wi * lddx;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
             const int ix = i / cv, c = (i - ix * cv) * 4 * NV;
             int xlo, xhi;
@@ -120,13 +134,13 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
                     src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
                     const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
                     if (wx == 0.f) continue;
-                    const T* gp = base + ((int64_t)oy * Wo + ox) * C + c;
+                    const T* gp = base + ((int64_t)oy * Wo + ox) * lddy + c;
 #pragma unroll
                     for (int v = 0; v < NV; ++v) acc[v] += Vec4<T>::load(gp + 4 * v) * (wy * wx);
                 }
             }
 #pragma unroll
-            for (int v = 0; v < NV; ++v) Vec4<T>::store(xr + (int64_t)ix * C + c + 4 * v, acc[v]);
+            for (int v = 0; v < NV; ++v) Vec4<T>::store(xr + (int64_t)ix * lddx + c + 4 * v, acc[v]);
         }
     }
 }
@@ -141,15 +155,16 @@ __device__ __forceinline__ void ld_bf16x8(const bf16_t* p, float (&f)[8]) {
 // forward: a thread computes the same (ox, 8 channels) of FOUR consecutive output rows: its 16 loads are issued before the first
 // is used (one element per thread left the kernel latency-bound at 3.4 TB/s: tools/bilinear_bench.py)
 __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
-                                                                int Wo, int C, int align) {
+                                                                int Wo, int C, int align, int64_t ldx, int64_t ldy, int relu) {
     constexpr int R = 4;
+    const float floor_ = relu ? 0.f : -INFINITY;
     const int cv = C >> 3;
     const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
     const int groups = (Ho + R - 1) / R;
     for (int bg = blockIdx.y; bg < B * groups; bg += gridDim.y) {
         const int b = bg / groups, oy0 = (bg - b * groups) * R;
-        const bf16_t* xb = x + (int64_t)b * Hi * Wi * C;
+        const bf16_t* xb = x + (int64_t)b * Hi * Wi * ldx;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
             const int ox = i / cv, c = (i - ox * cv) * 8;
             int x0, x1;
@@ -162,12 +177,12 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
                 const int oy = min(oy0 + r, Ho - 1);
                 int y0, y1;
                 src_index(oy, sh, align, Hi, y0, y1, ly0[r], ly1[r]);
-                const bf16_t* r0 = xb + (int64_t)y0 * Wi * C + c;
-                const bf16_t* r1 = xb + (int64_t)y1 * Wi * C + c;
-                t[r][0] = *(const bf16x8*)(r0 + (int64_t)x0 * C);
-                t[r][1] = *(const bf16x8*)(r0 + (int64_t)x1 * C);
-                t[r][2] = *(const bf16x8*)(r1 + (int64_t)x0 * C);
-                t[r][3] = *(const bf16x8*)(r1 + (int64_t)x1 * C);
+                const bf16_t* r0 = xb + (int64_t)y0 * Wi * ldx + c;
+                const bf16_t* r1 = xb + (int64_t)y1 * Wi * ldx + c;
+                t[r][0] = *(const bf16x8*)(r0 + (int64_t)x0 * ldx);
+                t[r][1] = *(const bf16x8*)(r0 + (int64_t)x1 * ldx);
+                t[r][2] = *(const bf16x8*)(r1 + (int64_t)x0 * ldx);
+                t[r][3] = *(const bf16x8*)(r1 + (int64_t)x1 * ldx);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -175,8 +190,8 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    o[j] = (bf16_t)(ly0[r] * (lx0 * (float)t[r][0][j] + lx1 * (float)t[r][1][j]) + ly1[r] * (lx0 * (float)t[r][2][j] + lx1 * (float)t[r][3][j]));
-                *(bf16x8*)(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * C + c) = o;
+                    o[j] = (bf16_t)fmaxf(ly0[r] * (lx0 * (float)t[r][0][j] + lx1 * (float)t[r][1][j]) + ly1[r] * (lx0 * (float)t[r][2][j] + lx1 * (float)t[r][3][j]), floor_);
+                *(bf16x8*)(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c) = o;
             }
         }
     }
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
 // a per-tap `continue` left one load in flight per thread (3.3 TB/s on the final x2 resize).
 template <int NCX>
 __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int Hi, int Wi, int Ho,
-                                                                int Wo, int C, int align) {
+                                                                int Wo, int C, int align, int64_t lddy, int64_t lddx) {
     constexpr int NC = 8;
     const int cv = C >> 3;
     const int rowlen = Wi * cv;
@@ -215,20 +230,20 @@ __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* 
         weights(ix, sw, Wi, Wo, xlo, wx);
         int xoff[NCX];       // element offsets of the NCX candidate columns, clamped inside the row
 #pragma unroll
-        for (int kx = 0; kx < NCX; ++kx) xoff[kx] = ((xlo + kx < Wo ? xlo + kx : Wo - 1) - xlo) * C;
+        for (int kx = 0; kx < NCX; ++kx) xoff[kx] = ((xlo + kx < Wo ? xlo + kx : Wo - 1) - xlo) * (int)lddy;
         for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
             const int b = by / Hi, iy = by - b * Hi;
             int ylo;
             float wy[NC];
             weights(iy, sh, Hi, Ho, ylo, wy);
-            const bf16_t* base = dy + (int64_t)b * Ho * Wo * C + (int64_t)xlo * C + c;
+            const bf16_t* base = dy + (int64_t)b * Ho * Wo * lddy + (int64_t)xlo * lddy + c;
             float acc[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
             for (int ky = 0; ky < NC; ++ky) {
                 if (wy[ky] == 0.f) continue;          // block-uniform
-                const bf16_t* rowp = base + (int64_t)(ylo + ky) * Wo * C;
+                const bf16_t* rowp = base + (int64_t)(ylo + ky) * Wo * lddy;
                 bf16x8 t[NCX];
 #pragma unroll
                 for (int kx = 0; kx < NCX; ++kx) t[kx] = *(const bf16x8*)(rowp + xoff[kx]);
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* 
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
-            *(bf16x8*)(dx + ((int64_t)by * Wi + ix) * C + c) = o;
+            *(bf16x8*)(dx + ((int64_t)by * Wi + ix) * lddx + c) = o;
         }
     }
 }
@@ -934,34 +949,54 @@ static int bilinear_gy_cap() {
     return v > 0 ? v : 65535;
 }
 
-extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
-                                umr_stream_t stream) {
+// flags: UMR_BILINEAR_RELU = max(., 0) on the result; UMR_BILINEAR_OUT_X3 (dtype f32, C % 8 == 0) = the result as three bf16 planes per
+// pixel, ldy in bf16 elements (>= 3 C).  ldx / ldy: elements between consecutive pixels (0 = C: dense maps)
+extern "C" int umr_bilinear_fwd_ex(const void* x, int64_t ldx, void* y, int64_t ldy, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                   int align_corners, int flags, int dtype, umr_stream_t stream) {
     UMR_CHECK_ARG(x && y && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_fwd: bad arguments");
+    const bool planes = (flags & UMR_BILINEAR_OUT_X3) != 0;
+    const int relu = (flags & UMR_BILINEAR_RELU) ? 1 : 0;
+    if (ldx == 0) ldx = C;
+    if (ldy == 0) ldy = planes ? 3 * (int64_t)C : C;
+    UMR_CHECK_ARG(ldx >= C && ldy >= (planes ? 3 * (int64_t)C : C) && ldx % 4 == 0 && ldy % 4 == 0, "bilinear_fwd: ldx / ldy smaller than a pixel or not a multiple of 4");
+    UMR_CHECK_ARG(!planes || (dtype == UMR_F32 && C % 8 == 0 && ldy % 8 == 0), "bilinear_fwd: plane output needs f32 input, C and ldy multiples of 8");
     hipStream_t s = (hipStream_t)stream;
     {
-        const int nv = (C % 8 == 0) ? 2 : 1;
+        const int nv = (C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0) ? 2 : 1;
         const int rowlen = Wo * (C / (4 * nv));
         int64_t gy = (int64_t)B * Ho;
         if (gy > bilinear_gy_cap()) gy = bilinear_gy_cap();
         const dim3 g((unsigned)((rowlen + 255) / 256), (unsigned)gy);
-        if (nv == 2 && dtype == UMR_BF16) {
+        if (planes) {
+            hipLaunchKernelGGL((bilinear_fwd_kernel<float, 2, true>), g, dim3(256), 0, s, (const float*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu);
+        } else if (nv == 2 && dtype == UMR_BF16) {
             int64_t gy4 = (int64_t)B * ((Ho + 3) / 4);
             if (gy4 > bilinear_gy_cap()) gy4 = bilinear_gy_cap();
-            hipLaunchKernelGGL(bilinear_fwd_bf16x8_kernel, dim3(g.x, (unsigned)gy4), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, align_corners);
+            hipLaunchKernelGGL(bilinear_fwd_bf16x8_kernel, dim3(g.x, (unsigned)gy4), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu);
         }
-        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
-        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)x, (T*)y, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu)); }
+        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu)); }
     }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }
 
-extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
+extern "C" int umr_bilinear_fwd(const void* x, void* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
                                 umr_stream_t stream) {
+    return umr_bilinear_fwd_ex(x, 0, y, 0, B, Hi, Wi, Ho, Wo, C, align_corners, 0, dtype, stream);
+}
+
+// lddy / lddx: elements between consecutive pixels of dy / dx (0 = C)
+extern "C" int umr_bilinear_bwd_ex(const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hi, int Wi, int Ho, int Wo, int C,
+                                   int align_corners, int dtype, umr_stream_t stream) {
     UMR_CHECK_ARG(dy && dx && B > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 4 == 0, "bilinear_bwd: bad arguments");
+    if (lddy == 0) lddy = C;
+    if (lddx == 0) lddx = C;
+    UMR_CHECK_ARG(lddy >= C && lddx >= C && lddy % 4 == 0 && lddx % 4 == 0 && (int64_t)Wo * lddy < ((int64_t)1 << 31),
+                  "bilinear_bwd: lddy / lddx smaller than a pixel, not a multiple of 4, or a dy row of 2^31 elements");
     hipStream_t s = (hipStream_t)stream;
     {
-        const int nv = (C % 8 == 0) ? 2 : 1;
+        const int nv = (C % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0) ? 2 : 1;
         const int rowlen = Wi * (C / (4 * nv));
         int64_t gy = (int64_t)B * Hi;
         if (gy > bilinear_gy_cap()) gy = bilinear_gy_cap();
@@ -974,14 +1009,19 @@ extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi,
             // 1.57-1.59 with 3-12 on the final x2 resize at cfg2, tools/bilinear_bench.py)
             if (getenv("UMR_BILINEAR_GY") == nullptr && g.y > 2048) g.y = 2048;
             // align_corners: contributors of input column i are the outputs o with o * sw in (i - 1, i + 1): at most lo + 5 for sw >= 0.49
-            if (align_corners && sw_ >= 0.49f) hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<6>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
-            else hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<8>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners);
+            if (align_corners && sw_ >= 0.49f) hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<6>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx);
+            else hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<8>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx);
         }
-        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
-        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners)); }
+        else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx)); }
+        else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx)); }
     }
     UMR_LAUNCH_CHECK();
     return UMR_OK;
+}
+
+extern "C" int umr_bilinear_bwd(const void* dy, void* dx, int B, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, int dtype,
+                                umr_stream_t stream) {
+    return umr_bilinear_bwd_ex(dy, 0, dx, 0, B, Hi, Wi, Ho, Wo, C, align_corners, dtype, stream);
 }
 
 extern "C" int umr_pixel_shuffle(const void* src, void* dst, int B, int H, int W, int s_, int C, int inverse, int dtype, umr_stream_t stream) {

@@ -206,6 +206,54 @@ __global__ __launch_bounds__(256) void lh_bwd_weight_kernel(const T* __restrict_
     if (threadIdx.x == 0) o[9 * C + 9] = sh[9 * C + 4];   // D = sum_p g(p): the centre tap is inside for every pixel
 }
 
+// The nine shifted gradient maps of a pixel as a 16-channel NHWC map: s9[q][t] = g(q - off_t) (t < 9; zero outside the image and for
+// t >= 9), g = dout * act'(yout).  With them the two big reductions of the head's backward become linear maps of ONE small tensor:
+//   G[t][c] = sum_q s9[q][t] x(q)[c],   dx(q)[c] = sum_t s9[q][t] K[t][c]
+// and when x is itself a bilinear resize of a smaller map (x = U y: the head reads the x2-interpolated feature map, models.py:70-72),
+// both move to the small map through the resize's adjoint applied to s9 (16 channels instead of 256):
+//   G[t] = (U^T s9)[:, t]^T y,   dy = (U^T s9) K.
+// n[t] = sum_q s9[q][t] and D = n[4] are summed here in f32 (block partials [gridDim.x][16] -> lh_reduce_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void lh_shift9_kernel(const float* __restrict__ dout, const float* __restrict__ yout, T* __restrict__ s9,
+                                                        float* __restrict__ part, int B, int H, int W, int act) {
+    __shared__ float sh[4][9];
+    const int64_t M = (int64_t)B * H * W;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float nt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) nt[t] = 0.f;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < M; q += (int64_t)gridDim.x * 256) {
+        const int64_t row = q / W;
+        const int px = (int)(q - row * W), py = (int)(row % H);
+        float g[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) g[t] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = py - (t / 3 - 1), xx = px - (t % 3 - 1);
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const int64_t r = q - (int64_t)(t / 3 - 1) * W - (t % 3 - 1);
+                g[t] = dout[r] * act_grad_from_out(yout ? yout[r] : 0.f, act);
+            }
+            nt[t] += g[t];
+        }
+        T* o = s9 + q * 16;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Vec4<T>::store(o + 4 * v, f32x4{g[4 * v], g[4 * v + 1], g[4 * v + 2], g[4 * v + 3]});
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float s_ = wave_sum(nt[t]);
+        if (lane == 0) sh[wv][t] = s_;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int t = threadIdx.x;
+        const int src = t < 9 ? t : 4;      // slot 9 = D = sum_p g(p) = n[4] (the centre tap is inside for every pixel)
+        part[(int64_t)blockIdx.x * 16 + t] = (t <= 9) ? ((sh[0][src] + sh[1][src]) + (sh[2][src] + sh[3][src])) : 0.f;
+    }
+}
+
 // block = 64 columns x 16 slab phases; phase y sums slabs y, y+16, ... (8 loads in flight), the 16 phase sums are added in
 // a fixed order through LDS (one thread per column walking all slabs serially took 0.29 ms for 9.5 MB)
 __global__ __launch_bounds__(1024) void lh_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int n, int stride) {
@@ -332,6 +380,26 @@ extern "C" int umr_linear_head_bwd_weight(const void* x, const float* dout, cons
     LH_DISPATCH(dtype, hipLaunchKernelGGL(lh_bwd_weight_kernel<T>, dim3(nb), dim3(256), lds, s, (const T*)x, dout, yout, (float*)workspace, B, H, W, C, act, rpr, runs, rpb));
     UMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(lh_reduce_kernel, dim3((9 * C + 10 + 63) / 64), dim3(1024), 0, s, (const float*)workspace, out, nb, 9 * C + 10, stride);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+static int lh_shift9_blocks(int64_t M) { const int64_t b = (M + 255) / 256; return (int)(b > 2048 ? 2048 : b); }
+extern "C" int64_t umr_linear_head_shift9_workspace(int64_t M) { return (int64_t)lh_shift9_blocks(M) * 16 * 4; }
+
+// s9: [B*H*W][16] of dtype (the nine shifted gradient maps, see lh_shift9_kernel); nd: [16] f32 = n[0..8], D, zeros
+extern "C" int umr_linear_head_shift9(const float* dout, const float* yout, void* s9, float* nd, void* workspace, int64_t workspace_bytes,
+                                      int B, int H, int W, int act, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(dout && s9 && nd && workspace && B > 0 && H > 0 && W > 0, "linear_head_shift9: bad arguments");
+    UMR_CHECK_ARG(act != UMR_ACT_TANH || yout, "linear_head_shift9: tanh needs the forward output");
+    if (act == 4) return umr_set_error(UMR_ERR_UNSUPPORTED, "linear_head: sine backward is not implemented");
+    const int64_t M = (int64_t)B * H * W;
+    UMR_CHECK_ARG(workspace_bytes >= umr_linear_head_shift9_workspace(M), "linear_head_shift9: workspace too small");
+    const int nb = lh_shift9_blocks(M);
+    hipStream_t s = (hipStream_t)stream;
+    LH_DISPATCH(dtype, hipLaunchKernelGGL(lh_shift9_kernel<T>, dim3(nb), dim3(256), 0, s, dout, yout, (T*)s9, (float*)workspace, B, H, W, act));
+    UMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lh_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nd, nb, 16, 16);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

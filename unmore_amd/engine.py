@@ -225,6 +225,12 @@ _FUSE_HEAD_OUT = os.environ.get("UMR_FUSE_HEAD_OUT", "1") != "0"  # A/B switch f
 _X3_HEADS = os.environ.get("UMR_X3_HEADS", "1") != "0"            # A/B switch: fp32-mode inference heads on the bf16-plane kernel
 _X3_ALL = os.environ.get("UMR_X3_ALL", "1") != "0"            # A/B switch: 0 = fp32 mode as in round 3 (only the heads on the plane kernels)
 _MERGE_DFEAT = os.environ.get("UMR_MERGE_DFEAT", "1") != "0"    # A/B switch: one GEMM for the feature-map gradient of both heads
+# A 1x1 convolution and a bilinear resize commute exactly (both linear, one per pixel across channels, the other per channel across
+# pixels with weights that sum to 1, so the bias commutes too): conv1x1(resize(x)) == resize(conv1x1(x)).  The fusion blocks'
+# out_conv (blocks.py:377-381: interpolate x2, then out_conv) and the first layer of both heads (objectness_net.py:110,121 on the
+# x2-interpolated feature map, models.py:70-72) therefore run on the map BEFORE the resize -- a quarter of the rows in the GEMM, its
+# weight gradient and its data gradient -- and the resize moves the GEMM's output.  0 = the reference's order (A/B switch).
+_COMMUTE_RESIZE = os.environ.get("UMR_COMMUTE_RESIZE", "1") != "0"
 # Backward of a head without non-linearities between its convs (objectness_net.py:119-142): "algebraic" (default) = exact
 # gradients of all eight factored tensors from three pixel reductions (no 512/1024-channel tensor is stored, read or
 # multiplied in backward); "gemm" = the layer-by-layer data/weight-gradient GEMMs (A/B switch, the round-1 form).
@@ -337,6 +343,18 @@ class Engine(X3Path):
             ops.linear_head_bwd_data(dout, hs["out"], Kw, dfeat, act, False)
         else:
             ops.linear_head_bwd_data(dout, hs["out"], Kw, dfeat.view(feat.shape), act, True)
+        self._linear_head_algebra(P, name, idx, hs, Gm, n, D, G)
+        return dfeat
+
+    def _linear_head_algebra(self, P, name, idx, hs, Gm, n, D, G):
+        """the factored parameters' gradients from G [9*C] (tap major), n [9], D [1] (all f32)"""
+        W1, b1 = self._f32(P, f"{name}.{idx[0]}.weight"), self._f32(P, f"{name}.{idx[0]}.bias")
+        W2, b2 = self._f32(P, f"{name}.{idx[1]}.weight"), self._f32(P, f"{name}.{idx[1]}.bias")
+        W3, b3 = self._f32(P, f"{name}.{idx[2]}.weight"), self._f32(P, f"{name}.{idx[2]}.bias")
+        W4 = self._f32(P, f"{name}.{idx[3]}.weight")
+        C, C1, C3 = W1.shape[1], W1.shape[0], W3.shape[0]
+        dev = Gm.device
+        u, Vc = hs["u"], hs["Vc"]
         g = lambda k: (G[f"{name}.{idx[k]}.weight"], G[f"{name}.{idx[k]}.bias"])
         (gW1, gb1), (gW2, gb2), (gW3, gb3), (gW4, gb4) = g(0), g(1), g(2), g(3)
         gvc = torch.empty(C1 * 9, dtype=torch.float32, device=dev)
@@ -355,7 +373,6 @@ class Engine(X3Path):
         ops.small_gemm(W4, gu, gW3, C3, C1, 1, (1, 0), (0, 1), (C1, 1))         # dW3 = W4^T gu
         ops.small_gemm(W4, D, gb3, C3, 1, 1, (1, 0), (0, 0), (1, 0))            # db3 = D W4^T
         ops.cast(D, torch.float32, out=gb4.view(1))                              # db4 = D
-        return dfeat
 
     # ------------------------------------------------------------------ helpers
     def _w(self, P, name, kind):
@@ -550,11 +567,19 @@ class Engine(X3Path):
                 # the reference's wiring: exactly x2 (blocks.py:377-379); a token grid that does not survive the stride-2 conv and
                 # the doublings (e.g. an odd grid) then fails at the skip addition, as the reference does (blocks.py:372)
                 Ho, Wo = 2 * hh, 2 * ww
-            up = ops.bilinear_fwd(u, Ho, Wo, True)
-            path = ops.gemm_nt(up.view(-1, 256), self._w(P, r_ + "out_conv.weight", "lin"), self._f32(P, r_ + "out_conv.bias"))
-            path = path.view(nb, Ho, Wo, 256)
+            if _COMMUTE_RESIZE:
+                # out_conv before the resize (see _COMMUTE_RESIZE): its backward reads u, not the 4x larger resized map
+                ul = ops.gemm_nt(u.view(-1, 256), self._w(P, r_ + "out_conv.weight", "lin"), self._f32(P, r_ + "out_conv.bias"))
+                path = ops.bilinear_fwd(ul.view(nb, hh, ww, 256), Ho, Wo, True)
+                up = None
+                del ul
+            else:
+                up = ops.bilinear_fwd(u, Ho, Wo, True)
+                path = ops.gemm_nt(up.view(-1, 256), self._w(P, r_ + "out_conv.weight", "lin"), self._f32(P, r_ + "out_conv.bias"))
+                path = path.view(nb, Ho, Wo, 256)
             if save:
-                fs.update(s_relu=s_relu, t2=t2, up=up, in_hw=(hh, ww))
+                fs.update(s_relu=s_relu, t2=t2, in_hw=(hh, ww))
+                fs.update(dict(u=u) if up is None else dict(up=up))
                 fus_saved[k] = fs
         if cfg["patch"] == 16:
             # models.py:70-72: Interpolate(scale_factor=2) -- the maps have 32 * (grid // 2 ...) = 16 * grid pixels per side, which is
@@ -562,12 +587,19 @@ class Engine(X3Path):
             H, W = 2 * path.shape[1], 2 * path.shape[2]
             if save:
                 S["H"], S["W"] = H, W
-        feat = ops.bilinear_fwd(path, H, W, True)
+        x3_ok = _X3_HEADS and dt == torch.float32 and ops.get_f32_mode() in ("x3", "x3_fast")
+        # the heads' first layer before the final resize (_COMMUTE_RESIZE): the interpolated 256-channel feature map is never
+        # formed, and the backward of that layer -- weight gradient, data gradient, the algebraic head's reductions -- runs on
+        # the quarter-size map
+        lowres = _COMMUTE_RESIZE and not self.collapse_linear_heads and not x3_ok
+        feat = None if lowres else ops.bilinear_fwd(path, H, W, True)
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
             S["path1_hw"] = (path.shape[1], path.shape[2])
             S["feat"] = feat
+            if lowres:
+                S["path"] = path
 
         # ---- heads (objectness_net.py:109-135)
         outs = []
@@ -576,7 +608,6 @@ class Engine(X3Path):
         # value held as three bf16 planes (six plane pairs per K-tile, csrc/gemm_nt256p.hip X3) -- the same six-term products as
         # the 128x128 fp32 kernel's in-register split (UMR_F32_X3), without the split arithmetic in the loop.  Training keeps
         # f32 activations (its backward reads them), and the exact-f32 mode keeps the f32 MFMA.
-        x3_ok = _X3_HEADS and dt == torch.float32 and ops.get_f32_mode() in ("x3", "x3_fast")
         featp = None
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
@@ -628,7 +659,12 @@ class Engine(X3Path):
                 heads_saved.append(dict(h1=h1, h2=h2, h3=h3, out=out, x3=True))
                 del h1, h2, h3
                 continue
-            h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
+            if lowres:
+                h1l = ops.gemm_nt(path.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"))
+                h1 = ops.bilinear_fwd(h1l.view(path.shape[0], path.shape[1], path.shape[2], -1), H, W, True, relu=lay["relu"]).view(B * H * W, -1)
+                del h1l
+            else:
+                h1 = ops.gemm_nt(feat.view(-1, 256), self._w(P, f"{name}.{idx[0]}.weight", "lin"), self._f32(P, f"{name}.{idx[0]}.bias"), act=act)
             h2 = ops.gemm_nt(h1.view(B, H, W, 512), self._w(P, f"{name}.{idx[1]}.weight", "c3"), self._f32(P, f"{name}.{idx[1]}.bias"),
                              conv=1, act=act)
             w3, b3 = self._w(P, f"{name}.{idx[2]}.weight", "lin"), self._f32(P, f"{name}.{idx[2]}.bias")
@@ -657,40 +693,12 @@ class Engine(X3Path):
             S["heads"] = heads_saved
         return outs[0], outs[1], S
 
-    # ------------------------------------------------------------------ backward
-    def backward(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
-        """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
-        Parameters that receive no gradient (SURVEY Appendix A) are left untouched.
-        stage_cb(name, wg) is called when a stage's gradients are complete or enqueued behind wg (the WgradStream of this pass):
-        the data-parallel exchange launches its bucket there, a single-GPU step enqueues the stage's Adam update behind wg;
-        join_at_stages: the caller reads the gradients inside stage_cb (so the weight-gradient stream is joined before each call)."""
-        cfg, dt = self.cfg, self.dt
-        if S.get("x3"):
-            return self.backward_x3(P, S, d_center, d_sdf, G, stage_cb, join_at_stages)
-        B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
-        D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
-        g, Nt = gh * gw, gh * gw + 1
+    def _heads_backward_fullres(self, P, S, d_center, d_sdf, G, wgrad_lin, wgrad_c3):
+        """backward of both heads on the interpolated feature map (the reference's order of operations); returns the gradient of the
+        map before the final resize"""
+        dt = self.dt
+        B, H, W = S["B"], S["H"], S["W"]
         dev = d_center.device
-        wg = WgradStream(dev, WgradStream.wanted(B * H * W))
-
-        def cb(name):
-            if join_at_stages:
-                wg.join()
-            if stage_cb is not None:
-                stage_cb(name, wg)
-
-        def wgrad_lin(name, dy, x, bias_name=None, **kw):
-            wg.run(lambda: ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw), dy, x)
-
-        def wgrad_c3(name, dy, x_nhwc, bias_name=None, conv=1):
-            co = G[name].shape[0]
-
-            def launch():
-                dwp = ops.gemm_tn(dy.reshape(-1, co), x_nhwc, dbias=(G[bias_name] if bias_name else None), conv=conv)
-                _unpack_conv3_grad(dwp, G[name])
-            wg.run(launch, dy, x_nhwc)
-
-        # ---- heads
         dfeat = None
         feat = S["feat"]
         # Both heads factored: their layer-1 input gradients dh1 go side by side into one [M, 2*C1] buffer and the gradient of
@@ -744,10 +752,106 @@ class Engine(X3Path):
             dfeat = ops.gemm_nt(dh1cat, torch.cat(w1cat, dim=1), None)
             del dh1cat
         S["feat"] = None
-        cb("heads")
         ph, pw = S["path1_hw"]
         dpath = ops.bilinear_bwd(dfeat.view(B, H, W, 256), ph, pw, True)
         del dfeat
+        return dpath
+
+    def _heads_backward_lowres(self, P, S, d_center, d_sdf, G, wgrad_lin, wgrad_c3):
+        """Backward of both heads when their first layer ran before the final resize (_COMMUTE_RESIZE).  The gradient of that layer's
+        OUTPUT goes through the resize's adjoint -- the 512 channels of a factored head, the 16-channel map of shifted output
+        gradients of an algebraic head (csrc/linear_head.hip, lh_shift9_kernel) -- side by side into ONE [Ml, K] buffer on the small
+        map; the layer's weight gradients, the algebraic head's tap reductions and the gradient of the small map (one GEMM over K)
+        are taken there.  Returns that gradient [nb, ph, pw, 256]."""
+        dt = self.dt
+        B, H, W = S["B"], S["H"], S["W"]
+        path = S["path"]
+        nb, ph, pw, C = path.shape
+        pl = path.view(-1, C)
+        Ml = pl.shape[0]
+        dev = path.device
+        widths = [64 if hs_.get("algebraic") else hs_["h1"].shape[-1] for hs_ in S["heads"]]
+        K = sum(widths)
+        dlow = torch.empty((Ml, K), dtype=dt, device=dev)
+        bcat = torch.zeros((C, K), dtype=dt, device=dev)          # [256, K]: dpath = dlow . bcat^T
+        c0 = 0
+        for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
+                                               ("sdf_prediction_head", self.sdf_layout, d_sdf))):
+            hs = S["heads"][hi]
+            idx = lay["conv_idx"]
+            if hs.get("algebraic"):
+                if "u" not in hs:
+                    hs["u"], hs["Vc"], hs["Kw"], _ = self._linear_head_weights(P, name, idx, dev)
+                s9, nd = ops.linear_head_shift9(dout.contiguous(), hs["out"], hs["act"], dt)
+                ops.bilinear_bwd(s9, ph, pw, True, out=dlow[:, c0:c0 + 16].unflatten(0, (nb, ph, pw)))
+                del s9
+                dlow[:, c0 + 16:c0 + 64].zero_()
+                gm = ops.gemm_tn(dlow[:, c0:c0 + 16], pl)           # [16, 256]: G[t][c] = sum_q (U^T s9)[q][t] path(q)[c]
+                self._linear_head_algebra(P, name, idx, hs, gm[:9].reshape(-1), nd[:9], nd[9:10], G)
+                bcat[:, c0:c0 + 9].copy_(hs["Kw"].view(9, C).t())
+                c0 += 64
+                continue
+            relu = lay["relu"]
+            w4 = self._f32(P, f"{name}.{idx[3]}.weight")
+            dh3 = ops.head_out_bwd(hs["h3"], w4.reshape(w4.shape[0], -1), dout.contiguous(), hs["out"], _ACT[lay["final"]], relu,
+                                   G[f"{name}.{idx[3]}.weight"].view(w4.shape[0], -1), G[f"{name}.{idx[3]}.bias"])
+            hs["h3"] = None
+            wgrad_lin(f"{name}.{idx[2]}.weight", dh3, hs["h2"], f"{name}.{idx[2]}.bias")
+            dh2 = ops.gemm_nt(dh3, self._w(P, f"{name}.{idx[2]}.weight", "lin_t"), None, aux=(hs["h2"] if relu else None), mask_relu=relu)
+            del dh3
+            c1 = hs["h1"].shape[-1]
+            wgrad_c3(f"{name}.{idx[1]}.weight", dh2, hs["h1"].view(B, H, W, c1), f"{name}.{idx[1]}.bias")
+            hs["h2"] = None
+            dh1 = ops.gemm_nt(dh2.view(B, H, W, -1), self._w(P, f"{name}.{idx[1]}.weight", "c3_d"), None, conv=1,
+                              aux=(hs["h1"] if relu else None), mask_relu=relu)
+            del dh2
+            hs["h1"] = None
+            ops.bilinear_bwd(dh1.view(B, H, W, c1), ph, pw, True, out=dlow[:, c0:c0 + c1].unflatten(0, (nb, ph, pw)))
+            del dh1
+            wgrad_lin(f"{name}.{idx[0]}.weight", dlow[:, c0:c0 + c1], pl, f"{name}.{idx[0]}.bias")
+            bcat[:, c0:c0 + c1].copy_(self._w(P, f"{name}.{idx[0]}.weight", "lin_t"))
+            c0 += c1
+        dpath = ops.gemm_nt(dlow, bcat, None).view(nb, ph, pw, C)
+        S["path"] = None
+        return dpath
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
+        """G: dict name -> preallocated fp32 gradient tensor (parameter shape) to fill.
+        Parameters that receive no gradient (SURVEY Appendix A) are left untouched.
+        stage_cb(name, wg) is called when a stage's gradients are complete or enqueued behind wg (the WgradStream of this pass):
+        the data-parallel exchange launches its bucket there, a single-GPU step enqueues the stage's Adam update behind wg;
+        join_at_stages: the caller reads the gradients inside stage_cb (so the weight-gradient stream is joined before each call)."""
+        cfg, dt = self.cfg, self.dt
+        if S.get("x3"):
+            return self.backward_x3(P, S, d_center, d_sdf, G, stage_cb, join_at_stages)
+        B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
+        D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
+        g, Nt = gh * gw, gh * gw + 1
+        dev = d_center.device
+        wg = WgradStream(dev, WgradStream.wanted(B * H * W))
+
+        def cb(name):
+            if join_at_stages:
+                wg.join()
+            if stage_cb is not None:
+                stage_cb(name, wg)
+
+        def wgrad_lin(name, dy, x, bias_name=None, **kw):
+            wg.run(lambda: ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw), dy, x)
+
+        def wgrad_c3(name, dy, x_nhwc, bias_name=None, conv=1):
+            co = G[name].shape[0]
+
+            def launch():
+                dwp = ops.gemm_tn(dy.reshape(-1, co), x_nhwc, dbias=(G[bias_name] if bias_name else None), conv=conv)
+                _unpack_conv3_grad(dwp, G[name])
+            wg.run(launch, dy, x_nhwc)
+
+        # ---- heads
+        heads_bwd = self._heads_backward_lowres if S.get("path") is not None else self._heads_backward_fullres
+        dpath = heads_bwd(P, S, d_center, d_sdf, G, wgrad_lin, wgrad_c3)
+        cb("heads")
 
         # ---- refinenets + scratch convs
         sc = "backbone.scratch."
@@ -757,10 +861,16 @@ class Engine(X3Path):
             fs = S["fus"][k]
             hh, ww = fs["in_hw"]
             nb = dpath.shape[0]
-            wgrad_lin(r_ + "out_conv.weight", dpath.reshape(-1, 256), fs["up"].view(-1, 256), r_ + "out_conv.bias")
-            dup = ops.gemm_nt(dpath.reshape(-1, 256), self._w(P, r_ + "out_conv.weight", "lin_t"), None)
-            du = ops.bilinear_bwd(dup.view(nb, dpath.shape[1], dpath.shape[2], 256), hh, ww, True)
-            del dup
+            if "u" in fs:    # out_conv ran before the resize (_COMMUTE_RESIZE)
+                dul = ops.bilinear_bwd(dpath, hh, ww, True).view(-1, 256)
+                wgrad_lin(r_ + "out_conv.weight", dul, fs["u"].view(-1, 256), r_ + "out_conv.bias")
+                du = ops.gemm_nt(dul, self._w(P, r_ + "out_conv.weight", "lin_t"), None).view(nb, hh, ww, 256)
+                del dul
+            else:
+                wgrad_lin(r_ + "out_conv.weight", dpath.reshape(-1, 256), fs["up"].view(-1, 256), r_ + "out_conv.bias")
+                dup = ops.gemm_nt(dpath.reshape(-1, 256), self._w(P, r_ + "out_conv.weight", "lin_t"), None)
+                du = ops.bilinear_bwd(dup.view(nb, dpath.shape[1], dpath.shape[2], 256), hh, ww, True)
+                del dup
             # RCU2: u = conv2(relu(conv1(relu(s)))) + s
             wgrad_c3(r_ + "resConfUnit2.conv2.weight", du, fs["t2"], r_ + "resConfUnit2.conv2.bias")
             dt2 = ops.gemm_nt(du, self._w(P, r_ + "resConfUnit2.conv2.weight", "c3_d"), None, conv=1, aux=fs["t2"], mask_relu=True)

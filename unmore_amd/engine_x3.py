@@ -154,6 +154,7 @@ class X3Path:
 
     # ------------------------------------------------------------------ forward
     def forward_x3(self, P, images, save):
+        from .engine import _COMMUTE_RESIZE
         cfg = self.cfg
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
         images = images.contiguous()
@@ -289,6 +290,16 @@ class X3Path:
                 Ho, Wo = nxt[1], nxt[2]  # patch-14 extension: resize to the next skip's size
             else:
                 Ho, Wo = 2 * hh, 2 * ww      # blocks.py:377-379
+            if _COMMUTE_RESIZE:
+                # out_conv before the resize (engine._COMMUTE_RESIZE): a quarter of the rows, and its backward reads u
+                ul = mm(u.view(nb * hh * ww, 256), r_ + "out_conv.weight", "lin", b_(r_ + "out_conv.bias"))
+                path = XT(f=ops.bilinear_fwd(ul.F().view(nb, hh, ww, 256), Ho, Wo, True))
+                del ul
+                if save:
+                    u.drop_f()      # the weight gradient reads the planes
+                    fs.update(s_relu=s_relu, t2=t2, u=u, in_hw=(hh, ww))
+                    fus_saved[k] = fs
+                continue
             up = XT(f=ops.bilinear_fwd(u.F(), Ho, Wo, True))
             path = mm(up.view(nb * Ho * Wo, 256), r_ + "out_conv.weight", "lin", b_(r_ + "out_conv.bias")).view(nb, Ho, Wo, 256)
             if save:
@@ -299,18 +310,23 @@ class X3Path:
             H, W = 2 * path.shape[1], 2 * path.shape[2]   # models.py:70-72
             if save:
                 S["H"], S["W"] = H, W
-        feat = XT(f=ops.bilinear_fwd(path.F(), H, W, True))
+        # the heads' first layer before the final resize (engine._COMMUTE_RESIZE): the interpolated 256-channel map is never formed
+        lowres = _COMMUTE_RESIZE and not self.collapse_linear_heads
+        feat = None if lowres else XT(f=ops.bilinear_fwd(path.F(), H, W, True))
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
             S["path1_hw"] = (path.shape[1], path.shape[2])
             S["feat"] = feat
+            if lowres:
+                S["path"] = path
 
         # ---- heads (objectness_net.py:109-135)
         from .engine import _ACT
         outs, heads_saved = [], []
         M = B * H * W
-        feat2 = feat.view(M, 256)
+        feat2 = None if lowres else feat.view(M, 256)
+        nbp, php, pwp = path.shape[0], path.shape[1], path.shape[2]
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
             if self.collapse_linear_heads and not lay["relu"]:
@@ -324,7 +340,13 @@ class X3Path:
             algebraic = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"
             keep = save and not algebraic
             hb = lambda k: b_(f"{name}.{idx[k]}.bias")
-            h1 = mm(feat2, f"{name}.{idx[0]}.weight", "lin", hb(0), act=act, want="p")
+            if lowres:
+                # resize(W1 path + b1), then the ReLU: written straight as the planes the 3x3 conv stages
+                h1l = mm(path.view(nbp * php * pwp, 256), f"{name}.{idx[0]}.weight", "lin", hb(0))
+                h1 = XT(p=ops.bilinear_fwd(h1l.F().view(nbp, php, pwp, -1), H, W, True, relu=lay["relu"], planes=True)).view(M, h1l.n)
+                del h1l
+            else:
+                h1 = mm(feat2, f"{name}.{idx[0]}.weight", "lin", hb(0), act=act, want="p")
             h2 = mm(h1.view(B, H, W, 512), f"{name}.{idx[1]}.weight", "c3", hb(1), conv=1, act=act, want="p")
             w4 = b_(f"{name}.{idx[3]}.weight")
             w4 = w4.reshape(w4.shape[0], -1)
@@ -374,14 +396,33 @@ class X3Path:
 
         # ---- heads
         M = B * H * W
+        lowres = S.get("path") is not None        # the heads' first layer ran before the final resize (engine._COMMUTE_RESIZE)
         feat = S["feat"]
-        feat2 = feat.view(M, 256)
-        dfeat = None          # f32 [M, 256]
+        feat2 = None if lowres else feat.view(M, 256)
+        if lowres:
+            pathx = S["path"]
+            nbp, php, pwp = pathx.shape[0], pathx.shape[1], pathx.shape[2]
+            Ml = nbp * php * pwp
+            pl = pathx.view(Ml, 256)
+        dfeat = None          # f32 [M, 256] (lowres: the gradient of the map before the resize, [Ml, 256])
         dh1s, w1names = [], []
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                 ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
             idx = lay["conv_idx"]
+            if lowres and hs.get("algebraic"):
+                # the head's two reductions as products on the small map (csrc/linear_head.hip, lh_shift9_kernel)
+                if "u" not in hs:
+                    hs["u"], hs["Vc"], hs["Kw"], _ = self._linear_head_weights(P, name, idx, dev)
+                s9, nd = ops.linear_head_shift9(dout.contiguous(), hs["out"], hs["act"], torch.float32)
+                E = ops.bilinear_bwd(s9, php, pwp, True).view(Ml, 16)
+                del s9
+                gm = ops.gemm_tn(E, pl.F())
+                self._linear_head_algebra(P, name, idx, hs, gm[:9].reshape(-1), nd[:9], nd[9:10], G)
+                kwt = torch.zeros((256, 16), dtype=torch.float32, device=dev)
+                kwt[:, :9].copy_(hs["Kw"].view(9, 256).t())
+                dfeat = ops.gemm_nt(E, kwt, None) if dfeat is None else ops.gemm_nt(E, kwt, None, aux=dfeat, out=dfeat)
+                continue
             if hs.get("collapsed") or hs.get("algebraic"):
                 dfeat = self._linear_head_backward(P, name, idx, feat.F().view(B, H, W, 256), hs, dout, dfeat, G)
                 continue
@@ -396,19 +437,23 @@ class X3Path:
             h1 = hs["h1"].view(B, H, W, 512)
             wgrad_c3(f"{name}.{idx[1]}.weight", dh2, h1, f"{name}.{idx[1]}.bias")
             hs["h2"] = None
-            dh1 = mm(dh2.view(B, H, W, 512), f"{name}.{idx[1]}.weight", "c3_d", None, conv=1, mask=(hs["h1"] if relu else None), want="p")
+            dh1 = mm(dh2.view(B, H, W, 512), f"{name}.{idx[1]}.weight", "c3_d", None, conv=1, mask=(hs["h1"] if relu else None),
+                     want=("f" if lowres else "p"))
             del dh2
             hs["h1"] = None
-            wgrad_lin(f"{name}.{idx[0]}.weight", dh1, feat2, f"{name}.{idx[0]}.bias")
+            if lowres:
+                dh1 = XT(f=ops.bilinear_bwd(dh1.F().view(B, H, W, dh1.n), php, pwp, True)).view(Ml, dh1.n)
+            wgrad_lin(f"{name}.{idx[0]}.weight", dh1, (pl if lowres else feat2), f"{name}.{idx[0]}.bias")
             if dfeat is None:
                 dfeat = mm(dh1, f"{name}.{idx[0]}.weight", "lin_t", None).F()
             else:
                 dfeat = mm(dh1, f"{name}.{idx[0]}.weight", "lin_t", None, aux=dfeat).F()
             del dh1
         S["feat"] = None
+        S["path"] = None
         cb("heads")
         ph, pw = S["path1_hw"]
-        dpath = XT(f=ops.bilinear_bwd(dfeat.view(B, H, W, 256), ph, pw, True))
+        dpath = XT(f=dfeat.view(nbp, php, pwp, 256)) if lowres else XT(f=ops.bilinear_bwd(dfeat.view(B, H, W, 256), ph, pw, True))
         del dfeat
 
         # ---- refinenets + scratch convs
@@ -421,10 +466,16 @@ class X3Path:
             nb, Hp, Wp = dpath.shape[0], dpath.shape[1], dpath.shape[2]
             shp = (nb, hh, ww, 256)
             dp2 = dpath.view(nb * Hp * Wp, 256)
-            wgrad_lin(r_ + "out_conv.weight", dp2, fs["up"].view(nb * Hp * Wp, 256), r_ + "out_conv.bias")
-            dup = mm(dp2, r_ + "out_conv.weight", "lin_t", None).F()
-            du = XT(f=ops.bilinear_bwd(dup.view(nb, Hp, Wp, 256), hh, ww, True))
-            del dup
+            if "u" in fs:     # out_conv ran before the resize
+                dul = XT(f=ops.bilinear_bwd(dpath.F().view(nb, Hp, Wp, 256), hh, ww, True)).view(nb * hh * ww, 256)
+                wgrad_lin(r_ + "out_conv.weight", dul, fs["u"].view(nb * hh * ww, 256), r_ + "out_conv.bias")
+                du = mm(dul, r_ + "out_conv.weight", "lin_t", None).view(*shp)
+                del dul
+            else:
+                wgrad_lin(r_ + "out_conv.weight", dp2, fs["up"].view(nb * Hp * Wp, 256), r_ + "out_conv.bias")
+                dup = mm(dp2, r_ + "out_conv.weight", "lin_t", None).F()
+                du = XT(f=ops.bilinear_bwd(dup.view(nb, Hp, Wp, 256), hh, ww, True))
+                del dup
             # RCU2: u = conv2(relu(conv1(relu(s)))) + s
             wgrad_c3(r_ + "resConfUnit2.conv2.weight", du, fs["t2"], r_ + "resConfUnit2.conv2.bias")
             dt2 = mm(du, r_ + "resConfUnit2.conv2.weight", "c3_d", None, conv=1, mask=fs["t2"], want="p").view(*shp)

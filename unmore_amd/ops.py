@@ -464,22 +464,44 @@ def patchify(images, patch, dtype, ldk=None):
     return out
 
 
-def bilinear_fwd(x, Ho, Wo, align_corners):
+def _pixel_view(t, what):
+    """(pointer tensor, B, H, W, C, pixel stride) of a [B, H, W, C] map whose pixels are rows of a (possibly wider) row-major buffer"""
+    B, H, W, C = t.shape
+    ld = t.stride(2)
+    assert t.stride(3) == 1 and t.stride(1) == W * ld and (B == 1 or t.stride(0) == H * W * ld) and ld >= C, \
+        f"{what}: [B,H,W,C] with contiguous channels and one pixel stride expected, got strides {t.stride()}"
+    return B, H, W, C, ld
+
+
+BILINEAR_RELU, BILINEAR_OUT_X3 = 1, 2
+
+
+def bilinear_fwd(x, Ho, Wo, align_corners, relu=False, planes=False, out=None):
+    """NHWC resize (blocks.py:155-172).  x / out may be column slices of wider row-major buffers.  relu: max(., 0) on the result;
+    planes (x f32): the result as three bf16 planes per pixel [B, Ho, Wo, 3C] (the operand format of the plane GEMMs)."""
     _need_gpu(x)
-    B, Hi, Wi, C = x.shape
-    assert x.is_contiguous()
-    y = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
-    L.check(L.lib().umr_bilinear_fwd(_p(x), _p(y), B, Hi, Wi, Ho, Wo, C, int(align_corners), _DT[x.dtype], _stream()), "umr_bilinear_fwd")
-    return y
+    B, Hi, Wi, C, ldx = _pixel_view(x, "bilinear_fwd input")
+    if out is None:
+        out = torch.empty((B, Ho, Wo, 3 * C if planes else C), dtype=(torch.bfloat16 if planes else x.dtype), device=x.device)
+    Bo, Ho_, Wo_, Co, ldy = _pixel_view(out, "bilinear_fwd output")
+    assert (Bo, Ho_, Wo_) == (B, Ho, Wo) and Co == (3 * C if planes else C) and out.dtype == (torch.bfloat16 if planes else x.dtype)
+    flags = (BILINEAR_RELU if relu else 0) | (BILINEAR_OUT_X3 if planes else 0)
+    L.check(L.lib().umr_bilinear_fwd_ex(_p(x), ldx, _p(out), ldy, B, Hi, Wi, Ho, Wo, C, int(align_corners), flags, _DT[x.dtype], _stream()),
+            "umr_bilinear_fwd_ex")
+    return out
 
 
-def bilinear_bwd(dy, Hi, Wi, align_corners):
+def bilinear_bwd(dy, Hi, Wi, align_corners, out=None):
+    """exact adjoint of bilinear_fwd; dy / out may be column slices of wider row-major buffers"""
     _need_gpu(dy)
-    B, Ho, Wo, C = dy.shape
-    assert dy.is_contiguous()
-    dx = torch.empty((B, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
-    L.check(L.lib().umr_bilinear_bwd(_p(dy), _p(dx), B, Hi, Wi, Ho, Wo, C, int(align_corners), _DT[dy.dtype], _stream()), "umr_bilinear_bwd")
-    return dx
+    B, Ho, Wo, C, lddy = _pixel_view(dy, "bilinear_bwd input")
+    if out is None:
+        out = torch.empty((B, Hi, Wi, C), dtype=dy.dtype, device=dy.device)
+    Bo, Hi_, Wi_, Co, lddx = _pixel_view(out, "bilinear_bwd output")
+    assert (Bo, Hi_, Wi_, Co) == (B, Hi, Wi, C) and out.dtype == dy.dtype
+    L.check(L.lib().umr_bilinear_bwd_ex(_p(dy), lddy, _p(out), lddx, B, Hi, Wi, Ho, Wo, C, int(align_corners), _DT[dy.dtype], _stream()),
+            "umr_bilinear_bwd_ex")
+    return out
 
 
 def pixel_shuffle(src, B, H, W, s, C, inverse=False):
@@ -778,6 +800,20 @@ def linear_head_bwd_weight(x, dout, yout, act):
     L.check(L.lib().umr_linear_head_bwd_weight(_p(x), _p(dout), _p(yout), _p(out), _p(ws), ws.numel(), B, H, W, C, act, _DT[x.dtype],
                                                _stream()), "umr_linear_head_bwd_weight")
     return out
+
+
+def linear_head_shift9(dout, yout, act, dtype):
+    """-> (s9 [B, H, W, 16] of `dtype`: the nine shifted gradient maps g(q - off_t) of every pixel, zero padded to 16 channels;
+    nd f32 [16] = n[0..8], D, zeros) -- csrc/linear_head.hip"""
+    _need_gpu(dout)
+    B, H, W = dout.shape[0], dout.shape[-2], dout.shape[-1]
+    assert dout.dtype == torch.float32 and dout.is_contiguous() and dout.numel() == B * H * W
+    s9 = torch.empty((B, H, W, 16), dtype=dtype, device=dout.device)
+    nd = torch.empty(16, dtype=torch.float32, device=dout.device)
+    ws = _workspace(L.lib().umr_linear_head_shift9_workspace(B * H * W), dout.device)
+    L.check(L.lib().umr_linear_head_shift9(_p(dout), _p(yout), _p(s9), _p(nd), _p(ws), ws.numel(), B, H, W, act, _DT[dtype], _stream()),
+            "umr_linear_head_shift9")
+    return s9, nd
 
 
 # ---- existence classifier pieces (csrc/classifier.hip; SURVEY 8f row f3)

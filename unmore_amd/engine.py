@@ -591,8 +591,10 @@ class Engine(X3Path):
         # the heads' first layer before the final resize (_COMMUTE_RESIZE): the interpolated 256-channel feature map is never
         # formed, and the backward of that layer -- weight gradient, data gradient, the algebraic head's reductions -- runs on
         # the quarter-size map
-        lowres = _COMMUTE_RESIZE and not self.collapse_linear_heads and not x3_ok
-        feat = None if lowres else ops.bilinear_fwd(path, H, W, True)
+        lowres = _COMMUTE_RESIZE and not x3_ok
+        # (a head collapsed into one 3x3 convolution -- opt-in -- reads the interpolated map itself)
+        need_feat = not lowres or (self.collapse_linear_heads and not (self.center_layout["relu"] and self.sdf_layout["relu"]))
+        feat = ops.bilinear_fwd(path, H, W, True) if need_feat else None
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
@@ -770,15 +772,23 @@ class Engine(X3Path):
         pl = path.view(-1, C)
         Ml = pl.shape[0]
         dev = path.device
-        widths = [64 if hs_.get("algebraic") else hs_["h1"].shape[-1] for hs_ in S["heads"]]
+        widths = [0 if hs_.get("collapsed") else 64 if hs_.get("algebraic") else hs_["h1"].shape[-1] for hs_ in S["heads"]]
         K = sum(widths)
         dlow = torch.empty((Ml, K), dtype=dt, device=dev)
         bcat = torch.zeros((C, K), dtype=dt, device=dev)          # [256, K]: dpath = dlow . bcat^T
         c0 = 0
+        dpath_c = None
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
             idx = lay["conv_idx"]
+            if hs.get("collapsed"):
+                # (opt-in form) this head read the interpolated map: its gradient comes back through the resize's adjoint
+                assert dpath_c is None
+                dfeat = self._linear_head_backward(P, name, idx, S["feat"], hs, dout, None, G)
+                dpath_c = ops.bilinear_bwd(dfeat.view(B, H, W, C), ph, pw, True).view(Ml, C)
+                del dfeat
+                continue
             if hs.get("algebraic"):
                 if "u" not in hs:
                     hs["u"], hs["Vc"], hs["Kw"], _ = self._linear_head_weights(P, name, idx, dev)
@@ -811,8 +821,9 @@ class Engine(X3Path):
             wgrad_lin(f"{name}.{idx[0]}.weight", dlow[:, c0:c0 + c1], pl, f"{name}.{idx[0]}.bias")
             bcat[:, c0:c0 + c1].copy_(self._w(P, f"{name}.{idx[0]}.weight", "lin_t"))
             c0 += c1
-        dpath = ops.gemm_nt(dlow, bcat, None).view(nb, ph, pw, C)
+        dpath = ops.gemm_nt(dlow, bcat, None, aux=dpath_c).view(nb, ph, pw, C)
         S["path"] = None
+        S["feat"] = None
         return dpath
 
     # ------------------------------------------------------------------ backward

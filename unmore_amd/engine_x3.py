@@ -311,8 +311,10 @@ class X3Path:
             if save:
                 S["H"], S["W"] = H, W
         # the heads' first layer before the final resize (engine._COMMUTE_RESIZE): the interpolated 256-channel map is never formed
-        lowres = _COMMUTE_RESIZE and not self.collapse_linear_heads
-        feat = None if lowres else XT(f=ops.bilinear_fwd(path.F(), H, W, True))
+        lowres = _COMMUTE_RESIZE
+        # (a head collapsed into one 3x3 convolution -- opt-in -- reads the interpolated map itself)
+        need_feat = not lowres or (self.collapse_linear_heads and not (self.center_layout["relu"] and self.sdf_layout["relu"]))
+        feat = XT(f=ops.bilinear_fwd(path.F(), H, W, True)) if need_feat else None
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
@@ -406,6 +408,15 @@ class X3Path:
             pl = pathx.view(Ml, 256)
         dfeat = None          # f32 [M, 256] (lowres: the gradient of the map before the resize, [Ml, 256])
         dh1s, w1names = [], []
+        if lowres:
+            for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
+                                                    ("sdf_prediction_head", self.sdf_layout, d_sdf))):
+                if S["heads"][hi].get("collapsed"):
+                    # (opt-in form) this head read the interpolated map: its gradient comes back through the resize's adjoint
+                    assert dfeat is None
+                    dfc = self._linear_head_backward(P, name, lay["conv_idx"], feat.F().view(B, H, W, 256), S["heads"][hi], dout, None, G)
+                    dfeat = ops.bilinear_bwd(dfc.view(B, H, W, 256), php, pwp, True).view(Ml, 256)
+                    del dfc
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                 ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
@@ -423,6 +434,8 @@ class X3Path:
                 kwt[:, :9].copy_(hs["Kw"].view(9, 256).t())
                 dfeat = ops.gemm_nt(E, kwt, None) if dfeat is None else ops.gemm_nt(E, kwt, None, aux=dfeat, out=dfeat)
                 continue
+            if lowres and hs.get("collapsed"):
+                continue              # done above
             if hs.get("collapsed") or hs.get("algebraic"):
                 dfeat = self._linear_head_backward(P, name, idx, feat.F().view(B, H, W, 256), hs, dout, dfeat, G)
                 continue

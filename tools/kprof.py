@@ -22,6 +22,19 @@ if which == "convnt":
 elif which == "convtn":
     dy = torch.randn((M, 512), generator=g).to(dev).to(dt)
     fn = lambda: ops.gemm_tn(dy, x512, conv=1)
+elif which in ("dgrad1x1_n256", "dgrad1x1_nomask"):
+    # decomposition of the data gradient's FETCH_SIZE: one N-tile per M-tile (the A panel is needed once) / no mask operand
+    dh3 = torch.randn((M // 8, 1024), generator=g).to(dt).to(dev).repeat(8, 1)
+    n = 256 if which.endswith("n256") else 512
+    w3t = (torch.randn((n, 1024), generator=g) * 0.04).to(dev).to(dt)
+    out = torch.empty((M, n), dtype=dt, device=dev)
+    fn = lambda: ops.gemm_nt(dh3, w3t, None, out=out)
+elif which == "dgrad1x1":
+    # the centre head's masked 1024 -> 512 data gradient (two N-tiles per M-tile, K = 1024)
+    dh3 = torch.randn((M // 8, 1024), generator=g).to(dt).to(dev).repeat(8, 1)
+    w3t = (torch.randn((512, 1024), generator=g) * 0.04).to(dev).to(dt)
+    out = torch.empty((M, 512), dtype=dt, device=dev)
+    fn = lambda: ops.gemm_nt(dh3, w3t, None, aux=x512.view(M, 512), mask_relu=True, out=out)
 else:
     w1 = (torch.randn((1024, 512), generator=g) * 0.04).to(dev).to(dt)
     out2 = torch.empty((M, 1024), dtype=dt, device=dev)

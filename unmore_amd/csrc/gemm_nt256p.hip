@@ -110,7 +110,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // tile sequence of this workgroup: virtual ids pw, pw + G, pw + 2G, ...; workgroups of one XCD (blockIdx % 8)
     // own a contiguous run of G/8 ids per round, so neighbouring tiles share that XCD's L2
     const int G = gridDim.x;
+#ifdef UMR_EXP_NO_XCD_REMAP   // experiment (tools/probe/xcd_remap_fetch.sh): consecutive tiles on consecutive workgroups = on different XCDs
+    const int pw = (int)blockIdx.x;
+#else
     const int pw = ((G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+#endif
     if (pw >= total_tiles) return;
     const int n_my = (total_tiles - pw + G - 1) / G;
 

@@ -14,7 +14,11 @@ assert os.environ.get("UMR_LIB"), "run with UMR_LIB=<instrumented library>"
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
 M = 64 * 384 * 384 // 4
-for K, N, aux in ((768, 512, 0), (512, 1024, 0), (512, 1024, 3), (768, 512, 2), (768, 768, 1)):   # aux 3 = fused row reduction
+SHAPES = ((768, 512, 0), (512, 1024, 0), (512, 1024, 3), (768, 512, 2), (768, 768, 1))
+if len(sys.argv) > 1 and sys.argv[1] == "dgrad":     # the centre head's 1024 -> 512 data gradient at the full cfg2 row count, plain and masked
+    SHAPES = ((1024, 512, 0), (1024, 512, 2), (1024, 256, 0))
+    M *= 4
+for K, N, aux in SHAPES:   # aux 3 = fused row reduction
     A = torch.randn(M // 64, K, generator=g).to(dev).bfloat16().repeat(64, 1)
     w = (torch.randn(N, K, generator=g) * 0.03).to(dev).bfloat16()
     bias = torch.zeros(N, device=dev)

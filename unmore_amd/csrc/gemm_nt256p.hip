@@ -75,7 +75,7 @@ __device__ __forceinline__ unsigned pos_mask_bf16x2(unsigned a) {
 // K-tiles accumulated in f32: the main loop is the bf16 kernel unchanged (no split arithmetic in it; the 128x128 fp32 kernel of
 // gemm_nt.hip spends more time splitting fragments than multiplying), only the staging offsets differ.  Per f32 product: 6 MFMA
 // products = 96 matrix-pipe cycles per 16x16x32 block against 256 for the f32 MFMA.
-template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false>
+template <int CONV, int EPI, int AUXM, bool RED, bool X3 = false, bool P2 = true>
 __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc p, int tiles_n, int total_tiles, int stagger, int bm, int npairs = 6,
                                                              int kt_per_arg = 0) {
     // X3 only -- split-K along gridDim.y: the K range of every output tile is cut into gridDim.y contiguous runs of `kt_per_arg`
@@ -86,7 +86,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // The run is a constant of the workgroup: the persistent loop itself is unchanged.
     const int sp = (X3 && kt_per_arg > 0) ? (int)blockIdx.y : 0;
     static_assert(X3 == (EPI == 5 || EPI == 6), "the plane-pair K loop and the f32 / plane epilogues (EPI 5, 6) go together");
-    constexpr bool PH2 = (CONV == 1);   // two-phase K-tile: +2.4 % on the 3x3 conv, neutral to slightly negative on plain GEMMs
+    // P2: two-phase K-tile (2 barriers instead of 4) with a static priority for waves 4-7; !P2: four phases with priority flips around
+    // the MFMA clusters.  The conv always runs two-phase (+2.4 %).  Plain GEMMs (round 4): two-phase from 8 K-tiles per output tile on
+    // -- 2-8 % faster on the head 1x1 layers, the ViT GEMMs and their plane (fp32-grade) forms, 11 % at K = 8192 -- four-phase below
+    // (the 256 -> 512 layers, 4 K-tiles, are 3 % SLOWER two-phase): the host picks (profiles/r04_plain_gemm_two_phase_ab.txt).
+    constexpr bool PH2 = P2;
+    static_assert(CONV == 0 || P2, "the conv is instantiated in its two-phase form only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SZ = 2;
     constexpr unsigned OOB = 0x80000000u;
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     // waves 0-3 and no flips; 3 = none.  Measured on the head conv (two-phase K-tile, same box, tools/probe/prio_ab.sh): 30.9 /
     // 30.2 / 31.1 / 31.2 ms -- the guide's "static priority for the younger half" (Two waves per SIMD, item 4).  The four-phase
     // plain GEMMs lose 4-10 % without the flips (their LDS-DMA pieces are issued inside the raised cluster) and keep them.
-    constexpr int PRIO_MODE = (CONV == 1) ? UMR_EXP_PRIO_MODE : 0;
+    constexpr int PRIO_MODE = P2 ? UMR_EXP_PRIO_MODE : 0;
 #define QPRIO(x) if (PRIO_MODE == 0) __builtin_amdgcn_s_setprio(x);
 #define QUADRANT_D(M0, N0, FB, DMA_A, DMA_B)                                                         \
     QPRIO(1)                                                                                        \
@@ -314,6 +319,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     else if (dead_blocks == 2) { QUADRANT_S(4, N0, FB, Gp) }                     \
     else { STAGE_DMA(Gp, 0); STAGE_DMA(Gp, 1); }
 
+    // the same for the two-phase bodies (explicit DMA slots): all four blocks, the first two, or the DMA slots only
+#define QUADRANT_SD(M0, N0, FB, DMA_A, DMA_B)                                                        \
+    QPRIO(1)                                                                                        \
+    MFMA(acc[M0 + 0][N0 + 0], FB[0][0], fa[0][0]); MFMA(acc[M0 + 0][N0 + 1], FB[0][1], fa[0][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[0][0], fa[0][1]); MFMA(acc[M0 + 1][N0 + 1], FB[0][1], fa[0][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    DMA_A;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    MFMA(acc[M0 + 0][N0 + 0], FB[1][0], fa[1][0]); MFMA(acc[M0 + 0][N0 + 1], FB[1][1], fa[1][0]);   \
+    MFMA(acc[M0 + 1][N0 + 0], FB[1][0], fa[1][1]); MFMA(acc[M0 + 1][N0 + 1], FB[1][1], fa[1][1]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    DMA_B;                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                              \
+    QPRIO(0)
+#define QUADRANT_HID(N0, FB, DMA_A, DMA_B)                                       \
+    if (dead_blocks == 0) { QUADRANT_D(4, N0, FB, DMA_A, DMA_B) }                \
+    else if (dead_blocks == 2) { QUADRANT_SD(4, N0, FB, DMA_A, DMA_B) }          \
+    else { DMA_A; DMA_B; }
+
 #define PHASE_SYNC() PHASE_SYNC_N(6)
     // Two-phase form of the same K-tile (PH2): phases (Q0,Q1) and (Q2,Q3) merged -- 2 barriers instead of 4.  All waves
     // of the workgroup move in lock-step (read, wait, barrier, MFMA), and a wave cannot run far ahead of its queued
@@ -352,8 +376,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
         PHASE_SYNC_N(2);
-        QUADRANT_D(4, 2, fb1, STAGE_DMA(0, 0); STAGE_DMA(0, 1), STAGE_DMA(1, 0); STAGE_DMA(1, 1))
-        QUADRANT_D(4, 0, fb0, STAGE_DMA(2, 0), STAGE_DMA(2, 1))
+        QUADRANT_HID(2, fb1, STAGE_DMA(0, 0); STAGE_DMA(0, 1), STAGE_DMA(1, 0); STAGE_DMA(1, 1))
+        QUADRANT_HID(0, fb0, STAGE_DMA(2, 0), STAGE_DMA(2, 1))
     };
     auto tile_body = [&](const char* sbuf) {
         if (PH2) { tile_body2(sbuf); return; }
@@ -419,8 +443,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #pragma unroll
             for (int i = 0; i < 4; ++i) fa[ks][i] = A_FRAG(ks, 4 + i);
         READ_WAIT();
-        QUADRANT_D(4, 2, fb1, STAGE_DMA(3, 0), STAGE_DMA(3, 1))
-        QUADRANT_D(4, 0, fb0, (void)0, (void)0)
+        QUADRANT_HID(2, fb1, STAGE_DMA(3, 0), STAGE_DMA(3, 1))
+        QUADRANT_HID(0, fb0, (void)0, (void)0)
         END_SYNC_N(2);                      // A0,B0,B1(t+1) landed; A1(t+1) may fly
     };
     auto tile_body4_ahead = [&](const char* sbuf) {
@@ -913,6 +937,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
 #undef QUADRANT
 #undef QUADRANT_S
 #undef QUADRANT_HI
+#undef QUADRANT_HID
+#undef QUADRANT_SD
 #undef TS
 #undef PT
 #undef QUADRANT_D
@@ -1074,10 +1100,20 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     dim3 g((unsigned)grid, (unsigned)ksplit), b(512);
     // fast class = bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
+    // K-tile form of a plain GEMM (see the kernel): two-phase from 8 K-tiles (X3: plane-pair steps) per output tile on.
+    // UMR_NT256_PH2=0|1 forces a form (read per launch: A/B, tests)
+    const char* ph_e = getenv("UMR_NT256_PH2");
+    const int kt_steps = (d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2)) * (d->dtype == UMR_BF16X3 ? npairs_x3 : 1) / (ksplit > 1 ? ksplit : 1);
+    const bool two = ph_e ? (atoi(ph_e) != 0) : (kt_steps >= 8);
 #define L256P(CV, EP, AX, RD)                                                                                          \
     do {                                                                                                               \
-        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, AX, RD>), LDS2P);                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm);     \
+        if (CV == 1 || two) {                                                                                          \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, AX, RD, false, true>), LDS2P);                            \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, AX, RD, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm); \
+        } else {                                                                                                       \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, EP, AX, RD, false, false>), LDS2P);                            \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, EP, AX, RD, false, false>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm); \
+        }                                                                                                              \
     } while (0)
     // EPI 3: the fast class (bias / aux add / ReLU mask / ReLU, bf16-staged; one instantiation per aux mode, plus the fused
     // row reduction); EPI 4: the GELU class (plain GEMM only); EPI 1: everything else
@@ -1086,14 +1122,24 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     const int auxm = (d->flags & UMR_EPI_ADD_AUX) ? 1 : (d->flags & UMR_EPI_MASK_RELU) ? 2 : 0;
 #define L256PX(CV, EP)                                                                                                 \
     do {                                                                                                               \
-        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, 0, false, true>), LDS2P);                                     \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, 0, false, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0); \
+        if (CV == 1 || two) {                                                                                          \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, EP, 0, false, true, true>), LDS2P);                           \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<CV, EP, 0, false, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0); \
+        } else {                                                                                                       \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, EP, 0, false, true, false>), LDS2P);                           \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, EP, 0, false, true, false>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0); \
+        }                                                                                                              \
     } while (0)
     if (d->dtype == UMR_BF16X3) {   // eligibility checked by umr_gemm_nt (gemm_nt.hip)
         const int npairs = npairs_x3;
         if (d->red_w) {
-            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, true, true>), LDS2P);
-            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0);
+            if (two) {
+                UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, true, true, true>), LDS2P);
+                hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true, true>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0);
+            } else {
+                UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, true, true, false>), LDS2P);
+                hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, true, true, false>), g, b, LDS2P, s, *d, tiles_n, (int)total, stagger, bm, npairs, 0);
+            }
         } else if (ksplit > 1) {
             // work items write raw f32 sums to their slab; the finish kernel applies the caller's epilogue
             umr_gemm_desc sd = *d;
@@ -1104,8 +1150,13 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
             const int kt_per = (kt_all + ksplit - 1) / ksplit;
 #define L256PXS(CV)                                                                                                    \
     do {                                                                                                               \
-        UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, 5, 0, false, true>), LDS2P);                                      \
-        hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true>), g, b, LDS2P, s, *dd, tiles_n, (int)total, stagger, bm, npairs, kt_per); \
+        if (CV == 1 || two) {                                                                                          \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<CV, 5, 0, false, true, true>), LDS2P);                            \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<CV, 5, 0, false, true, true>), g, b, LDS2P, s, *dd, tiles_n, (int)total, stagger, bm, npairs, kt_per); \
+        } else {                                                                                                       \
+            UMR_SET_MAX_LDS_ONCE((gemm_nt256p_kernel<0, 5, 0, false, true, false>), LDS2P);                            \
+            hipLaunchKernelGGL((gemm_nt256p_kernel<0, 5, 0, false, true, false>), g, b, LDS2P, s, *dd, tiles_n, (int)total, stagger, bm, npairs, kt_per); \
+        }                                                                                                              \
     } while (0)
             if (d->conv == 0) L256PXS(0); else L256PXS(1);
 #undef L256PXS

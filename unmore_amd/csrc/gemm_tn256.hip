@@ -261,7 +261,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256_kernel(const umr_gemm_tn_de
 #ifndef UMR_EXP_TN_PRIO_MODE
 #define UMR_EXP_TN_PRIO_MODE 1   // conv weight gradient, same box: 33.7 / 33.2 / 33.4 ms for modes 0 / 1 / 3
 #endif
-    constexpr int PRIO_MODE = (CONV == 1 && PH2) ? UMR_EXP_TN_PRIO_MODE : 0;   // as in gemm_nt256p.hip
+    // static priority for waves 4-7 in the two-phase form, as in gemm_nt256p.hip; round 4: for the plain weight gradients as well
+    // (about -1 %: 1x1 head 7.81 -> 7.73 ms, ViT-B fc1 182.6 -> 174.0 us; profiles/r04_plain_gemm_two_phase_ab.txt)
+    constexpr int PRIO_MODE = PH2 ? UMR_EXP_TN_PRIO_MODE : 0;
 #define QPRIO(x) if (PRIO_MODE == 0) __builtin_amdgcn_s_setprio(x);
 #define QUADRANT_D(N0, K0, FX, DMA_A, DMA_B)                                                         \
     QPRIO(1)                                                                                        \

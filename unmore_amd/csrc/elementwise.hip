@@ -152,46 +152,64 @@ __device__ __forceinline__ void ld_bf16x8(const bf16_t* p, float (&f)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (float)t[j];
 }
-// forward: a thread computes the same (ox, 8 channels) of FOUR consecutive output rows: its 16 loads are issued before the first
-// is used (one element per thread left the kernel latency-bound at 3.4 TB/s: tools/bilinear_bench.py)
+// forward, streaming over a run of output rows (round 4): a thread owns the column (ox, 8 channels) and keeps the x-interpolated vectors
+// of the two input rows the current output row blends; when the upper row moves on by one (every second output row at a x2 resize) the
+// lower vector becomes the upper one and ONE new input row is needed -- its two taps were requested when the previous row was
+// taken.  Two loads per new input row instead of sixteen per four output rows (most of them repeats that cost load-unit slots): the
+// kernel is left with its stores.  Same expression as the gather form (x first, then y).
 __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
-                                                                int Wo, int C, int align, int64_t ldx, int64_t ldy, int relu) {
-    constexpr int R = 4;
+                                                                int Wo, int C, int align, int64_t ldx, int64_t ldy, int relu, int RUN) {
     const float floor_ = relu ? 0.f : -INFINITY;
     const int cv = C >> 3;
     const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
-    const int groups = (Ho + R - 1) / R;
-    for (int bg = blockIdx.y; bg < B * groups; bg += gridDim.y) {
-        const int b = bg / groups, oy0 = (bg - b * groups) * R;
-        const bf16_t* xb = x + (int64_t)b * Hi * Wi * ldx;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
-            const int ox = i / cv, c = (i - ox * cv) * 8;
-            int x0, x1;
-            float lx0, lx1;
-            src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
-            bf16x8 t[R][4];
-            float ly0[R], ly1[R];
+    const int runs_per_image = (Ho + RUN - 1) / RUN;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
+        const int ox = i / cv, c = (i - ox * cv) * 8;
+        int x0, x1;
+        float lx0, lx1;
+        src_index(ox, sw, align, Wi, x0, x1, lx0, lx1);
+        const int64_t o0 = (int64_t)x0 * ldx + c, o1 = (int64_t)x1 * ldx + c;
+        for (int run = blockIdx.y; run < B * runs_per_image; run += gridDim.y) {
+            const int b = run / runs_per_image, oy0 = (run - b * runs_per_image) * RUN;
+            const int oy1 = min(Ho, oy0 + RUN);
+            const bf16_t* xb = x + (int64_t)b * Hi * Wi * ldx;
+            auto row_taps = [&](int yy, bf16x8& a, bf16x8& bb) {
+                const bf16_t* r = xb + (int64_t)(yy < Hi ? yy : Hi - 1) * Wi * ldx;
+                a = *(const bf16x8*)(r + o0);
+                bb = *(const bf16x8*)(r + o1);
+            };
+            auto xin = [&](const bf16x8& a, const bf16x8& bb, float (&v)[8]) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int oy = min(oy0 + r, Ho - 1);
+                for (int j = 0; j < 8; ++j) v[j] = lx0 * (float)a[j] + lx1 * (float)bb[j];
+            };
+            float vA[8], vB[8];
+            bf16x8 na, nb;            // taps of input row cury + 2, in flight
+            int cury = -4;
+            for (int oy = oy0; oy < oy1; ++oy) {
                 int y0, y1;
-                src_index(oy, sh, align, Hi, y0, y1, ly0[r], ly1[r]);
-                const bf16_t* r0 = xb + (int64_t)y0 * Wi * ldx + c;
-                const bf16_t* r1 = xb + (int64_t)y1 * Wi * ldx + c;
-                t[r][0] = *(const bf16x8*)(r0 + (int64_t)x0 * ldx);
-                t[r][1] = *(const bf16x8*)(r0 + (int64_t)x1 * ldx);
-                t[r][2] = *(const bf16x8*)(r1 + (int64_t)x0 * ldx);
-                t[r][3] = *(const bf16x8*)(r1 + (int64_t)x1 * ldx);
-            }
+                float l0, l1;
+                src_index(oy, sh, align, Hi, y0, y1, l0, l1);
+                if (y0 != cury) {     // block-uniform
+                    if (y0 == cury + 1) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (oy0 + r >= Ho) break;
+                        for (int j = 0; j < 8; ++j) vA[j] = vB[j];
+                        xin(na, nb, vB);                       // input row cury + 2 = y0 + 1 (clamped = y1)
+                    } else {
+                        bf16x8 a0, b0, a1, b1;
+                        row_taps(y0, a0, b0);
+                        row_taps(y0 + 1, a1, b1);
+                        xin(a0, b0, vA);
+                        xin(a1, b1, vB);
+                    }
+                    cury = y0;
+                    row_taps(y0 + 2, na, nb);
+                }
+                // y1 == y0 only at the clamped last row, where vB was built from the same (clamped) row: the same value either way
                 bf16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = (bf16_t)fmaxf(ly0[r] * (lx0 * (float)t[r][0][j] + lx1 * (float)t[r][1][j]) + ly1[r] * (lx0 * (float)t[r][2][j] + lx1 * (float)t[r][3][j]), floor_);
-                *(bf16x8*)(y + (((int64_t)b * Ho + oy0 + r) * Wo + ox) * ldy + c) = o;
+                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)fmaxf(l0 * vA[j] + l1 * vB[j], floor_);
+                *(bf16x8*)(y + (((int64_t)b * Ho + oy) * Wo + ox) * ldy + c) = o;
             }
         }
     }
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
 // a per-tap `continue` left one load in flight per thread (3.3 TB/s on the final x2 resize).
 template <int NCX>
 __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B, int Hi, int Wi, int Ho,
-                                                                int Wo, int C, int align, int64_t lddy, int64_t lddx) {
+                                                                int Wo, int C, int align, int64_t lddy, int64_t lddx, int RUN) {
     constexpr int NC = 8;
     const int cv = C >> 3;
     const int rowlen = Wi * cv;
@@ -231,33 +249,69 @@ __global__ __launch_bounds__(256) void bilinear_bwd_bf16x8_kernel(const bf16_t* 
         int xoff[NCX];       // element offsets of the NCX candidate columns, clamped inside the row
 #pragma unroll
         for (int kx = 0; kx < NCX; ++kx) xoff[kx] = ((xlo + kx < Wo ? xlo + kx : Wo - 1) - xlo) * (int)lddy;
-        for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
-            const int b = by / Hi, iy = by - b * Hi;
-            int ylo;
-            float wy[NC];
-            weights(iy, sh, Hi, Ho, ylo, wy);
+        // Streaming over the OUTPUT rows (round 4).  An output row touches two neighbouring input rows, so gathering per input row
+        // read every output row twice (three candidate rows per input row at a x2 resize) -- and the second read came from HBM again:
+        // a CU's resident blocks keep ~0.6 MB of rows in flight, 19 MB per XCD against 4 MB of L2 (the 512-channel adjoint of the head
+        // layer fetched 14.4 GB for a 9.7-GB operand).  Here a block owns a run of input rows [iy0, iy1) of one image and walks the
+        // output rows that touch it ONCE, in order: row oy adds l0 * v to input row y0(oy) and l1 * v to y0 + 1 (v = the x-gathered
+        // row), y0 never decreases, so two accumulators are live and a finished input row is stored when y0 moves past it.  All
+        // control flow is block-uniform.  Only the run's first and last output rows are read by the neighbouring run as well.
+        const int runs_per_image = (Hi + RUN - 1) / RUN;
+        for (int run = blockIdx.y; run < B * runs_per_image; run += gridDim.y) {
+            const int b = run / runs_per_image, iy0 = (run - b * runs_per_image) * RUN;
+            const int iy1 = min(Hi, iy0 + RUN);
+            // output rows whose y0 lies in [iy0 - 1, iy1 - 1]
+            int oy_lo = (sh > 0.f) ? (int)floorf(((float)iy0 - 1.f) / sh - 1e-3f) - 1 : 0;
+            int oy_hi = (sh > 0.f) ? (int)ceilf((float)iy1 / sh + 1e-3f) + 1 : Ho - 1;
+            if (oy_lo < 0) oy_lo = 0;
+            if (oy_hi > Ho - 1) oy_hi = Ho - 1;
             const bf16_t* base = dy + (int64_t)b * Ho * Wo * lddy + (int64_t)xlo * lddy + c;
-            float acc[8];
+            bf16_t* xcol = dx + ((int64_t)b * Hi * Wi + ix) * lddx + c;
+            float accA[8], accB[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+            for (int j = 0; j < 8; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+            int cur = iy0 - 1;                       // the input row accA belongs to (accB: cur + 1)
+            auto retire = [&]() {                    // accA is complete: store it if the row is ours, then shift
+                if (cur >= iy0 && cur < iy1) {
+                    bf16x8 o;
 #pragma unroll
-            for (int ky = 0; ky < NC; ++ky) {
-                if (wy[ky] == 0.f) continue;          // block-uniform
-                const bf16_t* rowp = base + (int64_t)(ylo + ky) * Wo * lddy;
-                bf16x8 t[NCX];
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)accA[j];
+                    *(bf16x8*)(xcol + (int64_t)cur * Wi * lddx) = o;
+                }
 #pragma unroll
-                for (int kx = 0; kx < NCX; ++kx) t[kx] = *(const bf16x8*)(rowp + xoff[kx]);
+                for (int j = 0; j < 8; ++j) { accA[j] = accB[j]; accB[j] = 0.f; }
+                ++cur;
+            };
+            bf16x8 t[NCX], tn[NCX];
+#pragma unroll
+            for (int kx = 0; kx < NCX; ++kx) tn[kx] = *(const bf16x8*)(base + (int64_t)oy_lo * Wo * lddy + xoff[kx]);
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+#pragma unroll
+                for (int kx = 0; kx < NCX; ++kx) t[kx] = tn[kx];
+                if (oy < oy_hi) {                    // the next row's taps go out before this row is used
+                    const bf16_t* rowp = base + (int64_t)(oy + 1) * Wo * lddy;
+#pragma unroll
+                    for (int kx = 0; kx < NCX; ++kx) tn[kx] = *(const bf16x8*)(rowp + xoff[kx]);
+                }
+                int y0, y1;
+                float l0, l1;
+                src_index(oy, sh, align, Hi, y0, y1, l0, l1);
+                if (y0 < cur) continue;              // a row before the run (block-uniform)
+                while (y0 > cur && cur < iy1) retire();
+                if (cur >= iy1) break;               // everything of the run is stored
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
 #pragma unroll
                 for (int kx = 0; kx < NCX; ++kx) {
-                    const float wgt = wy[ky] * wx[kx];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += (float)t[kx][j] * wgt;
+                    for (int j = 0; j < 8; ++j) v[j] += (float)t[kx][j] * wx[kx];
                 }
-            }
-            bf16x8 o;
+                if (y1 == y0) l0 += l1;              // clamped at the last input row: both taps are that row
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)acc[j];
-            *(bf16x8*)(dx + ((int64_t)by * Wi + ix) * lddx + c) = o;
+                for (int j = 0; j < 8; ++j) { accA[j] += l0 * v[j]; if (y1 != y0) accB[j] += l1 * v[j]; }
+            }
+            while (cur < iy1) retire();
         }
     }
 }
@@ -970,9 +1024,12 @@ extern "C" int umr_bilinear_fwd_ex(const void* x, int64_t ldx, void* y, int64_t 
         if (planes) {
             hipLaunchKernelGGL((bilinear_fwd_kernel<float, 2, true>), g, dim3(256), 0, s, (const float*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu);
         } else if (nv == 2 && dtype == UMR_BF16) {
-            int64_t gy4 = (int64_t)B * ((Ho + 3) / 4);
-            if (gy4 > bilinear_gy_cap()) gy4 = bilinear_gy_cap();
-            hipLaunchKernelGGL(bilinear_fwd_bf16x8_kernel, dim3(g.x, (unsigned)gy4), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu);
+            // rows of a run (see the kernel): 16 where that still leaves >= 2048 blocks, fewer on small maps
+            int run = 16;
+            while (run > 2 && (int64_t)B * ((Ho + run - 1) / run) * g.x < 2048) run = (run + 1) / 2;
+            int64_t runs = (int64_t)B * ((Ho + run - 1) / run);
+            if (runs > bilinear_gy_cap()) runs = bilinear_gy_cap();
+            hipLaunchKernelGGL(bilinear_fwd_bf16x8_kernel, dim3(g.x, (unsigned)runs), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu, run);
         }
         else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu)); }
         else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)x, y, B, Hi, Wi, Ho, Wo, C, align_corners, ldx, ldy, relu)); }
@@ -1005,12 +1062,15 @@ extern "C" int umr_bilinear_bwd_ex(const void* dy, int64_t lddy, void* dx, int64
         const float sw_ = align_corners ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) : (float)Wi / (float)Wo;
         if (nv == 2 && dtype == UMR_BF16 && sh_ >= 0.4f && sw_ >= 0.4f)    // <= 8 candidate outputs per axis (see the kernel)
         {
-            // the x weights are per thread, not per row: a block should visit several rows (1.80 ms with one row per block,
-            // 1.57-1.59 with 3-12 on the final x2 resize at cfg2, tools/bilinear_bench.py)
-            if (getenv("UMR_BILINEAR_GY") == nullptr && g.y > 2048) g.y = 2048;
+            // rows of a run (see the kernel): 12 where that still leaves >= 2048 blocks, fewer on small maps
+            int run = 12;
+            while (run > 2 && (int64_t)B * ((Hi + run - 1) / run) * g.x < 2048) run = (run + 1) / 2;
+            int64_t runs = (int64_t)B * ((Hi + run - 1) / run);
+            if (runs > bilinear_gy_cap()) runs = bilinear_gy_cap();
+            g.y = (unsigned)runs;
             // align_corners: contributors of input column i are the outputs o with o * sw in (i - 1, i + 1): at most lo + 5 for sw >= 0.49
-            if (align_corners && sw_ >= 0.49f) hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<6>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx);
-            else hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<8>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx);
+            if (align_corners && sw_ >= 0.49f) hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<6>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx, run);
+            else hipLaunchKernelGGL(bilinear_bwd_bf16x8_kernel<8>, g, dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx, run);
         }
         else if (nv == 2) { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 2>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx)); }
         else { DISPATCH_T(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, 1>), g, dim3(256), 0, s, (const T*)dy, (T*)dx, B, Hi, Wi, Ho, Wo, C, align_corners, lddy, lddx)); }

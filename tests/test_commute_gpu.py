@@ -25,8 +25,8 @@ def _net(backbone, tag, dtype=torch.float32, args=ARGS):
     return net, sd
 
 
-def _ref_resize(x, Ho, Wo):
-    return F.interpolate(x.permute(0, 3, 1, 2).double(), size=(Ho, Wo), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+def _ref_resize(x, Ho, Wo, align=True):
+    return F.interpolate(x.permute(0, 3, 1, 2).double(), size=(Ho, Wo), mode="bilinear", align_corners=align).permute(0, 2, 3, 1)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -56,6 +56,29 @@ def test_resize_on_column_slices_with_relu(dtype, shape):
     lhs = (ref * dy.double().cpu()).sum()
     rhs = (x.double().cpu() * dense.double().cpu()).sum()
     assert abs(lhs - rhs) <= (1e-5 if dtype == torch.float32 else 2e-2) * (ref.abs() * dy.double().cpu().abs()).sum()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape", [(2, 24, 40, 32, 12, 20), (1, 1, 7, 16, 5, 14), (2, 37, 37, 64, 74, 74), (1, 30, 30, 24, 44, 52), (3, 5, 6, 8, 64, 3)])
+def test_row_stream_resizes_at_other_scales(dtype, align, shape):
+    """the bf16 resize kernels walk runs of rows (csrc/elementwise.hip): down-scaling, a single input row, x2 on an odd size, odd
+    ratios, more runs than rows -- forward against torch, the adjoint through <U x, dy> == <x, U^T dy> and against float64 autograd"""
+    from unmore_amd import ops
+    B, Hi, Wi, C, Ho, Wo = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn((B, Hi, Wi, C), generator=g).to(dtype).cuda()
+    dy = torch.randn((B, Ho, Wo, C), generator=g).to(dtype).cuda()
+    xr = x.double().cpu().requires_grad_(True)
+    ref = _ref_resize(xr, Ho, Wo, align)
+    # (the interpolation weights are f32 here as in the reference's f32 run; against float64 weights that is ~1e-6 of a weight)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    y = ops.bilinear_fwd(x, Ho, Wo, align)
+    torch.testing.assert_close(y.double().cpu(), ref.detach(), atol=tol, rtol=tol)
+    (ref * dy.double().cpu()).sum().backward()
+    dx = ops.bilinear_bwd(dy, Hi, Wi, align)
+    scale = max(1.0, (Ho * Wo) / (Hi * Wi))          # an input pixel sums that many output pixels
+    torch.testing.assert_close(dx.double().cpu(), xr.grad, atol=tol * scale, rtol=tol)
 
 
 def test_resize_writes_planes():

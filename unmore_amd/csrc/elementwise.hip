@@ -95,13 +95,17 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, void* __restrict__ 
     }
 }
 
-// exact adjoint by gathering: for input pixel (iy,ix) visit the few output pixels whose taps touch it
-__device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, int& hi) {
+// exact adjoint by gathering: for input pixel (iy,ix) visit the few output pixels whose taps touch it.  Output o reads at
+// s(o) = scale * o (align_corners) or scale * (o + 0.5) - 0.5 clamped at 0; it touches input i when s lies in (i - 1, i + 1) -- plus,
+// without align_corners, every o whose s was clamped to the first / last input pixel (round 4: the half-pixel offsets were missing
+// from this range and strongly up-scaling resizes without align_corners lost contributors; tests/test_commute_gpu.py)
+__device__ __forceinline__ void out_range(int i, float scale, int in, int out, int align, int& lo, int& hi) {
     if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
-    lo = (int)floorf(((float)i - 1.f) / scale) - 1;
-    hi = (int)ceilf(((float)i + 1.f) / scale) + 1;
-    if (lo < 0) lo = 0;
-    if (hi > out - 1) hi = out - 1;
+    const float off = align ? 0.f : 0.5f;
+    lo = (int)floorf(((float)i - 1.f + off) / scale - off) - 1;
+    hi = (int)ceilf(((float)i + 1.f + off) / scale - off) + 1;
+    if (lo < 0 || i == 0) lo = 0;
+    if (hi > out - 1 || i == in - 1) hi = out - 1;
 }
 
 template <typename T, int NV>
@@ -114,13 +118,13 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
     for (int by = blockIdx.y; by < B * Hi; by += gridDim.y) {
         const int b = by / Hi, iy = by - b * Hi;
         int ylo, yhi;
-        out_range(iy, sh, Ho, ylo, yhi);
+        out_range(iy, sh, Hi, Ho, align, ylo, yhi);
         const T* base = dy + (int64_t)b * Ho * Wo * lddy;
         T* xr = dx + (int64_t)by * Wi * lddx;
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rowlen; i += gridDim.x * blockDim.x) {
             const int ix = i / cv, c = (i - ix * cv) * 4 * NV;
             int xlo, xhi;
-            out_range(ix, sw, Wo, xlo, xhi);
+            out_range(ix, sw, Wi, Wo, align, xlo, xhi);
             f32x4 acc[NV];
 #pragma unroll
             for (int v = 0; v < NV; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};

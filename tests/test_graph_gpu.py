@@ -146,3 +146,26 @@ def test_weight_gradient_stream_does_not_change_results(dtype, graph, monkeypatc
             assert step.graph_replays == 3
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+def test_capture_scratch_is_per_stream_and_outgrown_buffers_stay_alive(monkeypatch):
+    """ops._workspace / _splitk_workspace / the plane GEMMs' K-split scratch inside a capture: one buffer per STREAM of the capture (the
+    weight-gradient branch of a train step runs beside the main branch in a replay -- sharing one scratch made
+    test_weight_gradient_stream_does_not_change_results[on-float32] fail about one run in three), and a buffer that a later, larger
+    request replaces is kept: launches recorded earlier still point at it."""
+    from unmore_amd import graphs, ops
+    dev = torch.device("cuda:0")
+    store = {}
+    monkeypatch.setitem(graphs._state, "capturing", True)
+    monkeypatch.setitem(graphs._state, "store", store)
+    side = torch.cuda.Stream(device=dev)
+    a = ops._workspace(1 << 20, dev)
+    assert ops._workspace(1 << 10, dev) is a                       # reused on the same stream
+    sk = ops._splitk_workspace(dev)
+    with torch.cuda.stream(side):
+        b = ops._workspace(1 << 20, dev)
+        skb = ops._splitk_workspace(dev)
+    assert b.data_ptr() != a.data_ptr() and skb.data_ptr() != sk.data_ptr()
+    big = ops._workspace(8 << 20, dev)                              # outgrows a: a new buffer, the old one stays referenced
+    assert big.data_ptr() != a.data_ptr() and any(t is a for t in store["outgrown"])
+    assert (sk[:16384] == 0).all() and (skb[:16384] == 0).all()     # tile counters start at zero on either stream

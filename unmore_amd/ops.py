@@ -72,10 +72,16 @@ def _workspace(nbytes, device):
     if graphs.capturing():
         # a captured graph owns its scratch (allocated from the capture's private pool, kept alive by the Captured object): two
         # graphs recorded on the same internal capture stream may be replayed on different streams at the same time
+        # ... and one PER STREAM of the capture: the weight-gradient branch of a train step (engine.WgradStream) may run beside the
+        # main branch in a replay, as it does eagerly.  A buffer that was outgrown stays alive with the capture: launches recorded
+        # earlier still point at it, and the pool must not hand it to a tensor of the other branch.
         store = graphs.capture_store()
-        buf = store.get("ws")
+        key = ("ws", _stream_id(device.index))
+        buf = store.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = store["ws"] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            if buf is not None:
+                store.setdefault("outgrown", []).append(buf)
+            buf = store[key] = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         return buf
     key = (device.index, _stream_id(device.index))
     buf = _ws_cache.pop(key, None)
@@ -94,9 +100,10 @@ def _splitk_workspace(device):
     """Per-(device, stream) scratch of umr_gemm_nt_ws: tile counters (zeroed once here; every launch leaves them zero) + slabs."""
     if graphs.capturing():
         store = graphs.capture_store()   # see _workspace; the zeroing of the counters is recorded too: every replay starts clean
-        buf = store.get("sk")
+        key = ("sk", _stream_id(device.index))
+        buf = store.get(key)
         if buf is None:
-            buf = store["sk"] = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
+            buf = store[key] = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
             buf[:16384].zero_()
         return buf
     key = (device.index, _stream_id(device.index))
@@ -252,9 +259,12 @@ def _x3_workspace(d, device):
     need = int(L.lib().umr_gemm_nt_workspace()) + extra
     if graphs.capturing():
         store = graphs.capture_store()
-        buf = store.get("x3ws")
+        key = ("x3ws", _stream_id(device.index))
+        buf = store.get(key)
         if buf is None or buf.numel() < need:
-            buf = store["x3ws"] = torch.empty(need, dtype=torch.uint8, device=device)
+            if buf is not None:
+                store.setdefault("outgrown", []).append(buf)
+            buf = store[key] = torch.empty(need, dtype=torch.uint8, device=device)
         return buf
     key = (device.index, _stream_id(device.index))
     buf = _x3_ws_cache.pop(key, None)

@@ -19,6 +19,12 @@ if which == "convnt":
     w3 = (torch.randn((512, 4608), generator=g) * 0.02).to(dev).to(dt)
     out = torch.empty((M, 512), dtype=dt, device=dev)
     fn = lambda: ops.gemm_nt(x512, w3, torch.zeros(512, device=dev), conv=1, act=L.ACT_RELU, out=out)
+elif which == "convnt_masked":
+    # the centre head's ReLU-masked 3x3 data gradient
+    w3 = (torch.randn((512, 4608), generator=g) * 0.02).to(dev).to(dt)
+    out = torch.empty((M, 512), dtype=dt, device=dev)
+    h1 = torch.randn((M // 8, 512), generator=g).to(dt).to(dev).repeat(8, 1)
+    fn = lambda: ops.gemm_nt(x512, w3, None, conv=1, aux=h1, mask_relu=True, out=out)
 elif which == "convtn":
     dy = torch.randn((M, 512), generator=g).to(dev).to(dt)
     fn = lambda: ops.gemm_tn(dy, x512, conv=1)

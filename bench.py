@@ -542,12 +542,22 @@ def run_rank(a):
             # boundary-distance head's data- and weight-gradient GEMMs (2 x its forward) are not run
             head_fwd_gflop = 2.0 * H * W * (256 * 512 + 9 * 512 * 512 + 512 * 1024 + 1024) / 1e9
             skipped = 2.0 * head_fwd_gflop if net._engine().linear_head_backward == "algebraic" and not net._layouts[1]["relu"] and net._layouts[1]["final"] != "sine" else 0.0
+            from unmore_amd import engine as _eng
+            if _eng._COMMUTE_RESIZE:
+                # 1x1 layers that run BEFORE the x2 resize that precedes them in the reference (engine._COMMUTE_RESIZE): a quarter of
+                # the rows in their forward, data-gradient and weight-gradient GEMMs.  The heads' first layer (centre: all three;
+                # boundary-distance: forward only when its backward is algebraic, already counted above) and the fusion blocks' out_conv
+                w1 = 2.0 * H * W * 256 * 512 / 1e9
+                ocv = sum(2.0 * (H / 2 ** k) * (W / 2 ** k) * 256 * 256 / 1e9 for k in (1, 2, 3, 4))
+                skipped += 0.75 * (3 * w1 + (1 if skipped else 3) * w1 + 3 * ocv)
             res["train_tflops_per_gpu"] = 3 * fwd_gflop * B * a.steps / elapsed / 1e3
-            res["train_tflops_note"] = "MODEL FLOPs (3 x forward formula); executed_tflops_per_gpu counts what the step runs"
+            res["train_tflops_note"] = "MODEL FLOPs (3 x forward formula of the reference's order of operations); executed_tflops_per_gpu counts what the step runs (algebraic head backward, 1x1 layers before the resizes)"
             res["executed_tflops_per_gpu"] = (3 * fwd_gflop - skipped) * B * a.steps / elapsed / 1e3
             res["final_loss"] = float(last[0][0].item())
         elif kind == "forward":
             res["forward_tflops_per_gpu"] = fwd_gflop * B * a.steps / elapsed / 1e3
+            res["forward_tflops_note"] = ("MODEL FLOPs of the reference's order of operations; the heads' first layer and the fusion blocks' "
+                                          "out_conv run before the x2 resize that precedes them (a quarter of the rows): ~2 % fewer executed")
         else:
             res["crops_per_sec"] = world * wl["proposals"] * a.steps / elapsed
             res["config"].update({"proposals_per_image": wl["proposals"], "crop": [128, 128], "crops_per_batch": 50,

@@ -487,6 +487,15 @@ def run_rank(a):
             one()
     conv_ms = ops.kernel_timer_results_ms()
     ops.set_kernel_timer(None)
+    ar_trace = None
+    if world > 1 and kind == "train":
+        # one more, untimed step with the exchange traced: per bucket, when its all-reduce was issued and when it completed, against
+        # the end of backward (parallel.BucketedAllReduce.trace_report) -- how much of the exchange hides behind backward
+        step.comm.trace = True
+        one()
+        ar_trace = step.comm.trace_report()
+        step.comm.trace = False
+        barrier()
     own = gather_over_ranks(elapsed)
     elapsed = max_over_ranks(elapsed)
 
@@ -529,13 +538,15 @@ def run_rank(a):
             "roofline": {"bound": "mfma",
                          "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 of the heads ("
                                     + ("per step: 2 forward launches + the centre head's ReLU-masked data gradient; the boundary-distance head's "
-                                       "backward is algebraic and the weight gradient is the TN kernel" if kind == "train" else "forward, one launch per head and batch")
+                                       "backward is algebraic and the weight gradient is the TN kernel" if kind == "train" else "forward: the centre head's launch of every batch; the boundary-distance head runs collapsed")
                                     + (") bf16" if a.dtype == "bf16" else (") fp32-grade: f32 values as three bf16 planes, six bf16 MFMA products per "
                                                                           "f32 product; peak = 2500 / 6" if x3 else ") f32 MFMA"))),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "launches_timed": len(conv_ms), "avg_launch_ms": avg_ms, "flop_per_launch": conv_flop,
                          **measured_traffic(a, M_head)},
         }
+        if ar_trace is not None:
+            res["allreduce_trace_rank0"] = ar_trace
         if kind == "train":
             res["config"].update({"optimizer": "Adam lr=1e-4", "loss": "l2 center + l1 sdf + l1 sdf-gradient + bce"})
             # model FLOPs (3 x forward) and the FLOPs this step actually executes: with the algebraic backward the
@@ -605,6 +616,20 @@ def run_rank(a):
                                          "max_abs_map_difference_vs_6term": float(max((pf[k] - p6[k]).abs().max().item() for k in ("center_fields", "sdf_maps"))),
                                          "note": "opt-in umr_set_f32_mode(UMR_F32_X3_FAST): three instead of six bf16 products per f32 product in the heads' "
                                                  "plane GEMMs (2^-16 per product); not the headline"}
+                # the other way round (A/B of the inference default): the boundary-distance head as the reference's four convolutions
+                # instead of its collapsed form (one 3x3 conv 256 -> 1), same image, all 1225 proposals compared
+                net.set_sdf_head_mode("factored")
+                dtF = timed_sweeps(2)
+                mxF, amF, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
+                with torch.no_grad():
+                    pF = net.get_prediction(crops_chk)
+                net.set_sdf_head_mode("auto")
+                res["alt_fp32_factored_sdf_head"] = {"value": 1.0 / dtF, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dtF,
+                                                     "maps_with_peak": int((mxF > 0).sum().item()),
+                                                     "peak_index_differs_from_headline": int((amF != am0).sum().item()),
+                                                     "max_abs_map_difference_vs_headline": float(max((pF[k] - p6[k]).abs().max().item() for k in ("center_fields", "sdf_maps"))),
+                                                     "note": "set_sdf_head_mode('factored'): the head's four convolutions as the reference runs them; the headline is "
+                                                             "the inference default ('auto': collapsed under no_grad, qualified in tests/test_collapsed_head_gpu.py)"}
                 # beside the headline: the same sweep with bf16 storage (no bit-exact-peak claim) ...
                 net.set_compute_dtype(torch.bfloat16)
                 dt2 = timed_sweeps(2)
@@ -613,12 +638,12 @@ def run_rank(a):
                                    "maps_with_peak": int((mxb > 0).sum().item()),
                                    "peak_index_differs_from_fp32_mode": int((amb != am0).sum().item()),
                                    "note": "bf16 storage / bf16 MFMA: throughput mode, maps within ~3e-2 of the reference, peak indices NOT claimed"}
-                # ... and bf16 with the opt-in collapsed forward of the boundary-distance head (one 3x3 conv 256 -> 1)
-                net.set_sdf_head_mode("collapsed")
-                dt3 = timed_sweeps(2)
+                # ... and bf16 with the boundary-distance head's four convolutions
                 net.set_sdf_head_mode("factored")
-                res["alt_bf16_collapsed_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
-                                                      "note": "opt-in algebraic fast path; not the headline configuration"}
+                dt3 = timed_sweeps(2)
+                net.set_sdf_head_mode("auto")
+                res["alt_bf16_factored_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
+                                                     "note": "bf16 with set_sdf_head_mode('factored')"}
                 net.set_compute_dtype(dt)
             else:
                 net.set_compute_dtype(torch.float32)
@@ -626,6 +651,23 @@ def run_rank(a):
                 net.set_compute_dtype(dt)
                 res["alt_fp32_parity_mode"] = {"value": 1.0 / dt2, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt2,
                                                "note": "fp32 storage, fp32-grade products (UMR_F32_X3): the 1e-4 maps / bit-exact-peaks mode; the default --dtype of this workload"}
+        if kind != "train":
+            res["sdf_head"] = ("inference default 'auto': the boundary-distance head (no non-linearity before its tanh, objectness_net.py:128-135) "
+                               "evaluated as one 3x3 conv 256 -> 1 on the map before the final resize; 'factored' leg beside it")
+        if world == 1 and kind == "forward" and not a.no_alt:
+            # the same call with the boundary-distance head as the reference's four convolutions (A/B of the inference default)
+            net.set_sdf_head_mode("factored")
+            for _ in range(graphs.WARMUP_CALLS + 2):
+                one()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                one()
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t1) / a.steps
+            net.set_sdf_head_mode("auto")
+            res["alt_factored_sdf_head"] = {"value": B / dtf, "unit": "images/sec", "ms_per_step": 1e3 * dtf,
+                                            "note": "set_sdf_head_mode('factored'): the head's four convolutions as the reference runs them"}
         if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
             # algebraic form of the linear boundary-distance head (identical function and gradients

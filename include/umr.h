@@ -46,6 +46,16 @@ enum umr_f32_mode { UMR_F32_EXACT = 0, UMR_F32_X3 = 1, UMR_F32_X3_FAST = 2 };
 int umr_set_f32_mode(int mode);   /* returns UMR_OK or UMR_ERR_INVALID */
 int umr_get_f32_mode(void);
 
+/* CU budget of the persistent GEMM grids (umr_gemm_nt on the 256x256 kernel: one workgroup owns a CU's whole LDS).  0 (default;
+ * env UMR_CU_BUDGET) = the grid is a small multiple of the CU count and the dispatcher balances it; n > 0 = the grid is exactly
+ * min(n, CUs) workgroups, so the other CUs stay free for kernels that must run BESIDE it -- RCCL's all-reduce of the previous
+ * gradient bucket during backward (data-parallel training, train_objectness_net.py has no such step: build-defined).  Tile shape
+ * and K-split are planned on the device's CU count either way, and every output element's K sum is the same instruction
+ * sequence in any workgroup: results are bit-identical across budgets.  The weight-gradient kernel (umr_gemm_tn) launches
+ * (split, tile) workgroups whose count does not depend on the CU count and needs no budget.  Process-wide, run-time. */
+int umr_set_cu_budget(int cus);   /* returns UMR_OK or UMR_ERR_INVALID */
+int umr_get_cu_budget(void);
+
 /* ---- GEMM "NT" with implicit 3x3 convolution and fused epilogue ------------
  * C[M,N] = epi(A[M,K] . B[N,K]^T), fp32 accumulate on MFMA.
  * Replaces torch.nn.Linear / 1x1 nn.Conv2d (models/dpt/vit.py:84,263-327,
@@ -314,6 +324,11 @@ int umr_linear_head_bwd_weight(const void* x, const float* dout, const float* yo
 int64_t umr_linear_head_shift9_workspace(int64_t M);
 int umr_linear_head_shift9(const float* dout, const float* yout, void* s9, float* nd, void* workspace, int64_t workspace_bytes,
                            int B, int H, int W, int act, int dtype, umr_stream_t stream);
+/* gather9 (forward mirror of shift9): with taps[q][t] = kw[t] . x(q) given as a [B*H*W] map of >= 9 f32 channels (pixel stride ldt) --
+ * for x = resize(y) that is the resize of the 16-column product y kw^T taken on the small map --
+ * out(q) = act( sum_{t: q + off_t inside the image} (taps[q + off_t][t] + tapbias10[t]) + tapbias10[9] ), out [B,1,H,W] f32. */
+int umr_linear_head_gather9(const float* taps, int64_t ldt, const float* tapbias10, float* out, int B, int H, int W, int act,
+                            umr_stream_t stream);
 /* C[i*sc_m + j*sc_n] (=|+=) sum_k A[i*sa_m + k*sa_k] * B[k*sb_k + j*sb_n]  (tiny f32 products, arbitrary strides) */
 int umr_small_gemm_f32(const float* A, const float* B, float* C, int M, int N, int K, int64_t sa_m, int64_t sa_k, int64_t sb_k,
                        int64_t sb_n, int64_t sc_m, int64_t sc_n, int accumulate, umr_stream_t stream);

@@ -10,7 +10,7 @@ from oracle import mask_parity
 from oracle import objectness_oracle as orc
 
 
-def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, grads_out=None, **head_kw):
+def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, grads_out=None, masks_out=None, **head_kw):
     """net: unmore_amd ObjectnessNet on the GPU in fp32 mode holding `sd`.  Returns (worst max-norm error / max|g|, its
     parameter, worst relative L2, number of ReLU decisions that differ from float64's own)."""
     from unmore_amd import ops
@@ -18,6 +18,8 @@ def masked_gradient_check(net, sd, cfg_name, img, cf, sdf, sal, bar=5e-5, grads_
     P = {n: p.detach() for n, p in net.named_parameters()}
     c_hip, s_hip, S = eng.forward(P, img.cuda(), save=True)
     masks = mask_parity.hip_relu_masks(S, (eng.center_layout, eng.sdf_layout))
+    if masks_out is not None:
+        masks_out.update(masks)      # the ReLU decisions this run took (callers compare two runs' decisions)
     out5, dpc, dps = ops.objectness_loss(c_hip, s_hip, cf.cuda(), sdf.cuda(), sal.cuda())
     nograd = net.nograd_names()
     G = {n: torch.zeros_like(P[n]) for n in P if n not in nograd}

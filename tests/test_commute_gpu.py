@@ -124,18 +124,31 @@ def _run(net, batch, train=True):
     return out, {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
 
 
-def _same_gradients_fp32(g0, g1):
-    """The two orders round h1 = relu(.) of the centre head differently (resize of a GEMM result vs GEMM of a resized map), so a
-    handful of ReLU decisions at |pre-activation| ~ 1e-7 differ and with them single entries of the downstream gradients: the bar
-    between the two orders is 1e-3 * max|g| per parameter and a cosine of 1 - 1e-6 over all of them.  The parity bar proper -- the
-    default order against the float64 oracle under the engine's own ReLU decisions, 5e-5 -- is asserted by tests/test_model_gpu.py
-    and tests/test_parity_r2_gpu.py (masked_gradient_check)."""
-    assert g0.keys() == g1.keys()
-    for n in g0:
-        err = (g1[n] - g0[n]).abs().max().item() / (g0[n].abs().max().item() + 1e-12)
-        assert err < 1e-3, (n, err)
-    a = torch.cat([g0[n].flatten() for n in g0]).double()
-    b = torch.cat([g1[n].flatten() for n in g0]).double()
+def _check_orders_fp32(engine, monkeypatch, nets, sds, cfg_name, batch, **head_kw):
+    """fp32, order against order.  The two orders round h1 = relu(.) of the centre head differently (resize of a GEMM result vs GEMM
+    of a resized map), so a handful of ReLU decisions at |pre-activation| ~ 1e-7 differ -- and ONE such decision moves single
+    gradient entries by ~1e-3 * max|g|: noise of the function's kinks, not of either launch list.  So the kinks are taken out
+    instead of being allowed for (the rule of every other gradient test, tests/grad_common.py): EACH order is compared with the
+    float64 oracle run under that order's own ReLU decisions (oracle/mask_parity.py) at the suite's bar of 5e-5 * max|g| and
+    5e-5 relative L2 per parameter tensor -- either order is the exact gradient of its linear piece to rounding -- and the two
+    sets of decisions are required to differ only in a vanishing share of the sites (<= 1e-5; each set is separately asserted to
+    differ from float64's own only within 1e-4 rms of a kink, mask_parity.assert_flips_are_rounding)."""
+    from grad_common import masked_gradient_check
+    img, cf, sdf, sal = (t.cpu() for t in batch)
+    G, M = {}, {}
+    for order in (False, True):
+        monkeypatch.setattr(engine, "_COMMUTE_RESIZE", order)       # read at call time: each net runs under its own order
+        G[order], M[order] = {}, {}
+        worst_inf, worst_n, worst_l2, flips = masked_gradient_check(nets[order], sds[order], cfg_name, img, cf, sdf, sal, grads_out=G[order],
+                                                                    masks_out=M[order], **head_kw)
+        print(f"commute={order}: worst {worst_inf:.2e} ({worst_n}), rel L2 {worst_l2:.2e}, {flips} decisions differ from float64's own")
+    assert M[False].keys() == M[True].keys() and G[False].keys() == G[True].keys()
+    sites = sum(m.numel() for m in M[False].values())
+    differ = sum(int((M[False][k] != M[True][k]).sum()) for k in M[False])
+    print(f"ReLU decisions that differ between the two orders: {differ} of {sites}")
+    assert differ <= max(1.0, 1e-5 * sites), (differ, sites)
+    a = torch.cat([G[False][n].flatten() for n in G[False]]).double()
+    b = torch.cat([G[True][n].flatten() for n in G[False]]).double()
     assert 1 - torch.dot(a, b) / (a.norm() * b.norm()) < 1e-6
 
 
@@ -143,25 +156,27 @@ def _same_gradients_fp32(g0, g1):
 @pytest.mark.parametrize("head_bwd,sdf_act", [("algebraic", "tanh"), ("gemm", "tanh"), ("algebraic", "sine"), ("algebraic", None)])
 @pytest.mark.parametrize("backbone,tag,H,W", [("dpt_tiny", "tiny", 64, 96), ("dpt_large14", "l14", 56, 84)])
 def test_both_orders_give_the_same_outputs_and_gradients(dtype, head_bwd, sdf_act, backbone, tag, H, W, monkeypatch):
-    """outputs to rounding; gradients: fp32 see _same_gradients_fp32, bf16 by direction (the bar of the other A/B tests)"""
+    """outputs to rounding; gradients: fp32 see _check_orders_fp32 (each order at 5e-5 on its own linear piece), bf16 by direction
+    (the bar of the other A/B tests)"""
     from unmore_amd import engine
     if backbone == "dpt_large14" and (head_bwd, sdf_act, dtype) != ("algebraic", "tanh", torch.float32):
         pytest.skip("the patch-14 resizes (not x2) are covered once")
     args = Namespace(use_bg_sdf=True, sdf_activation=sdf_act)
     batch = tuple(torch.from_numpy(a).cuda() for a in synth.make_batch(2, H, W, seed=11))
-    res = {}
+    res, nets, sds = {}, {}, {}
     for commute in (False, True):
         monkeypatch.setattr(engine, "_COMMUTE_RESIZE", commute)
-        net, _ = _net(backbone, tag, dtype, args)
+        net, sd = _net(backbone, tag, dtype, args)
         net.set_linear_head_backward(head_bwd)
         res[commute] = _run(net, batch)
+        nets[commute], sds[commute] = net, sd
     (o0, g0), (o1, g1) = res[False], res[True]
     otol = 2e-5 if dtype == torch.float32 else 3e-2
     for k in ("center_fields", "sdf_maps"):
         torch.testing.assert_close(o1[k], o0[k], atol=otol, rtol=otol)
     assert g0.keys() == g1.keys()
     if dtype == torch.float32:
-        _same_gradients_fp32(g0, g1)
+        _check_orders_fp32(engine, monkeypatch, nets, sds, backbone, batch, use_bg_sdf=True, sdf_activation=sdf_act)
     else:
         a = torch.cat([g0[n].flatten() for n in g0]).double()
         b = torch.cat([g1[n].flatten() for n in g0]).double()
@@ -179,16 +194,17 @@ def test_fp32_modes_and_inference_in_both_orders(mode, monkeypatch):
     ops.set_f32_mode(mode)
     try:
         batch = tuple(torch.from_numpy(a).cuda() for a in synth.make_batch(2, 64, 64, seed=4))
-        outs, grads = {}, {}
+        outs, nets, sds = {}, {}, {}
         for commute in (False, True):
             monkeypatch.setattr(engine, "_COMMUTE_RESIZE", commute)
-            net, _ = _net("dpt_tiny", "tiny", torch.float32)
+            net, sd = _net("dpt_tiny", "tiny", torch.float32)
             net.eval()
             with torch.no_grad():
                 outs[commute] = net.get_prediction(batch[0])
-            grads[commute] = _run(net, batch)[1]
+            _run(net, batch)                 # a training step through the autograd.Function boundary in this order and mode
+            nets[commute], sds[commute] = net, sd
         for k in ("center_fields", "sdf_maps"):
             torch.testing.assert_close(outs[True][k], outs[False][k], atol=2e-5, rtol=2e-5)
-        _same_gradients_fp32(grads[False], grads[True])
+        _check_orders_fp32(engine, monkeypatch, nets, sds, "dpt_tiny", batch)
     finally:
         ops.set_f32_mode("x3")

@@ -748,3 +748,54 @@ def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, monkeypatch, f3
         else:
             monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
         torch.testing.assert_close(a.float(), c.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)
+
+
+def test_cu_budget_does_not_change_results(monkeypatch):
+    """umr_set_cu_budget (include/umr.h): the persistent 256x256 grids launch exactly `budget` workgroups, leaving the other CUs to
+    kernels that run beside them (RCCL's bucket all-reduces during a data-parallel backward).  Tile height and K-split are planned on
+    the device's CU count, every output element's K sum is the same instruction sequence in any workgroup: plain GEMMs of every
+    epilogue class, the 3x3 conv forms, the plane (fp32-grade) GEMMs incl. a K-split one, and a whole train step must be
+    BIT-IDENTICAL for budgets 0 (all), 208, 64 and 7 (a grid that is not a multiple of the 8 XCDs)."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    D, M = 768, 2500
+    x = _rnd((M, D), torch.bfloat16, dev, 171)
+    w = _rnd((D, D), torch.bfloat16, dev, 172, D ** -0.5)
+    w4 = _rnd((4 * D, D), torch.bfloat16, dev, 173, D ** -0.5)
+    bias = _rnd((D,), torch.float32, dev, 174)
+    b4 = _rnd((4 * D,), torch.float32, dev, 175)
+    aux = _rnd((M, D), torch.bfloat16, dev, 176)
+    redw = _rnd((2, 4 * D), torch.float32, dev, 177)
+    img = _rnd((2, 40, 56, 256), torch.bfloat16, dev, 178)
+    wc = _rnd((256, 9 * 256), torch.bfloat16, dev, 179, (9 * 256) ** -0.5)
+    cmask = _rnd((2 * 40 * 56, 256), torch.bfloat16, dev, 180)
+    xf = _rnd((1300, 1024), torch.float32, dev, 181)
+    wf = _rnd((1024, 1024), torch.float32, dev, 182, 1024 ** -0.5)
+    xp, wp = ops.split3(xf), ops.split3(wf)
+    monkeypatch.setenv("UMR_GEMM_TILE", "256")
+
+    def run():
+        outs = [ops.gemm_nt(x, w, bias, act=L.ACT_RELU), ops.gemm_nt(x, w, bias, aux=aux), ops.gemm_nt(x, w, None, aux=aux, mask_relu=True),
+                ops.gemm_nt(x, w, None, aux=aux, mask_dgelu=True), ops.gemm_nt(x, w, bias, out_f32=True)]
+        outs += list(ops.gemm_nt(x, w4, b4, act=L.ACT_GELU, c2_mode=2))
+        outs += list(ops.gemm_nt(x, w4, b4, act=L.ACT_RELU, red_w=redw))
+        outs.append(ops.gemm_nt(img, wc, bias[:256].contiguous(), conv=1, act=L.ACT_RELU))
+        outs.append(ops.gemm_nt(img, wc, None, conv=1, aux=cmask, mask_relu=True))
+        outs.append(ops.gemm_nt_x3(xp, wp, None))                           # plane GEMM at the reference recipe's token count (K-split)
+        outs.append(ops.gemm_nt_x3(xp, wp, None, out_planes=True))
+        torch.cuda.synchronize()
+        return outs
+
+    res = {}
+    try:
+        for budget in (0, 208, 64, 7):
+            ops.set_cu_budget(budget)
+            assert L.lib().umr_get_cu_budget() == budget
+            res[budget] = run()
+    finally:
+        ops.set_cu_budget(0)
+    for budget in (208, 64, 7):
+        for i, (a, b) in enumerate(zip(res[0], res[budget])):
+            assert torch.equal(a, b), (budget, i)
+    torch.testing.assert_close(res[64][0].float(), F.relu(x.float() @ w.float().t() + bias), atol=3e-2, rtol=3e-2)
+    torch.testing.assert_close(res[7][-2], xf @ wf.t(), atol=2e-4, rtol=2e-4)

@@ -169,3 +169,57 @@ def test_capture_scratch_is_per_stream_and_outgrown_buffers_stay_alive(monkeypat
     big = ops._workspace(8 << 20, dev)                              # outgrows a: a new buffer, the old one stays referenced
     assert big.data_ptr() != a.data_ptr() and any(t is a for t in store["outgrown"])
     assert (sk[:16384] == 0).all() and (skb[:16384] == 0).all()     # tile counters start at zero on either stream
+
+
+def test_failed_capture_leaves_no_unwritten_packs(monkeypatch):
+    """A capture that raises has only RECORDED the packs it built (PackCache.get inside the capture): their buffers hold nothing.
+    graphs.Captured's failure path purges them (PackCache.purge_capture), so the eager path that takes over re-packs instead of
+    reading uninitialised copies under a matching version."""
+    from unmore_amd import engine, graphs
+    net, _ = _net()
+    eng = net._engine()
+    w = net.center_field_prediction_head[0].weight
+    key = ("probe", "lin_t", torch.float32)
+    x = _batch(2, 64, 64, seed=3)[0]
+
+    def fn(xs):
+        eng.cache.get(key, w, lambda: engine._pack_linear_t(w.detach().reshape(w.shape[0], -1), torch.float32))   # built INSIDE the capture
+        assert key in eng.cache._c or key in eng.cache._o
+        raise RuntimeError("forced failure after a pack")
+    gen0 = eng.cache.generation()
+    with pytest.warns(UserWarning, match="capture failed"):
+        cap = graphs.Captured(fn, (x,), generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
+    assert cap.failed is not None and not cap.valid()
+    assert key not in eng.cache._c and key not in eng.cache._o
+    assert eng.cache.generation() != gen0                                  # other captures that read the set are invalidated
+    good = eng.cache.get(key, w, lambda: engine._pack_linear_t(w.detach().reshape(w.shape[0], -1), torch.float32))
+    torch.cuda.synchronize()
+    assert torch.equal(good, w.detach().reshape(w.shape[0], -1).t())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_trainstep_survives_a_failed_capture(dtype, monkeypatch):
+    """the capturing call of a train step fails late (Adam's launch raises under capture): the step falls back to the eager launch
+    list in the same call and stays bit-identical to a step that never tried to capture"""
+    from unmore_amd import graphs, ops
+    from unmore_amd.trainer import TrainStep
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    step_e = TrainStep(net_e, lr=1e-3).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=1e-3).set_graph_mode("on")
+    real = ops.adam_step_hyper
+
+    def adam(*a, **k):
+        if graphs.capturing():
+            raise RuntimeError("forced failure at the end of the captured step")
+        return real(*a, **k)
+    monkeypatch.setattr(ops, "adam_step_hyper", adam)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for it in range(5):
+            batch = _batch(2, 64, 64, seed=20 + it)
+            assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
+            assert torch.equal(step_e.flat_p, step_g.flat_p), it
+    assert step_g.graph_replays == 0
+    assert any(isinstance(v, graphs.Captured) and v.failed for v in step_g._graphs.values())

@@ -31,7 +31,19 @@ def _worker(rank, world, port, out_dir):
     for k in range(comm.num_buckets):  # backward-completion order
         comm.ready(k)
     scale = comm.finish()
-    torch.save({"local": local, "reduced": flat.clone(), "scale": scale}, os.path.join(out_dir, f"r{rank}.pt"))
+    # a second, traced exchange (what bench.py records for one untimed step when world > 1): same sums, plus per-bucket timestamps
+    reduced = flat.clone()
+    flat.copy_(local)
+    comm.trace = True
+    for k in range(comm.num_buckets):
+        comm.ready(k)
+    comm.finish()
+    rep = comm.trace_report()
+    assert torch.equal(flat, reduced)
+    assert [r["bucket"] for r in rep["buckets"]] == [0, 2, 3] and rep["clock"] == "host clock"       # the empty bucket launches nothing
+    assert all(0.0 <= r["issue_ms"] <= r["done_ms"] for r in rep["buckets"]) and rep["exposed_ms"] >= 0.0
+    assert rep["buckets"][1]["mbytes"] == round(576 * 4 / 2 ** 20, 2) and comm.trace_report() is None   # cleared
+    torch.save({"local": local, "reduced": reduced, "scale": scale}, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -33,6 +33,22 @@ for k in range(comm.num_buckets):
     comm.ready(k)
 scale = comm.finish()
 ops.adam_step(flat.clone(), flat, torch.zeros_like(flat), torch.zeros_like(flat), 1, grad_scale=scale)
+# the traced exchange (bench.py runs one untimed step with it when world > 1): RCCL's completion stamped by a side stream, a reduced
+# CU budget for the persistent GEMMs beside the collectives (ops.set_cu_budget), results unchanged
+big = torch.randn(8192, 768, device=dev).bfloat16(); wb = torch.randn(768, 768, device=dev).bfloat16()
+c_full = ops.gemm_nt(big, wb, None)
+ops.set_cu_budget(224)
+comm.trace = True
+for k in range(comm.num_buckets):
+    c_b = ops.gemm_nt(big, wb, None)
+    comm.ready(k)
+comm.finish()
+rep = comm.trace_report()
+ops.set_cu_budget(0)
+assert torch.equal(flat, ref) and torch.equal(c_full, c_b)
+assert [r["bucket"] for r in rep["buckets"]] == [0, 2, 3] and rep["clock"] == "device events", rep
+assert all(0.0 <= r["issue_ms"] <= r["done_ms"] for r in rep["buckets"]) and rep["exposed_ms"] >= 0.0, rep
+print("TRACE", rep)
 t = torch.tensor([1.25], dtype=torch.float64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 dist.barrier(device_ids=[0])

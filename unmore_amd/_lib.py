@@ -112,6 +112,7 @@ _SIGS = {
     "umr_linear_head_bwd_weight": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_linear_head_shift9_workspace": [_i64],
     "umr_linear_head_shift9": [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_linear_head_gather9": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_small_gemm_f32": [_vp, _vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "umr_permute4_batched": [_vp, _i32, _i64, _vp, _vp],
     "umr_split3": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
@@ -120,6 +121,8 @@ _SIGS = {
     "umr_gemm_nt_x3_workspace": [_vp],
     "umr_set_f32_mode": [_i32],
     "umr_get_f32_mode": [],
+    "umr_set_cu_budget": [_i32],
+    "umr_get_cu_budget": [],
     "umr_version": [],
     "umr_last_error_string": [],
 }

@@ -1093,8 +1093,13 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     int64_t kf = wg_per_cu > 0 ? wg_per_cu : total / ((int64_t)cus * 32);
     if (kf < 1) kf = 1;
     if (kf > 8) kf = 8;
-    int64_t grid64 = cus * kf;
-    if (ksplit > 1) grid64 = (cus + ksplit - 1) / ksplit;   // split-K: gridDim.y = ksplit rows of workgroups, about one workgroup per CU in all
+    // CU budget (umr_set_cu_budget): exactly `budget` workgroups, one per CU -- the other CUs stay free for a collective's kernels.
+    // (the tile height and K-split above were planned on the device's CU count: results do not depend on the budget)
+    const int budget = umr_cu_budget_now();
+    const int cub = (budget > 0 && budget < cus) ? budget : cus;
+    if (cub < cus) kf = 1;
+    int64_t grid64 = cub * kf;
+    if (ksplit > 1) grid64 = (cub + ksplit - 1) / ksplit;   // split-K: gridDim.y = ksplit rows of workgroups, about one workgroup per CU in all
     if (total < grid64) grid64 = total;
     const int grid = (int)grid64;
     dim3 g((unsigned)grid, (unsigned)ksplit), b(512);

@@ -254,6 +254,33 @@ __global__ __launch_bounds__(256) void lh_shift9_kernel(const float* __restrict_
     }
 }
 
+// Forward of the collapsed head when x is a bilinear resize of a smaller map (x = U y; the head reads the x2-interpolated feature map,
+// models.py:70-72): kw[t] . x(p) = (U (y kw^T))(p)[t] -- a 1x1 product with the nine tap vectors commutes with the resize -- so the
+// nine tap products are taken on the small map (a 16-column GEMM), resized as a 16-channel map T, and summed here over the taps'
+// shifted positions:  out(q) = act( sum_{t: q + off_t inside} (T[q + off_t][t] + tapbias[t]) + tapbias[9] ).  The mirror of
+// lh_shift9_kernel; the interpolated 256-channel map is never formed.
+__global__ __launch_bounds__(256) void lh_gather9_kernel(const float* __restrict__ T, int64_t ldt, const float* __restrict__ tapbias,
+                                                         float* __restrict__ out, int B, int H, int W, int act) {
+    const int64_t M = (int64_t)B * H * W;
+    float tb[10];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) tb[t] = tapbias[t];
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < M; q += (int64_t)gridDim.x * 256) {
+        const int64_t row = q / W;
+        const int px = (int)(q - row * W), py = (int)(row % H);
+        float acc = 0.f, sb = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                acc += T[(q + (int64_t)(t / 3 - 1) * W + (t % 3 - 1)) * ldt + t];
+                sb += tb[t];
+            }
+        }
+        out[q] = act_apply(acc + sb + tb[9], act);
+    }
+}
+
 // block = 64 columns x 16 slab phases; phase y sums slabs y, y+16, ... (8 loads in flight), the 16 phase sums are added in
 // a fixed order through LDS (one thread per column walking all slabs serially took 0.29 ms for 9.5 MB)
 __global__ __launch_bounds__(1024) void lh_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int n, int stride) {
@@ -400,6 +427,17 @@ extern "C" int umr_linear_head_shift9(const float* dout, const float* yout, void
     LH_DISPATCH(dtype, hipLaunchKernelGGL(lh_shift9_kernel<T>, dim3(nb), dim3(256), 0, s, dout, yout, (T*)s9, (float*)workspace, B, H, W, act));
     UMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(lh_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, nd, nb, 16, 16);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_linear_head_gather9(const float* taps, int64_t ldt, const float* tapbias10, float* out, int B, int H, int W, int act,
+                                       umr_stream_t stream) {
+    UMR_CHECK_ARG(taps && tapbias10 && out && B > 0 && H > 0 && W > 0 && ldt >= 9, "linear_head_gather9: bad arguments");
+    const int64_t M = (int64_t)B * H * W;
+    int64_t g = (M + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(lh_gather9_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, taps, ldt, tapbias10, out, B, H, W, act);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

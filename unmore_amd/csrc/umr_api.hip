@@ -32,3 +32,22 @@ extern "C" int umr_set_f32_mode(int mode) {
     return UMR_OK;
 }
 extern "C" int umr_get_f32_mode(void) { return umr_f32_mode_now(); }
+
+// ---- CU budget of the persistent GEMM grids (include/umr.h): process-wide, run-time
+static std::atomic<int> g_cu_budget{-1};
+int umr_cu_budget_now() {
+    int b = g_cu_budget.load(std::memory_order_relaxed);
+    if (b < 0) {
+        const char* e = getenv("UMR_CU_BUDGET");
+        b = e ? atoi(e) : 0;
+        if (b < 0) b = 0;
+        g_cu_budget.store(b, std::memory_order_relaxed);
+    }
+    return b;
+}
+extern "C" int umr_set_cu_budget(int cus) {
+    if (cus < 0) return umr_set_error(UMR_ERR_INVALID, "umr_set_cu_budget: negative budget");
+    g_cu_budget.store(cus, std::memory_order_relaxed);
+    return UMR_OK;
+}
+extern "C" int umr_get_cu_budget(void) { return umr_cu_budget_now(); }

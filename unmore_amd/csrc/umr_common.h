@@ -118,5 +118,6 @@ static inline int umr_env_int(const char* name, int dflt) { const char* e = gete
 // host-side error plumbing (umr_api.hip)
 int umr_set_error(int code, const char* msg);
 int umr_f32_mode_now();   // umr_api.hip: UMR_F32_EXACT / UMR_F32_X3
+int umr_cu_budget_now();  // umr_api.hip: 0 = every CU, n = the persistent GEMM grids occupy at most n CUs
 #define UMR_CHECK_ARG(cond, msg) do { if (!(cond)) return umr_set_error(UMR_ERR_INVALID, msg); } while (0)
 #define UMR_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return umr_set_error(UMR_ERR_HIP - (int)e_, hipGetErrorString(e_)); } while (0)

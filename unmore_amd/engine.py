@@ -31,6 +31,22 @@ CONFIGS = {
 _ACT = {None: L.ACT_NONE, "tanh": L.ACT_TANH, "sine": ops.ACT_SINE}
 
 
+class ParamGroup:
+    """Several parameters seen by PackCache.get as one: the key of a pack derived from all of them (the collapsed head's weight
+    algebra reads eight tensors) -- its version is the tuple of theirs, so a change of any one misses."""
+
+    def __init__(self, params):
+        self.ps = tuple(params)
+        self.is_cuda, self.device = self.ps[0].is_cuda, self.ps[0].device
+
+    @property
+    def _version(self):
+        return tuple(p._version for p in self.ps)
+
+    def data_ptr(self):
+        return tuple(p.data_ptr() for p in self.ps)
+
+
 class PackCache:
     """Kernel-layout copies of parameters, rebuilt when the parameter changes.
 
@@ -119,6 +135,23 @@ class PackCache:
         self._epoch = None
         self.gen_c += 1
         self.gen_o += 1
+
+    def purge_capture(self, store):
+        """A HIP-graph capture whose scratch dict is `store` FAILED: the packs it built were only recorded, never executed -- their
+        buffers (in the capture's private pool) hold nothing, yet they sit in the cache under the parameters' current versions.
+        Drop them, so the eager path that takes over re-packs (graphs.Captured calls this from its failure path)."""
+        dead_c = [k for k, e in self._c.items() if e[6] is store]
+        dead_o = [k for k, e in self._o.items() if e[6] is store]
+        for k in dead_c:
+            del self._c[k]
+        for k in dead_o:
+            del self._o[k]
+        if dead_c:
+            self._replay = {}
+            self.gen_c += 1
+        if dead_o:
+            self.gen_o += 1
+        return len(dead_c) + len(dead_o)
 
     def refresh(self, tag=None, select=None):
         """The parameters were updated IN PLACE by a kernel torch does not see (TrainStep's Adam launch): re-run every pack into
@@ -290,8 +323,10 @@ class Engine(X3Path):
         self.center_layout, self.sdf_layout = head_layouts
         self.dt = compute_dtype
         self.cache = PackCache()
-        # opt-in algebraic fast path for heads without non-linearities between their convs:
-        # default False = compute the four convolutions as the reference does
+        # algebraic fast path for heads without non-linearities between their convs: "auto" (the net's
+        # default) = inference calls (no saved activations) evaluate such a head as ONE 3x3 convolution, training runs the four
+        # convolutions as the reference does; True = always (opt-in for training); False = never
+        assert collapse_linear_heads in (False, True, "auto")
         self.collapse_linear_heads = collapse_linear_heads
 
     # ------------------------------------------------------------------ collapsed linear head (opt-in)
@@ -316,6 +351,47 @@ class Engine(X3Path):
         ops.small_gemm(u, b2, tb[9:10], 1, 1, C1, (0, 1), (1, 0), (0, 0), accumulate=True)
         ops.small_gemm(W4, b3, tb[9:10], 1, 1, C3, (0, 1), (1, 0), (0, 0), accumulate=True)
         return u, Vc, Kw, tb
+
+    def _collapse(self, lay, save):
+        """does this call evaluate the head `lay` in its collapsed form?  (a head with ReLUs never; 'sine' is not invertible from
+        its value, so its training step keeps the factored form whose backward gets the pre-activation)"""
+        if lay["relu"] or (save and lay["final"] == "sine"):
+            return False
+        return (not save) if self.collapse_linear_heads == "auto" else bool(self.collapse_linear_heads)
+
+    def _linear_head_weights_cached(self, P, name, idx, dev):
+        """inference: the collapsed weights (and the 16-row tap matrix in the compute dtype) per version of the head's eight
+        tensors (PackCache; dropped with the other non-replayable packs after an optimizer step of TrainStep)"""
+        ps = [P[f"{name}.{i}.{t}"] for i in idx for t in ("weight", "bias")]
+
+        def build():
+            u, Vc, Kw, tb = self._linear_head_weights(P, name, idx, dev)
+            return u, Vc, Kw, tb, self._tap_matrix(Kw)
+        return self.cache.get((name, "collapsed", self.dt), ParamGroup(ps), build)
+
+    def _tap_matrix(self, Kw):
+        """[16, C] in the compute dtype: rows 0..8 = the nine tap vectors, the rest zero (the N = 16 operand of the tap GEMM)"""
+        C = Kw.numel() // 9
+        k16 = torch.zeros((16, C), dtype=torch.float32, device=Kw.device)
+        k16[:9].copy_(Kw.view(9, C))
+        return k16 if self.dt == torch.float32 else ops.cast(k16, self.dt)
+
+    def _linear_head_forward_lowres(self, P, name, idx, path, H, W, act, save):
+        """Collapsed forward of a head that reads the x2-interpolated feature map (models.py:70-72, objectness_net.py:128-135), taken
+        BEFORE the resize: the nine tap products kw[t] . x are 1x1 products and commute with the resize (_COMMUTE_RESIZE), so they
+        are one 16-column GEMM on the small map `path` [nb, ph, pw, 256]; the resize moves 16 f32 channels instead of 256, and
+        lh_gather9_kernel sums every pixel's taps at their shifted positions (csrc/linear_head.hip).  The backward of a training
+        step in this form is the algebraic one (it needs the output only)."""
+        if save:
+            u, Vc, Kw, tb = self._linear_head_weights(P, name, idx, path.device)
+            k16 = self._tap_matrix(Kw)
+        else:
+            u, Vc, Kw, tb, k16 = self._linear_head_weights_cached(P, name, idx, path.device)
+        nb, ph, pw, C = path.shape
+        taps = ops.gemm_nt(path.reshape(-1, C), k16, None, out_f32=(self.dt != torch.float32))                    # [Ml, 16] f32
+        taps = ops.bilinear_fwd(taps.view(nb, ph, pw, 16), H, W, True)                        # [B, H, W, 16] f32
+        out = ops.linear_head_gather9(taps, tb, act)
+        return out, dict(algebraic=True, act=act, out=out, u=u, Vc=Vc, Kw=Kw)
 
     def _linear_head_forward(self, P, name, idx, feat, act):
         """opt-in collapsed forward (csrc/linear_head.hip): the head as ONE streaming 3x3 conv 256 -> 1"""
@@ -592,9 +668,7 @@ class Engine(X3Path):
         # formed, and the backward of that layer -- weight gradient, data gradient, the algebraic head's reductions -- runs on
         # the quarter-size map
         lowres = _COMMUTE_RESIZE and not x3_ok
-        # (a head collapsed into one 3x3 convolution -- opt-in -- reads the interpolated map itself)
-        need_feat = not lowres or (self.collapse_linear_heads and not (self.center_layout["relu"] and self.sdf_layout["relu"]))
-        feat = ops.bilinear_fwd(path, H, W, True) if need_feat else None
+        feat = ops.bilinear_fwd(path, H, W, True) if not lowres else None
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
@@ -615,14 +689,18 @@ class Engine(X3Path):
             idx = lay["conv_idx"]
             # in training the plane form serves the heads that keep no activation for their backward (algebraic backward)
             alg_ = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"
-            x3_heads = x3_ok and (not save or alg_) and not (self.collapse_linear_heads and not lay["relu"])
+            collapse = self._collapse(lay, save)
+            x3_heads = x3_ok and (not save or alg_) and not collapse
             if x3_heads and featp is None:
                 featp = ops.split3(feat.view(-1, 256))
-            if self.collapse_linear_heads and not lay["relu"]:
-                out, cs = self._linear_head_forward(P, name, idx, feat, _ACT[lay["final"]])
+            if collapse:
+                if lowres:
+                    out, cs = self._linear_head_forward_lowres(P, name, idx, path, H, W, _ACT[lay["final"]], save)
+                else:
+                    out, cs = self._linear_head_forward(P, name, idx, feat, _ACT[lay["final"]])
+                    cs["out"] = out
                 outs.append(out)
                 if save:
-                    cs["out"] = out
                     heads_saved.append(cs)
                 continue
             act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
@@ -772,24 +850,16 @@ class Engine(X3Path):
         pl = path.view(-1, C)
         Ml = pl.shape[0]
         dev = path.device
-        widths = [0 if hs_.get("collapsed") else 64 if hs_.get("algebraic") else hs_["h1"].shape[-1] for hs_ in S["heads"]]
+        widths = [64 if hs_.get("algebraic") else hs_["h1"].shape[-1] for hs_ in S["heads"]]
         K = sum(widths)
         dlow = torch.empty((Ml, K), dtype=dt, device=dev)
         bcat = torch.zeros((C, K), dtype=dt, device=dev)          # [256, K]: dpath = dlow . bcat^T
         c0 = 0
-        dpath_c = None
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
             idx = lay["conv_idx"]
-            if hs.get("collapsed"):
-                # (opt-in form) this head read the interpolated map: its gradient comes back through the resize's adjoint
-                assert dpath_c is None
-                dfeat = self._linear_head_backward(P, name, idx, S["feat"], hs, dout, None, G)
-                dpath_c = ops.bilinear_bwd(dfeat.view(B, H, W, C), ph, pw, True).view(Ml, C)
-                del dfeat
-                continue
-            if hs.get("algebraic"):
+            if hs.get("algebraic"):     # (also a head whose FORWARD ran collapsed: _linear_head_forward_lowres)
                 if "u" not in hs:
                     hs["u"], hs["Vc"], hs["Kw"], _ = self._linear_head_weights(P, name, idx, dev)
                 s9, nd = ops.linear_head_shift9(dout.contiguous(), hs["out"], hs["act"], dt)
@@ -821,7 +891,7 @@ class Engine(X3Path):
             wgrad_lin(f"{name}.{idx[0]}.weight", dlow[:, c0:c0 + c1], pl, f"{name}.{idx[0]}.bias")
             bcat[:, c0:c0 + c1].copy_(self._w(P, f"{name}.{idx[0]}.weight", "lin_t"))
             c0 += c1
-        dpath = ops.gemm_nt(dlow, bcat, None, aux=dpath_c).view(nb, ph, pw, C)
+        dpath = ops.gemm_nt(dlow, bcat, None).view(nb, ph, pw, C)
         S["path"] = None
         S["feat"] = None
         return dpath

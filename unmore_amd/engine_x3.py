@@ -312,9 +312,7 @@ class X3Path:
                 S["H"], S["W"] = H, W
         # the heads' first layer before the final resize (engine._COMMUTE_RESIZE): the interpolated 256-channel map is never formed
         lowres = _COMMUTE_RESIZE
-        # (a head collapsed into one 3x3 convolution -- opt-in -- reads the interpolated map itself)
-        need_feat = not lowres or (self.collapse_linear_heads and not (self.center_layout["relu"] and self.sdf_layout["relu"]))
-        feat = XT(f=ops.bilinear_fwd(path.F(), H, W, True)) if need_feat else None
+        feat = XT(f=ops.bilinear_fwd(path.F(), H, W, True)) if not lowres else None
         if save:
             S["fus"] = fus_saved
             S["rn_in"] = layers
@@ -331,11 +329,14 @@ class X3Path:
         nbp, php, pwp = path.shape[0], path.shape[1], path.shape[2]
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
             idx = lay["conv_idx"]
-            if self.collapse_linear_heads and not lay["relu"]:
-                out, cs = self._linear_head_forward(P, name, idx, feat.F(), _ACT[lay["final"]])
+            if self._collapse(lay, save):
+                if lowres:
+                    out, cs = self._linear_head_forward_lowres(P, name, idx, path.F(), H, W, _ACT[lay["final"]], save)
+                else:
+                    out, cs = self._linear_head_forward(P, name, idx, feat.F(), _ACT[lay["final"]])
+                    cs["out"] = out
                 outs.append(out)
                 if save:
-                    cs["out"] = out
                     heads_saved.append(cs)
                 continue
             act = L.ACT_RELU if lay["relu"] else L.ACT_NONE
@@ -407,16 +408,6 @@ class X3Path:
             Ml = nbp * php * pwp
             pl = pathx.view(Ml, 256)
         dfeat = None          # f32 [M, 256] (lowres: the gradient of the map before the resize, [Ml, 256])
-        dh1s, w1names = [], []
-        if lowres:
-            for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
-                                                    ("sdf_prediction_head", self.sdf_layout, d_sdf))):
-                if S["heads"][hi].get("collapsed"):
-                    # (opt-in form) this head read the interpolated map: its gradient comes back through the resize's adjoint
-                    assert dfeat is None
-                    dfc = self._linear_head_backward(P, name, lay["conv_idx"], feat.F().view(B, H, W, 256), S["heads"][hi], dout, None, G)
-                    dfeat = ops.bilinear_bwd(dfc.view(B, H, W, 256), php, pwp, True).view(Ml, 256)
-                    del dfc
         for hi, (name, lay, dout) in enumerate((("center_field_prediction_head", self.center_layout, d_center),
                                                 ("sdf_prediction_head", self.sdf_layout, d_sdf))):
             hs = S["heads"][hi]
@@ -434,8 +425,6 @@ class X3Path:
                 kwt[:, :9].copy_(hs["Kw"].view(9, 256).t())
                 dfeat = ops.gemm_nt(E, kwt, None) if dfeat is None else ops.gemm_nt(E, kwt, None, aux=dfeat, out=dfeat)
                 continue
-            if lowres and hs.get("collapsed"):
-                continue              # done above
             if hs.get("collapsed") or hs.get("algebraic"):
                 dfeat = self._linear_head_backward(P, name, idx, feat.F().view(B, H, W, 256), hs, dout, dfeat, G)
                 continue

@@ -56,7 +56,9 @@ def wanted(mode, pixels, train=False):
 class Captured:
     """One captured call: `fn(*static_inputs)` -> tuple of output tensors, recorded once, replayed with fresh input values."""
 
-    def __init__(self, fn, example_inputs, generation_of=None):
+    def __init__(self, fn, example_inputs, generation_of=None, on_fail=None):
+        """on_fail(store): called when the capture raised -- whatever the capture built for later use (packed weight copies in
+        engine.PackCache) was only RECORDED, never executed, and must not be served to the eager path that takes over"""
         self.failed = None
         self.graph = None
         self._gen_of = generation_of
@@ -75,6 +77,8 @@ class Captured:
         except Exception as e:   # noqa: BLE001 -- whatever went wrong, the eager path still works
             self.failed = f"{type(e).__name__}: {e}"
             warnings.warn(f"unmore_amd: HIP-graph capture failed, staying on the eager path ({self.failed})")
+            if on_fail is not None:
+                on_fail(self.store)
         finally:
             _state["capturing"], _state["store"] = False, None
         self.generation = generation_of(self.store) if generation_of else None

@@ -8,11 +8,16 @@ checkpoint and call it unchanged.  The sub-modules below only HOLD parameters un
 reference's names; all arithmetic runs in the hand-written HIP kernels via
 `unmore_amd.engine.Engine`.  There is no CPU path: calling it with CPU tensors raises.
 """
+import os
+
 import torch
 from torch import nn
 
 from . import graphs, ops
 from .engine import CONFIGS, Engine
+
+
+_SDF_HEAD_MODE = os.environ.get("UMR_SDF_HEAD_MODE", "auto")    # default of set_sdf_head_mode (A/B switch for benchmarking)
 
 
 def head_layout(use_bg_sdf, sdf_activation):
@@ -204,11 +209,15 @@ class ObjectnessNet(nn.Module):
         return self
 
     def set_sdf_head_mode(self, mode):
-        """'factored' (default): the boundary-distance head runs its four convolutions as the reference does.
-        'collapsed': opt-in algebraic fast path -- the head has no non-linearity between its convs (tanh / sine / None
-        variants, objectness_net.py:119-142) and is evaluated as one 3x3 conv 256->1 with exact gradients for all
-        factored weights (csrc/linear_head.hip).  Same function and gradients up to rounding; ~45 % fewer step FLOPs."""
-        assert mode in ("factored", "collapsed")
+        """How a head WITHOUT non-linearities between its convs (the boundary-distance head's tanh / sine / None variants,
+        objectness_net.py:119-142,128-135) is evaluated.  Its four convolutions compose to ONE 3x3 conv 256 -> 1 plus a
+        border-dependent bias (csrc/linear_head.hip).
+        'auto' (default): inference calls (torch.no_grad() / no parameter requires grad -- object_reasoning.py:326,351,413) use
+        that collapsed form; training runs the four convolutions as the reference does.  Qualified against every reference-made
+        forward fixture at the 1e-4 contract and through the peak chain (tests/test_collapsed_head_gpu.py).
+        'factored': always the four convolutions (the A/B switch).  'collapsed': the collapsed form in training too (exact
+        gradients of all factored weights; ~45 % fewer step FLOPs; opt-in, never the benchmark's `value`)."""
+        assert mode in ("auto", "factored", "collapsed")
         self.sdf_head_mode = mode
         self._eng = None
         return self
@@ -227,7 +236,8 @@ class ObjectnessNet(nn.Module):
     def _engine(self):
         if self._eng is None or self._eng.dt != self.compute_dtype:
             self._eng = Engine(self.cfg, self._layouts, self.compute_dtype,
-                               collapse_linear_heads=(getattr(self, "sdf_head_mode", "factored") == "collapsed"),
+                               collapse_linear_heads={"auto": "auto", "factored": False, "collapsed": True}[
+                                   getattr(self, "sdf_head_mode", None) or _SDF_HEAD_MODE],
                                linear_head_backward=getattr(self, "linear_head_bwd_mode", None))
         return self._eng
 
@@ -286,7 +296,7 @@ class ObjectnessNet(nn.Module):
         if graphs.wanted(mode, B * H * W) and ops._timer["select"] is None and not graphs.capturing():
             # the captures read the packed weight copies and, in fp32 mode, the parameters themselves: any in-place update bumps a
             # version counter, a re-homed parameter changes its address
-            sig = (sum(p._version for p in params), params[0].data_ptr(), params[-1].data_ptr(), id(eng))
+            sig = (sum(p._version for p in params), hash(tuple(p.data_ptr() for p in params)), id(eng))
             store = self.__dict__.setdefault("_inf_graphs", {})
             if store.get("sig") != sig:
                 store.clear()
@@ -308,7 +318,8 @@ class ObjectnessNet(nn.Module):
                     if sum(isinstance(v, graphs.Captured) for v in store.values()) >= graphs.MAX_CAPTURES:
                         for k in [k for k, v in store.items() if isinstance(v, graphs.Captured)]:
                             del store[k]
-                    cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation)
+                    cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation,
+                                          on_fail=eng.cache.purge_capture)
                     store[key] = cap
                     if cap.failed is None:
                         center, sdf = cap.replay(x)

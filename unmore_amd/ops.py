@@ -58,6 +58,15 @@ def get_f32_mode():
     return {L.F32_EXACT: "exact", L.F32_X3: "x3", L.F32_X3_FAST: "x3_fast"}[L.lib().umr_get_f32_mode()]
 
 
+def set_cu_budget(cus):
+    """CUs the persistent GEMM grids occupy (include/umr.h, umr_set_cu_budget): 0 = all; n = exactly min(n, CUs) workgroups, one per
+    CU, the rest left to kernels that run beside them (RCCL's bucket all-reduces during backward).  Bit-identical results.
+    Returns the previous budget."""
+    prev = int(L.lib().umr_get_cu_budget())
+    L.check(L.lib().umr_set_cu_budget(int(cus)), "umr_set_cu_budget")
+    return prev
+
+
 _ws_cache = {}
 
 
@@ -824,6 +833,17 @@ def linear_head_shift9(dout, yout, act, dtype):
     L.check(L.lib().umr_linear_head_shift9(_p(dout), _p(yout), _p(s9), _p(nd), _p(ws), ws.numel(), B, H, W, act, _DT[dtype], _stream()),
             "umr_linear_head_shift9")
     return s9, nd
+
+
+def linear_head_gather9(taps, tapbias10, act):
+    """taps [B, H, W, >= 9] f32 (taps[q][t] = kw[t] . x(q); channels contiguous, one pixel stride) -> [B,1,H,W] f32:
+    act(sum over the taps inside the image of (taps[q + off_t][t] + tapbias10[t]) + tapbias10[9]) -- csrc/linear_head.hip"""
+    _need_gpu(taps, tapbias10)
+    B, H, W, C, ldt = _pixel_view(taps, "linear_head_gather9 input")
+    assert taps.dtype == torch.float32 and C >= 9 and tapbias10.dtype == torch.float32 and tapbias10.numel() >= 10
+    out = torch.empty((B, 1, H, W), dtype=torch.float32, device=taps.device)
+    L.check(L.lib().umr_linear_head_gather9(_p(taps), ldt, _p(tapbias10), _p(out), B, H, W, act, _stream()), "umr_linear_head_gather9")
+    return out
 
 
 # ---- existence classifier pieces (csrc/classifier.hip; SURVEY 8f row f3)

@@ -189,7 +189,7 @@ class TrainStep:
                 self._graphs[key] = n
                 if n > graphs.WARMUP_CALLS:
                     # the warm-up steps have packed every weight, built the batched refresh and sized the workspaces
-                    cap = graphs.Captured(self._body, ins, generation_of=eng.cache.generation)
+                    cap = graphs.Captured(self._body, ins, generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
                     self._graphs[key] = cap
                     if cap.failed is None:
                         # the capture only RECORDED the step: run it

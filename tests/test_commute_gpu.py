@@ -81,6 +81,20 @@ def test_row_stream_resizes_at_other_scales(dtype, align, shape):
     torch.testing.assert_close(dx.double().cpu(), xr.grad, atol=tol * scale, rtol=tol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resize_propagates_nan(dtype):
+    """a NaN activation stays NaN through the resize, with and without the fused ReLU (torch: relu(nan) = nan) -- the ReLU is a
+    compare-and-select, not fmaxf, so a diverged run is not silently turned into zeros / -inf"""
+    from unmore_amd import ops
+    x = torch.randn((1, 8, 8, 16), generator=torch.Generator().manual_seed(3)).to(dtype).cuda()
+    x[0, 3, 4, 5] = float("nan")
+    for relu in (False, True):
+        y = ops.bilinear_fwd(x, 16, 16, True, relu=relu)
+        bad = torch.isnan(y)
+        assert bad[0, :, :, 5].any() and not bad[..., :5].any() and not bad[..., 6:].any()
+        assert torch.isfinite(y[~bad]).all() and (not relu or (y[~bad] >= 0).all())
+
+
 def test_resize_writes_planes():
     from unmore_amd import ops
     B, Hi, Wi, C, Ho, Wo = 2, 10, 14, 64, 20, 28

@@ -246,6 +246,7 @@ def test_fused_head_output_layer_matches_unfused(monkeypatch):
     inference (h3 never stored) form."""
     from unmore_amd import engine, ops
     net, _ = _net("dpt_tiny", "tiny", torch.bfloat16)
+    net.set_sdf_head_mode("factored")     # the four-convolution form of BOTH heads at inference too (the default collapses the sdf head there)
     x = torch.from_numpy(uniform01("img:fuse", (2, 3, 256, 256))).cuda()
     h2 = torch.zeros((2 * 256 * 256, 512), dtype=torch.bfloat16, device="cuda:0")
     w3 = torch.zeros((1024, 512), dtype=torch.bfloat16, device="cuda:0")

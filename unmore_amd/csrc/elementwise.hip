@@ -58,7 +58,8 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, void* __restrict__ 
     const int cv = C / (4 * NV);
     const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
-    const float floor_ = relu ? 0.f : -INFINITY;
+    // optional ReLU as a compare-and-select: NaN activations stay NaN (fmaxf(NaN, x) returns x and would hide a diverged run)
+    const bool relu_ = relu != 0;
     for (int by = blockIdx.y; by < B * Ho; by += gridDim.y) {
         const int b = by / Ho, oy = by - b * Ho;
         int y0, y1;
@@ -81,7 +82,10 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, void* __restrict__ 
                 const f32x4 v00 = Vec4<T>::load(p00 + 4 * v), v01 = Vec4<T>::load(p01 + 4 * v);
                 const f32x4 v10 = Vec4<T>::load(p10 + 4 * v), v11 = Vec4<T>::load(p11 + 4 * v);
                 for (int j = 0; j < 4; ++j)
-                    o[v][j] = fmaxf(ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]), floor_);
+                    {
+                    const float r_ = ly0 * (lx0 * v00[j] + lx1 * v01[j]) + ly1 * (lx0 * v10[j] + lx1 * v11[j]);
+                    o[v][j] = (relu_ && r_ < 0.f) ? 0.f : r_;
+                }
             }
             if constexpr (PLANES) {
                 static_assert(NV == 2, "plane output works on 8 channels per thread");
@@ -163,7 +167,8 @@ __device__ __forceinline__ void ld_bf16x8(const bf16_t* p, float (&f)[8]) {
 // kernel is left with its stores.  Same expression as the gather form (x first, then y).
 __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
                                                                 int Wo, int C, int align, int64_t ldx, int64_t ldy, int relu, int RUN) {
-    const float floor_ = relu ? 0.f : -INFINITY;
+    // optional ReLU as a compare-and-select: NaN activations stay NaN (fmaxf(NaN, x) returns x and would hide a diverged run)
+    const bool relu_ = relu != 0;
     const int cv = C >> 3;
     const int rowlen = Wo * cv;
     const float sh = area_scale(Hi, Ho, align), sw = area_scale(Wi, Wo, align);
@@ -212,7 +217,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_bf16x8_kernel(const bf16_t* 
                 // y1 == y0 only at the clamped last row, where vB was built from the same (clamped) row: the same value either way
                 bf16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16_t)fmaxf(l0 * vA[j] + l1 * vB[j], floor_);
+                for (int j = 0; j < 8; ++j) {
+                    const float r_ = l0 * vA[j] + l1 * vB[j];
+                    o[j] = (bf16_t)((relu_ && r_ < 0.f) ? 0.f : r_);
+                }
                 *(bf16x8*)(y + (((int64_t)b * Ho + oy) * Wo + ox) * ldy + c) = o;
             }
         }

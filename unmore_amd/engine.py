@@ -298,6 +298,7 @@ class WgradStream:
         if not self.on:
             return fn()
         self.side.wait_stream(self.main)       # the producers of `used` are enqueued on main
+        graphs.note_fork(self.main, self.side)
         with torch.cuda.stream(self.side):
             fn()
         for t in used:

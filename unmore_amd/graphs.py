@@ -18,7 +18,7 @@ import warnings
 
 import torch
 
-_state = {"capturing": False, "store": None}
+_state = {"capturing": False, "store": None, "forks": []}
 
 # "auto": capture small problems (their step is launch-bound), run large ones eagerly; "on" / "off" force it.  Environment
 # default for every net / TrainStep that is not told otherwise.
@@ -37,6 +37,13 @@ def capturing():
 def capture_store():
     """scratch buffers that belong to the capture in progress (ops._workspace): kept alive with the Captured object"""
     return _state["store"]
+
+
+def note_fork(main, side):
+    """a side stream was forked into the capture in progress (engine.WgradStream): if the captured call raises before its own join,
+    Captured joins it back, so that ending the capture is legal and the side stream leaves capture mode"""
+    if _state["capturing"] and all(side is not s for _, s in _state["forks"]):
+        _state["forks"].append((main, side))
 
 
 def wanted(mode, pixels, train=False):
@@ -69,10 +76,18 @@ class Captured:
         torch.cuda.synchronize(dev)          # everything enqueued before the capture is complete: no cross-capture dependencies
         g = torch.cuda.CUDAGraph()
         self.store = {}
-        _state["capturing"], _state["store"] = True, self.store
+        _state["capturing"], _state["store"], _state["forks"] = True, self.store, []
         try:
             with torch.cuda.graph(g):
-                outs = fn(*self.static_in)
+                try:
+                    outs = fn(*self.static_in)
+                except BaseException:
+                    # a capture may only end once every stream forked into it has rejoined its origin; a call that raised in
+                    # mid-backward has not joined its weight-gradient stream -- without this the runtime refuses to end the capture
+                    # and leaves the side stream in capture mode, where the eager fallback's next launch on it fails
+                    for main, side in _state["forks"]:
+                        main.wait_stream(side)
+                    raise
             self.graph, self.outs = g, tuple(outs)
         except Exception as e:   # noqa: BLE001 -- whatever went wrong, the eager path still works
             self.failed = f"{type(e).__name__}: {e}"
@@ -80,7 +95,7 @@ class Captured:
             if on_fail is not None:
                 on_fail(self.store)
         finally:
-            _state["capturing"], _state["store"] = False, None
+            _state["capturing"], _state["store"], _state["forks"] = False, None, []
         self.generation = generation_of(self.store) if generation_of else None
         torch.cuda.synchronize(dev)
 

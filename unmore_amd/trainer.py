@@ -168,8 +168,15 @@ class TrainStep:
         if images.shape[0] == 0:
             # the reference would take the mean of empty maps (NaN) and push NaN gradients into Adam; refuse instead
             raise ValueError("TrainStep.step: empty batch (every image was filtered out); skip this iteration")
-        self.iter += 1
-        ops.adam_set_hyper(self._hyper, self.iter, self.current_lr_for_step(), self.betas[0], self.betas[1], self.eps, 1.0 / self.comm.world)
+        # the step count and the schedule advance only once the step's launches are enqueued: a body or capture that raises leaves
+        # `iter` (and with it the checkpoint's 'iter' and the learning-rate schedule) where the last applied update put it
+        it = self.iter + 1
+        ops.adam_set_hyper(self._hyper, it, self.lr_of_step(it), self.betas[0], self.betas[1], self.eps, 1.0 / self.comm.world)
+        out5 = self._launch_step(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
+        self.iter = it
+        return out5
+
+    def _launch_step(self, images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
         ins = (images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
         eng = self.net._engine()
         B, _, H, W = images.shape
@@ -244,10 +251,13 @@ class TrainStep:
         generation and are captured again after two eager steps)."""
         self.net._engine().cache.clear()
 
-    def current_lr_for_step(self):
+    def lr_of_step(self, k):
         # torch's MultiStepLR.step() runs after optimizer.step(): step k (1-based) uses the lr of k-1 completed steps
         lr = self.lr0
         for ms in self.milestones:
-            if self.iter - 1 >= ms:
+            if k - 1 >= ms:
                 lr *= self.gamma
         return lr
+
+    def current_lr_for_step(self):
+        return self.lr_of_step(self.iter)

@@ -456,16 +456,18 @@ def run_rank(a):
             peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams)
         units_per_step = 1
 
-    # HIP-graph replay (unmore_amd/graphs.py): 'auto' captures the small INFERENCE workloads (cfg1 / cfg5) and leaves train steps
-    # eager (GPU-bound; the eager two-stream schedule is faster than a replay, graphs.wanted).  A replayed step cannot carry per-kernel
-    # HIP events, so the dominant kernel is then timed in a separate eager leg AFTER the timed region (said so in the line).
+    # HIP-graph replay (unmore_amd/graphs.py): 'auto' captures the small workloads -- inference calls (cfg1 / cfg5) as one graph, train
+    # steps (the reference recipe) as a chain of per-stage graphs replayed on two streams -- and leaves the large train steps eager
+    # (GPU-bound, graphs.wanted).  A replayed step cannot carry per-kernel HIP events, so the dominant kernel is then timed in a
+    # separate eager leg AFTER the timed region (said so in the line).
     from unmore_amd import graphs
     if kind == "train":
         step.set_graph_mode(a.graphs)
     else:
         net.set_graph_mode(a.graphs)
     pixels = (50 if kind == "sweep" else B) * H * W
-    graphed = world == 1 and graphs.wanted(a.graphs, pixels, train=(kind == "train"))
+    from unmore_amd.engine import WgradStream
+    graphed = world == 1 and graphs.wanted(a.graphs, pixels, train=(kind == "train"), two_streams=WgradStream.wanted(pixels))
     warm = a.warmup + (graphs.WARMUP_CALLS + 1 if graphed and kind != "sweep" else 0)   # two eager calls + the capturing call, untimed
     for _ in range(warm):
         one()
@@ -533,6 +535,8 @@ def run_rank(a):
             # host time spent enqueueing one step (no synchronisation inside): what a HIP-graph replay removes
             "host_enqueue_ms_per_step": 1e3 * host_s / a.steps,
             "hip_graph": ({"mode": a.graphs, "replayed": True, "warmup_calls_untimed": warm,
+                           "form": ("chain of per-stage graphs on two streams (graphs.StagedCaptured)" if kind == "train" and graphs.STAGED and WgradStream.wanted(pixels)
+                                    else "one graph"),
                            "roofline_timing": "separate eager leg of 2 steps after the timed region (no per-kernel events inside a replay)"}
                           if graphed else {"mode": a.graphs, "replayed": False}),
             "roofline": {"bound": "mfma",

@@ -126,13 +126,18 @@ def test_sweep_on_three_streams_with_replays_equals_eager():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("graph", ["off", "on"])
+@pytest.mark.parametrize("graph", ["off", "on", "on-forked"])
 def test_weight_gradient_stream_does_not_change_results(dtype, graph, monkeypatch):
-    """engine.WgradStream: the weight-gradient GEMMs of a small problem run on a second stream beside the data-gradient chain
-    (as graph edges under capture).  Same kernels on the same operands: bit-identical to the one-stream schedule, step after step."""
-    from unmore_amd import engine
+    """engine.WgradStream: the weight-gradient GEMMs of a small problem run on a second stream beside the data-gradient chain --
+    eagerly, as a chain of per-stage graphs replayed on two streams (graphs.StagedCaptured, the default capture of such a step), or
+    as fork / join edges of one graph ('on-forked').  Same kernels on the same operands: bit-identical to the one-stream schedule,
+    step after step."""
+    from unmore_amd import engine, graphs
     from unmore_amd.trainer import TrainStep
     res = {}
+    if graph == "on-forked":
+        monkeypatch.setattr(graphs, "STAGED", False)
+        graph = "on"
     for mode in ("0", "1"):
         monkeypatch.setattr(engine, "_WGRAD_STREAM", mode)
         net, _ = _net(dtype=dtype)
@@ -144,8 +149,42 @@ def test_weight_gradient_stream_does_not_change_results(dtype, graph, monkeypatc
         res[mode] = (torch.stack(losses), step.flat_p.clone(), step.flat_g.clone())
         if graph == "on":
             assert step.graph_replays == 3
+            caps = [v for v in step._graphs.values() if isinstance(v, graphs.CAPTURE_TYPES)]
+            assert len(caps) == 1 and caps[0].failed is None
+            if mode == "1" and graphs.STAGED:
+                lanes = [lane for lane, _ in caps[0].segments]
+                # heads, refine, reassemble, 4 blocks, embed: a side graph per stage except the reassemble stage's update (main lane)
+                assert isinstance(caps[0], graphs.StagedCaptured) and lanes.count("side") >= 7 and lanes[0] == "main", lanes
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
+
+
+def test_staged_capture_follows_reload_and_lr_milestones():
+    """the chain-of-graphs train step (graphs.StagedCaptured) across a learning-rate milestone, a reloaded state dict (recaptured) and
+    changing inputs: bit-identical to the eager one-stream step throughout"""
+    from unmore_amd import graphs
+    from unmore_amd.trainer import TrainStep
+    net_e, sd = _net(dtype=torch.bfloat16)
+    net_g, _ = _net(dtype=torch.bfloat16)
+    step_e = TrainStep(net_e, lr=1e-3, lr_milestones=(3,), lr_gamma=0.1).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=1e-3, lr_milestones=(3,), lr_gamma=0.1).set_graph_mode("on")
+    import os
+    os.environ["UMR_WGRAD_STREAM"] = "auto"
+    for it in range(6):
+        batch = _batch(2, 64, 96, seed=60 + it)
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
+        assert torch.equal(step_e.flat_p, step_g.flat_p) and torch.equal(step_e.flat_g, step_g.flat_g), it
+    assert step_g.graph_replays == 4
+    assert any(isinstance(v, graphs.StagedCaptured) for v in step_g._graphs.values())
+    sd2 = {k: v * 0.5 for k, v in sd.items()}
+    for net, st in ((net_e, step_e), (net_g, step_g)):
+        net.load_state_dict(sd2, strict=True)
+        st.sync_from_model()
+    for it in range(4):
+        batch = _batch(2, 64, 96, seed=80 + it)
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
+    assert step_g.graph_replays == 6 and torch.equal(step_e.flat_p, step_g.flat_p)
+    assert torch.equal(step_e.m, step_g.m) and torch.equal(step_e.v, step_g.v)
 
 
 def test_capture_scratch_is_per_stream_and_outgrown_buffers_stay_alive(monkeypatch):
@@ -222,4 +261,4 @@ def test_trainstep_survives_a_failed_capture(dtype, monkeypatch):
             assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
             assert torch.equal(step_e.flat_p, step_g.flat_p), it
     assert step_g.graph_replays == 0
-    assert any(isinstance(v, graphs.Captured) and v.failed for v in step_g._graphs.values())
+    assert any(isinstance(v, graphs.CAPTURE_TYPES) and v.failed for v in step_g._graphs.values())

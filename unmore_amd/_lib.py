@@ -57,6 +57,7 @@ def build(verbose=False, jobs=8):
 
 
 _lib = None
+_count = [0]     # launches checked so far (graphs.StagedCaptured skips graph segments that recorded nothing)
 
 _f32 = ctypes.c_float
 _SIGS = {
@@ -155,5 +156,6 @@ def lib():
 
 
 def check(status, what):
+    _count[0] += 1
     if status != 0:
         raise RuntimeError(f"{what} failed with status {status}: {lib().umr_last_error_string().decode()}")

@@ -284,7 +284,10 @@ class WgradStream:
 
     def __init__(self, dev, on):
         self.on = bool(on)
-        if self.on:
+        # a staged capture in progress (graphs.StagedCaptured): the side-stream work is not launched here but deferred to the capture,
+        # which records it as the stage's own graph at the next stage boundary and replays that graph on its second stream
+        self.staged = graphs.staged() if self.on else None
+        if self.on and self.staged is None:
             self.main = torch.cuda.current_stream(dev)
             key = (dev.index, self.main.cuda_stream)
             if key not in _side_streams:
@@ -297,6 +300,8 @@ class WgradStream:
         """fn: launches on the current stream; used: tensors (allocated on the main stream) those launches read"""
         if not self.on:
             return fn()
+        if self.staged is not None:
+            return self.staged.defer(fn, used)
         self.side.wait_stream(self.main)       # the producers of `used` are enqueued on main
         graphs.note_fork(self.main, self.side)
         with torch.cuda.stream(self.side):
@@ -305,8 +310,13 @@ class WgradStream:
             if t is not None:
                 t.record_stream(self.side)
 
+    def stage_end(self):
+        """a stage of backward is complete (engine.backward's cb): a staged capture closes the stage's graphs here"""
+        if self.staged is not None:
+            self.staged.boundary()
+
     def join(self):
-        if self.on:
+        if self.on and self.staged is None:
             self.main.wait_stream(self.side)
 
     @staticmethod
@@ -918,6 +928,7 @@ class Engine(X3Path):
                 wg.join()
             if stage_cb is not None:
                 stage_cb(name, wg)
+            wg.stage_end()
 
         def wgrad_lin(name, dy, x, bias_name=None, **kw):
             wg.run(lambda: ops.gemm_tn(dy, x, dW=G[name].view(G[name].shape[0], -1), dbias=(G[bias_name] if bias_name else None), **kw), dy, x)

@@ -388,6 +388,7 @@ class X3Path:
                 wg.join()
             if stage_cb is not None:
                 stage_cb(name, wg)
+            wg.stage_end()
 
         def wgrad_lin(name, dy, x, bias_name=None):
             self._wgrad(dy, x, G[name].view(G[name].shape[0], -1), (G[bias_name] if bias_name else None), wg=wg)

@@ -18,7 +18,7 @@ import warnings
 
 import torch
 
-_state = {"capturing": False, "store": None, "forks": []}
+_state = {"capturing": False, "store": None, "forks": [], "staged": None, "lane": None}
 
 # "auto": capture small problems (their step is launch-bound), run large ones eagerly; "on" / "off" force it.  Environment
 # default for every net / TrainStep that is not told otherwise.
@@ -27,6 +27,9 @@ DEFAULT_MODE = os.environ.get("UMR_GRAPHS", "auto")
 # the 384^2 / 518^2 batches (9.4 M / 4.3 M: < 0.1 % of the step is launch gaps) are above
 AUTO_MAX_PIXELS = int(os.environ.get("UMR_GRAPHS_AUTO_MAX_PIXELS", str(1 << 20)))
 WARMUP_CALLS = 2
+# train steps of small problems: capture as a chain of per-stage graphs replayed on two streams (StagedCaptured); 0 = one graph whose
+# weight-gradient branches are fork / join edges (the round-4 form: the runtime executes them one after the other)
+STAGED = os.environ.get("UMR_GRAPH_STAGED", "1") != "0"
 MAX_CAPTURES = 8     # per net (inference): shapes x streams
 
 
@@ -39,6 +42,17 @@ def capture_store():
     return _state["store"]
 
 
+def staged():
+    """the StagedCaptured whose capture is in progress (engine.WgradStream defers its side-stream work to it), or None"""
+    return _state["staged"]
+
+
+def lane():
+    """'main' / 'side' inside a staged capture (its segments are all recorded on ONE capture stream, but replayed on two: scratch
+    buffers are keyed by lane as well as by stream, ops._workspace); None otherwise"""
+    return _state["lane"]
+
+
 def note_fork(main, side):
     """a side stream was forked into the capture in progress (engine.WgradStream): if the captured call raises before its own join,
     Captured joins it back, so that ending the capture is legal and the side stream leaves capture mode"""
@@ -46,17 +60,20 @@ def note_fork(main, side):
         _state["forks"].append((main, side))
 
 
-def wanted(mode, pixels, train=False):
-    """'auto': inference calls of small batches are captured; train steps are NOT -- measured on the reference recipe (dpt_large,
-    20 x 128^2, bf16): eager 794 images/s, replay 797 (the step is GPU-bound: its 1060 kernels add up to the step time, the
-    host enqueues them in 18 of the 25 ms), eager with the weight gradients on a second stream (engine.WgradStream) 852 -- and
-    a replay runs the captured fork / join branches one after the other (779 with them, 789 without), so the eager two-stream
-    schedule is the faster default.  'on' captures either."""
+def wanted(mode, pixels, train=False, two_streams=True):
+    """'auto': small problems are captured -- inference calls as one graph; train steps as a chain of per-stage graphs replayed on two
+    streams (StagedCaptured), where the eager schedule would put the weight gradients on a second stream (`two_streams`:
+    engine.WgradStream.wanted).  Measured on the reference recipe (dpt_large, 20 x 128^2, bf16): eager one
+    stream 794 images/s, one graph 797 (GPU-bound: the step's kernels add up to the step time), eager two streams 873 (host-bound
+    in backward: ~21 launches per transformer block), ONE graph with fork / join edges 779-806 (the runtime executes the branches
+    one after the other), chain of per-stage graphs on two streams 904.  'on' captures any size, 'off' nothing."""
     mode = mode or DEFAULT_MODE
     if mode == "on":
         return True
-    if mode == "off" or train:
+    if mode == "off":
         return False
+    if train:
+        return STAGED and two_streams and pixels <= AUTO_MAX_PIXELS
     return pixels <= AUTO_MAX_PIXELS
 
 
@@ -107,3 +124,131 @@ class Captured:
             s.copy_(t)
         self.graph.replay()
         return self.outs
+
+
+class StagedCaptured:
+    """A train step of a small problem captured as a CHAIN of graphs instead of one graph with forks.
+
+    Why: in the reference's regime (128x128 crops, batch 20: README.md:148-155, train_objectness_net.py:783-788) the backward pass
+    enqueues ~21 launches per transformer block (11 on the data-gradient chain, the weight gradients + Adam + weight refresh beside
+    it) and the host needs about as long for them as the GPU needs to run the chain: the eager two-stream schedule starves the
+    main stream (profiles/r05_ref_step_anatomy.txt: ~100 us of idle main stream per block boundary, 4-5 ms per 23-ms step), while
+    ONE captured graph with fork / join edges costs the host nothing but is executed branch after branch by the runtime (measured
+    in round 4: 790 images/s against 870 eager).  So the step is cut at the stage boundaries of backward (heads, refinenets,
+    reassemble, every transformer block, embeddings: the same cuts the data-parallel buckets use): main-lane graph A_k holds the
+    data-gradient chain of stage k, side-lane graph B_k the stage's weight gradients, its Adam update and its weight-copy refresh
+    (engine.WgradStream defers them here instead of launching them on the second stream).  A replay enqueues A_0, A_1, ... on the
+    caller's stream and every B_k on a second stream behind an event recorded after A_k: B_k runs beside A_k+1.., the host's part
+    is ~60 graph launches per step, and the main stream never waits for the host.
+
+    Memory rules (the two lanes run concurrently in a replay, but are RECORDED one after the other on one capture stream):
+      * the lanes allocate from separate private pools, so a temporary freed inside a side graph is only ever reused by a later
+        side graph (which runs after it on the same stream), never by the main lane;
+      * every main-lane tensor a deferred launch reads (`used`, the tensors the eager schedule record_stream()s) is kept alive
+        until the whole capture has ended: its block is not handed to a later main-lane allocation while the side lane may
+        still read it;
+      * scratch buffers are per lane (ops._workspace).
+    Same kernels on the same operands in the same per-lane order as the eager schedule: bit-identical results (tests/test_graph_gpu.py)."""
+
+    def __init__(self, fn, example_inputs, generation_of=None, on_fail=None):
+        self.failed = None
+        self.segments = []          # (lane, CUDAGraph) in issue order
+        self._gen_of = generation_of
+        dev = example_inputs[0].device
+        self.dev = dev
+        self.static_in = [torch.empty_like(t) for t in example_inputs]
+        for s, t in zip(self.static_in, example_inputs):
+            s.copy_(t)
+        torch.cuda.synchronize(dev)
+        self.store = {}
+        self._pending, self._keep = [], []
+        self._cur = None
+        self._pools = {"main": torch.cuda.graph_pool_handle(), "side": torch.cuda.graph_pool_handle()}
+        self._cap_stream = torch.cuda.Stream(device=dev)
+        self._side = torch.cuda.Stream(device=dev)
+        _state.update(capturing=True, store=self.store, forks=[], staged=self, lane=None)
+        try:
+            with torch.cuda.stream(self._cap_stream):
+                try:
+                    self._begin("main")
+                    outs = fn(*self.static_in)
+                    self.boundary()                  # anything still deferred goes into a last side graph
+                    self._end()
+                except BaseException:
+                    if self._cur is not None:
+                        self._cur[1].capture_end()   # leave capture mode before anything else touches the stream
+                        self._cur = None
+                    raise
+            self.outs = tuple(outs)
+        except Exception as e:   # noqa: BLE001 -- whatever went wrong, the eager path still works
+            self.failed = f"{type(e).__name__}: {e}"
+            self.segments = []
+            warnings.warn(f"unmore_amd: staged HIP-graph capture failed, staying on the eager path ({self.failed})")
+            if on_fail is not None:
+                on_fail(self.store)
+        finally:
+            _state.update(capturing=False, store=None, forks=[], staged=None, lane=None)
+            self._pending, self._keep = [], []       # the captures have ended: the kept tensors' blocks stay reserved in the graphs' pools
+        self.generation = generation_of(self.store) if generation_of else None
+        self._events = [torch.cuda.Event() for lane_, _ in self.segments if lane_ == "side"]
+        torch.cuda.synchronize(dev)
+
+    # ---- capture side (called through engine.WgradStream while fn runs)
+    def _begin(self, lane_):
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._pools[lane_])
+        self._cur = (lane_, g, _launches[0])
+        _state["lane"] = lane_
+
+    def _end(self):
+        lane_, g, n0 = self._cur
+        g.capture_end()
+        self._cur = None
+        _state["lane"] = None
+        if _launches[0] > n0:            # (a segment without a launch is not replayed)
+            self.segments.append((lane_, g))
+
+    def defer(self, fn, used):
+        self._pending.append(fn)
+        self._keep.extend(t for t in used if t is not None)
+
+    def boundary(self):
+        """end of a stage of backward: what was deferred since the last boundary becomes the stage's side graph"""
+        if not self._pending:
+            return
+        self._end()
+        self._begin("side")
+        pend, self._pending = self._pending, []
+        for fn in pend:
+            fn()
+        self._end()
+        self._begin("main")
+
+    # ---- replay side
+    def valid(self):
+        return bool(self.segments) and (self._gen_of is None or self._gen_of(self.store) == self.generation)
+
+    def replay(self, *inputs):
+        for s, t in zip(self.static_in, inputs):
+            s.copy_(t)
+        main = torch.cuda.current_stream(self.dev)
+        side = self._side
+        k = 0
+        for lane_, g in self.segments:
+            if lane_ == "main":
+                g.replay()
+            else:
+                ev = self._events[k]
+                k += 1
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    g.replay()
+        main.wait_stream(side)
+        return self.outs
+
+
+from ._lib import _count as _launches     # libumr launches so far (counted by _lib.check): a staged capture skips empty segments  # noqa: E402
+
+
+CAPTURE_TYPES = (Captured, StagedCaptured)

@@ -85,7 +85,7 @@ def _workspace(nbytes, device):
         # main branch in a replay, as it does eagerly.  A buffer that was outgrown stays alive with the capture: launches recorded
         # earlier still point at it, and the pool must not hand it to a tensor of the other branch.
         store = graphs.capture_store()
-        key = ("ws", _stream_id(device.index))
+        key = ("ws", _stream_id(device.index), graphs.lane())
         buf = store.get(key)
         if buf is None or buf.numel() < nbytes:
             if buf is not None:
@@ -109,7 +109,7 @@ def _splitk_workspace(device):
     """Per-(device, stream) scratch of umr_gemm_nt_ws: tile counters (zeroed once here; every launch leaves them zero) + slabs."""
     if graphs.capturing():
         store = graphs.capture_store()   # see _workspace; the zeroing of the counters is recorded too: every replay starts clean
-        key = ("sk", _stream_id(device.index))
+        key = ("sk", _stream_id(device.index), graphs.lane())
         buf = store.get(key)
         if buf is None:
             buf = store[key] = torch.empty(int(L.lib().umr_gemm_nt_workspace()), dtype=torch.uint8, device=device)
@@ -268,7 +268,7 @@ def _x3_workspace(d, device):
     need = int(L.lib().umr_gemm_nt_workspace()) + extra
     if graphs.capturing():
         store = graphs.capture_store()
-        key = ("x3ws", _stream_id(device.index))
+        key = ("x3ws", _stream_id(device.index), graphs.lane())
         buf = store.get(key)
         if buf is None or buf.numel() < need:
             if buf is not None:

@@ -154,10 +154,11 @@ class TrainStep:
         return (out5,)
 
     def set_graph_mode(self, mode):
-        """'on': the step is captured into a HIP graph after two eager steps of the same shape and replayed (bit-identical; host
-        enqueue 18.3 -> 0.36 ms per step on the reference recipe).  'auto' (default; env UMR_GRAPHS) and 'off' run eagerly: the step
-        is GPU-bound and the eager two-stream schedule is faster than a replay (graphs.wanted).  Data-parallel runs (world > 1)
-        always run eagerly: their collectives are not captured."""
+        """'auto' (default; env UMR_GRAPHS): steps of small problems (B*H*W <= 2^20 pixels: the reference's recipe) are captured after
+        two eager steps of the same shape as a chain of per-stage HIP graphs and replayed on two streams (graphs.StagedCaptured:
+        bit-identical to the eager step, host enqueue 18.7 -> 1.0 ms, 873 -> 904 images/s on the reference recipe); large ones run
+        eagerly (GPU-bound, < 3 % of the step is host time).  'on' captures any size, 'off' nothing.  Data-parallel runs
+        (world > 1) always run eagerly: their collectives are not captured."""
         assert mode in ("auto", "on", "off")
         self.graph_mode = mode
         self._graphs.clear()
@@ -180,10 +181,12 @@ class TrainStep:
         ins = (images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
         eng = self.net._engine()
         B, _, H, W = images.shape
-        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W, train=True) and ops._timer["select"] is None:
+        from .engine import WgradStream
+        two = WgradStream.wanted(B * H * W)
+        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W, train=True, two_streams=two) and ops._timer["select"] is None:
             key = (tuple(images.shape), eng.dt, ops.get_f32_mode(), torch.cuda.current_stream(images.device).cuda_stream)
             ent = self._graphs.get(key)
-            if isinstance(ent, graphs.Captured):
+            if isinstance(ent, graphs.CAPTURE_TYPES):
                 if ent.valid():
                     (out5,) = ent.replay(*ins)
                     eng.cache.refreshed_by_replay(images.device)
@@ -191,12 +194,19 @@ class TrainStep:
                     return out5.clone()
                 if ent.failed is None:
                     ent = None            # the packed weights moved (state dict reloaded): warm up and capture again
-            if not isinstance(ent, graphs.Captured):
+            if not isinstance(ent, graphs.CAPTURE_TYPES):
                 n = (ent or 0) + 1
                 self._graphs[key] = n
                 if n > graphs.WARMUP_CALLS:
                     # the warm-up steps have packed every weight, built the batched refresh and sized the workspaces
-                    cap = graphs.Captured(self._body, ins, generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
+                    # small problems (the two-stream regime, engine.WgradStream): a chain of per-stage graphs on two streams; large
+                    # ones: one graph.  Every capture keeps its own pools of temporaries: a loop whose batch size keeps changing (the
+                    # reference's batch filter, train_objectness_net.py:190-207) holds at most MAX_CAPTURES of them
+                    if sum(isinstance(v, graphs.CAPTURE_TYPES) for v in self._graphs.values()) >= graphs.MAX_CAPTURES:
+                        for k_ in [k_ for k_, v in self._graphs.items() if isinstance(v, graphs.CAPTURE_TYPES)]:
+                            del self._graphs[k_]
+                    kind = graphs.StagedCaptured if (graphs.STAGED and two) else graphs.Captured
+                    cap = kind(self._body, ins, generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
                     self._graphs[key] = cap
                     if cap.failed is None:
                         # the capture only RECORDED the step: run it

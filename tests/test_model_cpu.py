@@ -109,13 +109,17 @@ def test_flat_layout_buckets_follow_backward_completion_order():
 
 
 def test_graph_and_stream_policies():
-    """graphs.wanted / WgradStream.wanted: 'auto' captures small inference calls only, train steps never; the second stream serves
-    small problems only (the 384x384 batches fill the chip and keep one stream)."""
+    """graphs.wanted / WgradStream.wanted: 'auto' captures small inference calls, and small train steps where the eager schedule would
+    use two streams (as a chain of per-stage graphs); large problems run eagerly; the second stream serves small problems only (the
+    384x384 batches fill the chip and keep one stream)."""
     from unmore_amd import engine, graphs
     small, big = 20 * 128 * 128, 64 * 384 * 384
-    assert graphs.wanted("auto", small) and not graphs.wanted("auto", big) and not graphs.wanted("auto", small, train=True)
-    assert graphs.wanted("on", big, train=True) and not graphs.wanted("off", small)
+    assert graphs.wanted("auto", small) and not graphs.wanted("auto", big)
+    assert graphs.wanted("auto", small, train=True) and not graphs.wanted("auto", small, train=True, two_streams=False)
+    assert not graphs.wanted("auto", big, train=True)
+    assert graphs.wanted("on", big, train=True) and not graphs.wanted("off", small) and not graphs.wanted("off", small, train=True)
     assert engine.WgradStream.wanted(small) and not engine.WgradStream.wanted(big)
+    assert graphs.CAPTURE_TYPES == (graphs.Captured, graphs.StagedCaptured) and graphs.lane() is None and graphs.staged() is None
 
 
 def test_xt_views_share_one_cell():

@@ -399,6 +399,8 @@ def run_rank(a):
     B = a.batch or wl["batch"]
     H, W = wl["H"], wl["W"]
     cfg = CONFIGS[wl["backbone"]]
+    if a.cu_budget:
+        ops.set_cu_budget(a.cu_budget)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     kind = wl["kind"]
 
@@ -493,9 +495,13 @@ def run_rank(a):
     if world > 1 and kind == "train":
         # one more, untimed step with the exchange traced: per bucket, when its all-reduce was issued and when it completed, against
         # the end of backward (parallel.BucketedAllReduce.trace_report) -- how much of the exchange hides behind backward
-        step.comm.trace = True
-        one()
-        ar_trace = step.comm.trace_report()
+        # (never at the price of the line: whatever goes wrong here is reported in place of the trace)
+        try:
+            step.comm.trace = True
+            one()
+            ar_trace = step.comm.trace_report()
+        except Exception as e:   # noqa: BLE001
+            ar_trace = {"error": f"{type(e).__name__}: {e}"}
         step.comm.trace = False
         barrier()
     own = gather_over_ranks(elapsed)
@@ -530,6 +536,7 @@ def run_rank(a):
             "config": {"workload": name, "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
                        "parallelism": (f"dp{world}" if kind == "train" else f"replicas x{world}")},
             "collective": coll,
+            "cu_budget": a.cu_budget,
             "per_rank_images_per_sec": [units_per_step * a.steps / t for t in own],   # each rank's own clock between the barriers
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             # host time spent enqueueing one step (no synchronisation inside): what a HIP-graph replay removes
@@ -773,6 +780,8 @@ def main():
     ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # launcher test hook
     ap.add_argument("--graphs", default="auto", choices=["auto", "on", "off"],
                     help="HIP-graph replay: auto = small inference workloads only (B*H*W <= 2^20 pixels), on = also train steps")
+    ap.add_argument("--cu-budget", type=int, default=0,
+                    help="CUs the persistent GEMM grids occupy (umr_set_cu_budget; 0 = all): leaves the rest to RCCL's kernels when world > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
     a = ap.parse_args()

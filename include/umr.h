@@ -141,8 +141,10 @@ int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
  * ordering it relies on): (1) its first 16 KiB are zero before the first launch that uses it; (2) it belongs to ONE stream -- two
  * launches that may run concurrently must not share it (results would be silently wrong); (3) a launch that was enqueued and then
  * aborted (device fault, reset) leaves counters undefined: zero them again before reuse (umr_gemm_nt_ws does so itself when the
- * launch call reports an error).  libumr_fence.so (make fence) is the same library with the textbook agent-scope release / acquire
- * hand-over and a trap on an out-of-range ticket: the slow reference form the default build is tested against.
+ * launch call reports an error).  An out-of-range ticket traps in every build.  The textbook agent-scope release / acquire hand-over
+ * -- the slow reference form the default is tested against, bit for bit -- is available at run time (environment
+ * UMR_SPLITK_FENCE=1, read per launch) and as a build (libumr_fence.so, make fence).  The default form's reliance on sc1 write-through
+ * stores and sc1 loads is the chip's documented behaviour, not a promise of the HIP memory model: DESIGN.md section 4 quotes the guide.
  * umr_gemm_nt_splits: the number of K ranges umr_gemm_nt_ws would use for d with a workspace of that size (1 = not split). */
 int64_t umr_gemm_nt_workspace(void);
 int umr_gemm_nt_splits(const umr_gemm_desc* d, int64_t workspace_bytes);

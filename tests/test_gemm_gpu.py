@@ -705,16 +705,20 @@ for dtype in (torch.float32, torch.bfloat16):
 torch.save(outs, sys.argv[1])
 """ % os.path.dirname(os.path.dirname(os.path.abspath(L.__file__)))
     res = {}
-    for tag, lib in (("default", L.LIB_PATH), ("fence", fence)):
+    # ... and the same switch at RUN time: the default library with UMR_SPLITK_FENCE=1 takes the fenced hand-over without a rebuild
+    for tag, lib, fe in (("default", L.LIB_PATH, None), ("fence", fence, None), ("runtime", L.LIB_PATH, "1")):
         env = dict(os.environ, UMR_LIB=lib)
         env.pop("UMR_NT_SPLITK", None)
+        env.pop("UMR_SPLITK_FENCE", None)
+        if fe:
+            env["UMR_SPLITK_FENCE"] = fe
         out = tmp_path / f"{tag}.pt"
         r = subprocess.run([sys.executable, "-c", script, str(out)], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         res[tag] = torch.load(out)
-    assert len(res["default"]) == len(res["fence"]) > 30
-    for a, b in zip(res["default"], res["fence"]):
-        assert torch.equal(a, b)
+    assert len(res["default"]) == len(res["fence"]) == len(res["runtime"]) > 30
+    for a, b, c in zip(res["default"], res["fence"], res["runtime"]):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

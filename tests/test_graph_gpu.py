@@ -262,3 +262,29 @@ def test_trainstep_survives_a_failed_capture(dtype, monkeypatch):
             assert torch.equal(step_e.flat_p, step_g.flat_p), it
     assert step_g.graph_replays == 0
     assert any(isinstance(v, graphs.CAPTURE_TYPES) and v.failed for v in step_g._graphs.values())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_staged_capture_at_the_reference_recipe_shape(dtype):
+    """where the chain of per-stage graphs is the default: the reference's own recipe (dpt_large, 20 crops of 128 x 128,
+    train_objectness_net.py:783-788,815-817) -- 24 transformer blocks = 28 stages, split-K GEMMs and their per-lane scratch, the
+    fp32 mode's plane kernels with their K-split workspaces on both lanes.  Default graph mode ('auto') against eager, five steps,
+    bit for bit."""
+    from unmore_amd import graphs
+    from unmore_amd.trainer import TrainStep
+    net_e, _ = _net("dpt_large", "large", dtype=dtype, size=128)
+    net_g, _ = _net("dpt_large", "large", dtype=dtype, size=128)
+    step_e = TrainStep(net_e, lr=1e-4).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=1e-4)                      # 'auto'
+    assert step_g.graph_mode == graphs.DEFAULT_MODE
+    for it in range(5):
+        batch = _batch(20, 128, 128, seed=300 + it)
+        le, lg = step_e.step(*batch), step_g.step(*batch)
+        assert torch.equal(le, lg), (it, le.tolist(), lg.tolist())
+    torch.cuda.synchronize()
+    assert torch.equal(step_e.flat_p, step_g.flat_p) and torch.equal(step_e.m, step_g.m) and torch.equal(step_e.v, step_g.v)
+    if graphs.DEFAULT_MODE == "auto":
+        caps = [v for v in step_g._graphs.values() if isinstance(v, graphs.StagedCaptured)]
+        assert len(caps) == 1 and caps[0].failed is None and step_g.graph_replays == 3
+        lanes = [lane for lane, _ in caps[0].segments]
+        assert lanes.count("side") >= 27 and lanes.count("main") >= 27, (lanes.count("main"), lanes.count("side"))

@@ -18,6 +18,7 @@
 // hd^-0.5 = 1/8 is folded into Q (K in the dK/dV kernel): exact in bf16 and f32.
 #include "umr_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -134,22 +135,45 @@ __device__ __forceinline__ void load_tile(char* tile, const T* base, int64_t ld,
 
 template <typename T> __device__ __forceinline__ float fexp(float x) { return sizeof(T) == 2 ? __expf(x) : expf(x); }
 
+// XCD-aware block map.  The dispatcher deals consecutive workgroups round-robin to the eight XCDs (id % 8), each with its own L2.
+// The gx workgroups of one (batch, head) all read that head's K and V (forward, dQ) or Q and dO (dK / dV): as blockIdx.x of a 2-D
+// grid they were consecutive ids, i.e. on gx DIFFERENT XCDs, and every XCD fetched the head's rows again from beyond its L2 --
+// 0.62 GB per forward launch at the cfg2 shape for a 0.17-GB qkv tensor, 5.9 TB/s for 0.105 ms: the kernels ran at the fabric's
+// rate, not the matrix pipe's (profiles/r05_attention_xcd_map_ab.txt).  Launched 1-D; id -> (XCD, slot) -> a virtual id such
+// that an XCD owns a contiguous run of virtual ids (bijective for any grid size, as in gemm_nt.hip): the workgroups of a head are
+// neighbours on one XCD, dispatched within a few slots of each other.  gx_arg < 0: the old order (A/B).
+__device__ __forceinline__ void attn_block(int gx_arg, int& bx, int& by) {
+    int bid = blockIdx.x;
+    int gx = gx_arg;
+    if (gx_arg > 0) {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        bid = base + (bid >> 3);
+    } else {
+        gx = -gx_arg;
+    }
+    by = bid / gx;
+    bx = bid - by * gx;
+}
+
 // ------------------------------------------------------------------ forward
 template <typename T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
-                                                       int N, int heads) {
+                                                       int N, int heads, int gx_arg) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
     char* sK = smem;
     char* sV = smem + KT * AT<T>::ROWB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const T* qb = qkv + (int64_t)b * N * ld + h * HD;
     const T* kb = qb + D;
     const T* vb = qb + 2 * D;
-    const int q = blockIdx.x * 64 + w * 16 + li;
+    const int q = bx_ * 64 + w * 16 + li;
     const RowFrag<T> qf = rowfrag_global<T>(q < N ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
 
     f32x4 o[4];
@@ -245,7 +269,7 @@ template <int QB>   // 16-query blocks per wave: a workgroup covers 64 * QB quer
 #define UMR_ATTN_DKV_MIN_WAVES 1
 #endif
 __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int N, int heads) {
+                                                            float* __restrict__ lse, int N, int heads, int gx_arg) {
     constexpr int TK = 64;                 // keys per tile
     constexpr int OPB = TK * 128;          // one operand tile: 8 KiB
     constexpr int STB = 2 * OPB;           // K | V
@@ -253,13 +277,15 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* kb = qb + D;
     const bf16_t* vb = qb + 2 * D;
-    const int q0 = blockIdx.x * (64 * QB) + w * (16 * QB) + li;   // query of block qi: q0 + 16 qi
+    const int q0 = bx_ * (64 * QB) + w * (16 * QB) + li;   // query of block qi: q0 + 16 qi
     RowFrag<bf16_t> qf[QB];
     // Q carries hd^-0.5 AND log2(e): the scores come off the matrix pipe in log2 units, and the running maximum is subtracted by
     // STARTING the score accumulators from -m (the C operand of the first QK^T MFMA) -- exp2 applies to the accumulator as it is.
@@ -322,10 +348,17 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
 
     const int ntiles = (N + TK - 1) / TK;
     issue_tile(0);
+#ifdef UMR_ATTN_PEEL_LAST
+    // experiment hook (profiles/r05_attention_experiments.txt): the tile body twice, the key mask only in the copy that runs the last tile
+    auto tile_body = [&](int j, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+#else
     for (int j = 0; j < ntiles; ++j) {
+        const bool LAST = j == ntiles - 1;
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // tile j landed for everyone; everyone is done reading buffer (j+1)&1
-        if (j + 1 < ntiles) issue_tile(j + 1);
+        if (!LAST) issue_tile(j + 1);
         const int sb = (j & 1) * STB;
         // S^T tiles: 4 x (16 keys x 16 queries) per query block
         f32x4 s[QB][4];
@@ -340,7 +373,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
                 s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][sub], 0, 0, 0);
             }
         }
-        if (j == ntiles - 1) {
+        if (LAST) {
 #pragma unroll
             for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
@@ -418,7 +451,13 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) lacc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qi], lacc[qi], 0, 0, 0);
         }
+#ifdef UMR_ATTN_PEEL_LAST
+    };
+    for (int j = 0; j < ntiles - 1; ++j) tile_body(j, std::false_type{});
+    tile_body(ntiles - 1, std::true_type{});
+#else
     }
+#endif
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         const int q = q0 + 16 * qi;
@@ -492,13 +531,15 @@ __global__ void attn_bwd_prep_bf16_kernel(const bf16_t* __restrict__ o, const bf
 template <int QB>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
-                                                               int Npad, int heads) {
+                                                               int Npad, int heads, int gx_arg) {
     constexpr int TK = 64, OPB = TK * 128, STB = 2 * OPB;
     __shared__ __attribute__((aligned(16))) char smem[2 * STB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
@@ -506,7 +547,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     const bf16_t* vb = qb + 2 * D;
     const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
     const float* dsum_b = nl2_b + Npad;
-    const int q0 = blockIdx.x * (64 * QB) + w * (16 * QB) + li;
+    const int q0 = bx_ * (64 * QB) + w * (16 * QB) + li;
     RowFrag<bf16_t> qf[QB], dof[QB];
     float nl2q[QB], d_q[QB];
 #pragma unroll
@@ -622,14 +663,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 template <int KB>
 __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
-                                                                int Npad, int heads) {
+                                                                int Npad, int heads, int gx_arg) {
     constexpr int TQ = 64, OPB = TQ * 128, STB = 2 * OPB;
     // [stage][Q | dO][64 rows][128 B], then per stage 1 KiB: 64 x -lse*log2e | 64 x dsum | unused (zero-filled by the DMA)
     __shared__ __attribute__((aligned(16))) char smem[2 * STB + 2 * 1024];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
@@ -637,7 +680,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
     const bf16_t* vb = qb + 2 * D;
     const bf16_t* dob = dout + (int64_t)b * N * D + h * HD;
     const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
-    const int key0 = blockIdx.x * (64 * KB) + w * (16 * KB) + li;
+    const int key0 = bx_ * (64 * KB) + w * (16 * KB) + li;
     RowFrag<bf16_t> kf[KB], vf[KB];
 #pragma unroll
     for (int ki = 0; ki < KB; ++ki) {
@@ -783,19 +826,21 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                          T* __restrict__ dqkv, int N, int heads) {
+                                                          T* __restrict__ dqkv, int N, int heads, int gx_arg) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
     char* sK = smem;
     char* sV = smem + KT * AT<T>::ROWB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const T* qb = qkv + (int64_t)b * N * ld + h * HD;
     const T* kb = qb + D;
     const T* vb = qb + 2 * D;
-    const int q = blockIdx.x * 64 + w * 16 + li;
+    const int q = bx_ * 64 + w * 16 + li;
     const bool qok = q < N;
     const RowFrag<T> qf = rowfrag_global<T>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f);
     const RowFrag<T> dof = rowfrag_global<T>(qok ? dout + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
@@ -837,20 +882,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
-                                                           T* __restrict__ dqkv, int N, int heads) {
+                                                           T* __restrict__ dqkv, int N, int heads, int gx_arg) {
     __shared__ __attribute__((aligned(16))) char smem[2 * KT * AT<T>::ROWB];
     char* sQ = smem;
     char* sO = smem + KT * AT<T>::ROWB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int g = lane >> 4, li = lane & 15;
-    const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const T* qb = qkv + (int64_t)b * N * ld + h * HD;
     const T* kb = qb + D;
     const T* vb = qb + 2 * D;
     const T* dob = dout + (int64_t)b * N * D + h * HD;
-    const int key = blockIdx.x * 64 + w * 16 + li;
+    const int key = bx_ * 64 + w * 16 + li;
     const bool kok = key < N;
     const RowFrag<T> kf = rowfrag_global<T>(kok ? kb + (int64_t)key * ld : nullptr, g, 0.125f);
     const RowFrag<T> vf = rowfrag_global<T>(kok ? vb + (int64_t)key * ld : nullptr, g, 1.0f);
@@ -903,18 +950,23 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     UMR_CHECK_ARG(B > 0 && N > 0 && heads > 0, "attention_fwd: empty problem");
     if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
     hipStream_t s = (hipStream_t)stream;
-    dim3 g((N + 63) / 64, B * heads), b(256);
+    // 1-D grids of gx x (B * heads) workgroups; the kernels map their id XCD-aware (attn_block).  UMR_ATTN_XCD=0: the old order
+    static const int xcd_map = umr_env_int("UMR_ATTN_XCD", 1);
+    const int gx1 = (N + 63) / 64, gx2 = (N + 127) / 128;
+    UMR_CHECK_ARG((int64_t)gx1 * B * heads < (1ll << 31), "attention_fwd: grid too large");
+    dim3 g((unsigned)(gx1 * B * heads)), b(256);
+    const int a1 = xcd_map ? gx1 : -gx1, a2 = xcd_map ? gx2 : -gx2;
     static const int fast_fwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernel for bf16 too (A/B)
     if (dtype == UMR_BF16 && fast_fwd) {
         if (N >= 128 && fast_fwd != 2) {   // 32 queries per wave: half the LDS reads per MFMA
-            dim3 g2((N + 127) / 128, B * heads);
-            hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+            dim3 g2((unsigned)(gx2 * B * heads));
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a2);
         } else {
-            hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a1);
         }
     }
-    else if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads);
-    else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads);
+    else if (dtype == UMR_BF16) hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a1);
+    else if (dtype == UMR_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, g, b, 0, s, (const float*)qkv, (float*)out, lse, N, heads, a1);
     else return umr_set_error(UMR_ERR_INVALID, "attention_fwd: dtype");
     UMR_LAUNCH_CHECK();
     return UMR_OK;
@@ -932,7 +984,11 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
     if (head_dim != HD) return umr_set_error(UMR_ERR_UNSUPPORTED, "attention: head_dim must be 64");
     hipStream_t s = (hipStream_t)stream;
     const int64_t total = (int64_t)B * N * heads;
-    dim3 gp((unsigned)((total + 255) / 256)), g((N + 63) / 64, B * heads), b(256);
+    static const int xcd_map = umr_env_int("UMR_ATTN_XCD", 1);
+    const int gx1 = (N + 63) / 64, gx2 = (N + 127) / 128;
+    UMR_CHECK_ARG((int64_t)gx1 * B * heads < (1ll << 31), "attention_bwd: grid too large");
+    const int a1 = xcd_map ? gx1 : -gx1, a2 = xcd_map ? gx2 : -gx2;
+    dim3 gp((unsigned)((total + 255) / 256)), g((unsigned)(gx1 * B * heads)), b(256);
     static const int fast_bwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernels for bf16 too (A/B)
     if (dtype == UMR_BF16 && fast_bwd) {
         const int Npad = (N + 63) / 64 * 64;
@@ -940,21 +996,21 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
         hipLaunchKernelGGL(attn_bwd_prep_bf16_kernel, dim3((unsigned)((tp + 255) / 256)), b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, lse,
                            dsum_ws, B, N, Npad, heads);
         if (N >= 128 && fast_bwd != 2) {
-            dim3 g2((N + 127) / 128, B * heads);
-            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
-            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+            dim3 g2((unsigned)(gx2 * B * heads));
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads, a2);
+            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads, a2);
         } else {
-            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
-            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads);
+            hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads, a1);
+            hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, dsum_ws, (bf16_t*)dqkv, N, Npad, heads, a1);
         }
     } else if (dtype == UMR_BF16) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, gp, b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, dsum_ws, B, N, heads);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads, a1);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, lse, dsum_ws, (bf16_t*)dqkv, N, heads, a1);
     } else if (dtype == UMR_F32) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, gp, b, 0, s, (const float*)out, (const float*)dout, dsum_ws, B, N, heads);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads, a1);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, g, b, 0, s, (const float*)qkv, (const float*)dout, lse, dsum_ws, (float*)dqkv, N, heads, a1);
     } else return umr_set_error(UMR_ERR_INVALID, "attention_bwd: dtype");
     UMR_LAUNCH_CHECK();
     return UMR_OK;

@@ -288,3 +288,32 @@ def test_staged_capture_at_the_reference_recipe_shape(dtype):
         assert len(caps) == 1 and caps[0].failed is None and step_g.graph_replays == 3
         lanes = [lane for lane, _ in caps[0].segments]
         assert lanes.count("side") >= 27 and lanes.count("main") >= 27, (lanes.count("main"), lanes.count("side"))
+
+
+@pytest.mark.parametrize("eval_graphs", ["off", "on"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_evaluation_between_replayed_train_steps_sees_the_new_weights(dtype, eval_graphs):
+    """The reference's loop evaluates between training steps (train_objectness_net.py:356, under torch.no_grad()).  An evaluation call
+    caches derived weights (the collapsed boundary-distance head's tap matrix, engine._linear_head_weights_cached) and may itself be
+    replayed from a graph; a REPLAYED train step updates the parameters on the device without touching their torch version counters.
+    Every evaluation must see the weights of the step before it: compared, call by call, with a twin trained eagerly."""
+    from unmore_amd.trainer import TrainStep
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    step_e = TrainStep(net_e, lr=2e-4).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=2e-4).set_graph_mode("on")
+    net_e.set_graph_mode("off")
+    net_g.set_graph_mode(eval_graphs)      # 'off': the evaluation's cached packs are built outside any capture (PackCache.refreshed_by_replay drops them)
+    xe = _batch(3, 64, 64, seed=7)[0]
+    prev = None
+    for it in range(8):
+        batch = _batch(2, 64, 64, seed=700 + it)
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
+        with torch.no_grad():
+            oe, og = net_e.get_prediction(xe), net_g.get_prediction(xe)
+        for k in ("center_fields", "sdf_maps"):
+            assert torch.equal(oe[k], og[k]), (it, k)
+        if prev is not None:                                       # the weights moved: so did both maps
+            assert not torch.equal(prev[0], og["sdf_maps"]) and not torch.equal(prev[1], og["center_fields"]), it
+        prev = (og["sdf_maps"].clone(), og["center_fields"].clone())
+    assert step_g.graph_replays == 6

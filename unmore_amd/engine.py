@@ -198,8 +198,16 @@ class PackCache:
             e[3].add(sid)
 
     def refreshed_by_replay(self, device):
-        """A graph replay on the current stream has just re-run the refresh: a consumer on another stream orders itself after it
-        (one event for the whole cache instead of one per entry)."""
+        """A graph replay on the current stream has just re-run the optimizer step and the refresh: a consumer on another stream
+        orders itself after it (one event for the whole cache instead of one per entry).  The replay updated the parameters on
+        the device without running this class's host code, so what refresh_done() does after an eager step is done here: copies
+        that cannot be replayed and were built OUTSIDE a capture (e.g. the collapsed head's weights an evaluation call cached
+        between two training steps) are stale now and are dropped; those a capture built itself are rewritten by each of its replays."""
+        stale = [k for k, e in self._o.items() if e[6] is None]
+        for k in stale:
+            del self._o[k]
+        if stale:
+            self.gen_o += 1
         st = torch.cuda.current_stream(device)
         ev = torch.cuda.Event()
         ev.record(st)

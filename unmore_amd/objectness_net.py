@@ -282,7 +282,13 @@ class ObjectnessNet(nn.Module):
     def set_graph_mode(self, mode):
         """Inference calls (no autograd) of small batches -- 'auto': B*H*W <= 2^20 pixels, the reference's [<= 50, 3, 128, 128] crops
         (object_reasoning.py:301-337) -- are captured into a HIP graph on their third call with the same shape and replayed
-        afterwards (graphs.py); 'on' / 'off' force it.  A change of any parameter drops the captures."""
+        afterwards (graphs.py); 'on' / 'off' force it.  A change of any parameter drops the captures.
+        Stream contract: a capture belongs to the stream it was recorded for (the key holds the stream) and a replay is ordered like
+        any launch on that stream.  The weight copies it reads were packed or refreshed by work enqueued BEFORE the capture was made
+        (the two eager warm-up calls, on this stream) or are refreshed in place by a train step whose caller has joined its streams
+        (TrainStep does before it returns); a caller that updates parameters on ANOTHER stream must order that stream before the
+        next call itself, exactly as for an eager call.  Every net keeps at most graphs.MAX_CAPTURES captures (each with its own
+        pool of temporaries); beyond that all are dropped and re-captured as their shapes recur."""
         assert mode in ("auto", "on", "off")
         self.graph_mode = mode
         self._inf_graphs = {}

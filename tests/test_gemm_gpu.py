@@ -803,3 +803,33 @@ def test_cu_budget_does_not_change_results(monkeypatch):
             assert torch.equal(a, b), (budget, i)
     torch.testing.assert_close(res[64][0].float(), F.relu(x.float() @ w.float().t() + bias), atol=3e-2, rtol=3e-2)
     torch.testing.assert_close(res[7][-2], xf @ wf.t(), atol=2e-4, rtol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_xcd_tile_order_does_not_change_results(dtype, monkeypatch):
+    """The 128x128 NT kernel walks an XCD's run of tiles n-fastest or m-fastest (csrc/gemm_nt.hip: the operand every XCD has to fetch
+    whole should be the smaller one; UMR_NT_ORDER forces an order per launch).  Which workgroup computes a tile never changes the
+    tile's arithmetic: both orders and the library's own choice are bit-identical, with and without split-K, ragged edges included."""
+    from unmore_amd import ops, _lib as L
+    dev = _dev()
+    monkeypatch.setenv("UMR_GEMM_TILE", "128")
+    for (M, N, K, force) in ((1300, 4096, 1024, None), (1300, 1024, 4096, None), (300, 200, 1096, "3"), (129, 136, 776, None), (70, 1544, 136, None)):
+        if force:
+            monkeypatch.setenv("UMR_NT_SPLITK", force)
+        else:
+            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+        A, B = _rnd((M, K), dtype, dev, 11), _rnd((N, K), dtype, dev, 12, K ** -0.5)
+        bias, aux = _rnd((N,), torch.float32, dev, 13), _rnd((M, N), dtype, dev, 14)
+        res = {}
+        for order in ("n", "m", None):
+            if order:
+                monkeypatch.setenv("UMR_NT_ORDER", order)
+            else:
+                monkeypatch.delenv("UMR_NT_ORDER", raising=False)
+            res[order] = (ops.gemm_nt(A, B, bias, act=L.ACT_RELU), ops.gemm_nt(A, B, None, aux=aux, mask_relu=True), ops.gemm_nt(A, B, bias, out_f32=True))
+            torch.cuda.synchronize()
+        for order in ("m", None):
+            for a, b in zip(res["n"], res[order]):
+                assert torch.equal(a, b), (M, N, K, order)
+        ref = torch.relu(A.float() @ B.float().t() + bias)
+        torch.testing.assert_close(res["m"][0].float(), ref, **_tol(dtype))

@@ -94,7 +94,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
     // the remapped order (same XCD, except where a tile straddles two XCD runs), each takes a contiguous range of K-tiles
     int sk = 0, tile_id = bid;
     if (splits > 1) { tile_id = bid / splits; sk = bid - tile_id * splits; }
-    const int tm = tile_id / tiles_n, tn = tile_id - tm * tiles_n;
+    // Tile order inside an XCD's run.  tiles_n > 0: n fastest -- the run covers a few M-rows of tiles and (nearly) every N-tile: the XCD
+    // streams its own A row panels once and ALL of B.  tiles_n < 0 (= -tiles_m): m fastest -- the run covers a few N-columns of tiles and
+    // every M-tile: its own B panels once and all of A.  The host picks the order that makes the operand every XCD has to fetch whole
+    // the SMALLER one (umr_gemm_nt: B = the weights is the larger one whenever N > M, i.e. at the reference recipe's 1300 tokens):
+    // profiles/r05_small_gemm_xcd_order.txt -- 77 MB fetched per launch for 11 MB of operands with the n-fastest order.
+    int tm, tn;
+    if (tiles_n < 0) { tn = tile_id / (-tiles_n); tm = tile_id - tn * (-tiles_n); }
+    else { tm = tile_id / tiles_n; tn = tile_id - tm * tiles_n; }
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging by buffer LDS-DMA (buffer_load_dwordx4 ... lds): address = descriptor base (tile-local,
@@ -642,6 +649,7 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
     UMR_CHECK_ARG(!(d->flags & UMR_EPI_ROWBIAS) || (d->rowbias && d->rows_per_batch > 0), "gemm_nt: rowbias");
     UMR_CHECK_ARG(d->c2_mode == 0 || d->C2, "gemm_nt: c2_mode without C2");
     const int tiles_m = (d->M + BM - 1) / BM, tiles_n = (d->N + BN - 1) / BN;
+    int tiles_n_arg = tiles_n;
     const int64_t grid = (int64_t)tiles_m * tiles_n;
     UMR_CHECK_ARG(grid < (1ll << 31), "gemm_nt: grid too large");
     hipStream_t s = (hipStream_t)stream;
@@ -652,6 +660,12 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     const int splits = pick_splits(d, grid, workspace != nullptr);
     float* skws = (float*)workspace;
+    // tile order per XCD (see the kernel): m fastest when the B operand is the larger one.  UMR_NT_ORDER=n|m forces an order (A/B; read per launch)
+    {
+        const char* oe = getenv("UMR_NT_ORDER");
+        const bool mfast = oe ? (oe[0] == 'm') : (d->conv == 0 && d->a_rows_in <= 0 && (int64_t)d->N > (int64_t)d->M);
+        if (mfast) tiles_n_arg = -tiles_m;
+    }
     dim3 g((unsigned)(grid * splits)), b(256);
     const bool fast_ep = ((d->N & 7) == 0) && ((d->ldc & 7) == 0) && (d->c2_mode == 0 || (d->ldc2 & 7) == 0) &&
                          (!(d->flags & (UMR_EPI_ADD_AUX | UMR_EPI_MASK_RELU | UMR_EPI_MASK_DGELU)) || (d->ldaux & 7) == 0) &&
@@ -661,13 +675,13 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
                          (d->act == UMR_ACT_NONE || d->act == UMR_ACT_RELU || (d->act == UMR_ACT_GELU && d->dtype == UMR_BF16));
 #define LAUNCH(T, CV)                                                                   \
     do {                                                                                \
-        if (fast_ep) launch_nt<T, CV, 0, false>(g, s, d, tiles_n, splits, skws);  \
-        else launch_nt<T, CV, 1, false>(g, s, d, tiles_n, splits, skws);          \
+        if (fast_ep) launch_nt<T, CV, 0, false>(g, s, d, tiles_n_arg, splits, skws);  \
+        else launch_nt<T, CV, 1, false>(g, s, d, tiles_n_arg, splits, skws);          \
     } while (0)
 #define LAUNCH_X3(CV)                                                                      \
     do {                                                                                   \
-        if (fast_ep) launch_nt<float, CV, 0, true>(g, s, d, tiles_n, splits, skws);  \
-        else launch_nt<float, CV, 1, true>(g, s, d, tiles_n, splits, skws);          \
+        if (fast_ep) launch_nt<float, CV, 0, true>(g, s, d, tiles_n_arg, splits, skws);  \
+        else launch_nt<float, CV, 1, true>(g, s, d, tiles_n_arg, splits, skws);          \
     } while (0)
     const int f32_x3 = umr_f32_mode_now() != UMR_F32_EXACT;   // include/umr.h: umr_set_f32_mode (default X3; UMR_F32_X3=0 selects the f32 MFMA)
     if (d->dtype == UMR_BF16) {

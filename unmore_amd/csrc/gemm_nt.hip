@@ -248,6 +248,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
             }
             return;
         }
+#ifndef UMR_NT_FRAGS_PER_KSTEP   // (A/B hook: the round-4 form below, fragments read per 32-wide k-step)
+        if constexpr (sizeof(T) == 2) {
+            // bf16: all 16 fragment reads of the K-tile are issued before its first MFMA -- one exposed LDS latency per K-tile instead of one per
+            // group of reads the compiler's schedule waited for (+32 VGPRs, still two workgroups per CU).  With two workgroups on a CU
+            // -7...-9 % per launch (qkv / fc1 at 1300 tokens: 18.4 -> 16.7, 21.9 -> 20.3 us), -3 % for lone workgroups at K = 1024, nothing at
+            // K = 4096 (profiles/r05_small_gemm_xcd_order.txt)
+            bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[ks][i] = *(const bf16x8*)(sbuf + a_addr[ks][i]);
+                    bfr[ks][i] = *(const bf16x8*)(sbuf + b_addr[ks][i]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl)
+                        acc[mt][ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][ntl], af[ks][mt], acc[mt][ntl], 0, 0, 0);
+            return;
+        }
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if constexpr (sizeof(T) == 2) {

@@ -317,3 +317,26 @@ def test_evaluation_between_replayed_train_steps_sees_the_new_weights(dtype, eva
             assert not torch.equal(prev[0], og["sdf_maps"]) and not torch.equal(prev[1], og["center_fields"]), it
         prev = (og["sdf_maps"].clone(), og["center_fields"].clone())
     assert step_g.graph_replays == 6
+
+
+def test_dropped_captures_release_their_pools():
+    """A loop whose batch size keeps changing (the reference's batch filter, train_objectness_net.py:190-207) captures every shape on
+    its third step and holds at most graphs.MAX_CAPTURES captures; every capture owns private memory pools, and a new capture never
+    draws from the allocator's cache -- dropped captures must hand their pools back (graphs.release_dropped), or reserved memory
+    grows by a pool per capture (measured before the fix: +33 GiB per 14 shapes of dpt_base 128^2)."""
+    from unmore_amd import graphs
+    from unmore_amd.trainer import TrainStep
+    net, _ = _net(dtype=torch.bfloat16)
+    step = TrainStep(net, lr=1e-4).set_graph_mode("on")
+    reserved = []
+    for rnd in range(3):
+        for B in range(2, 2 + graphs.MAX_CAPTURES + 4):           # more shapes than captures are held
+            batch = _batch(B, 64, 64, seed=B)
+            for _ in range(4):
+                step.step(*batch)
+        torch.cuda.synchronize()
+        held = sum(isinstance(v, graphs.CAPTURE_TYPES) for v in step._graphs.values())
+        assert 1 <= held <= graphs.MAX_CAPTURES
+        reserved.append(torch.cuda.memory_reserved())
+    assert step.graph_replays == 3 * (graphs.MAX_CAPTURES + 4) * 2
+    assert reserved[2] <= 1.25 * reserved[0] + (64 << 20), [r / 2 ** 20 for r in reserved]

@@ -324,6 +324,7 @@ class ObjectnessNet(nn.Module):
                     if sum(isinstance(v, graphs.Captured) for v in store.values()) >= graphs.MAX_CAPTURES:
                         for k in [k for k, v in store.items() if isinstance(v, graphs.Captured)]:
                             del store[k]
+                        graphs.release_dropped()
                     cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation,
                                           on_fail=eng.cache.purge_capture)
                     store[key] = cap

@@ -205,6 +205,7 @@ class TrainStep:
                     if sum(isinstance(v, graphs.CAPTURE_TYPES) for v in self._graphs.values()) >= graphs.MAX_CAPTURES:
                         for k_ in [k_ for k_, v in self._graphs.items() if isinstance(v, graphs.CAPTURE_TYPES)]:
                             del self._graphs[k_]
+                        graphs.release_dropped()
                     kind = graphs.StagedCaptured if (graphs.STAGED and two) else graphs.Captured
                     cap = kind(self._body, ins, generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
                     self._graphs[key] = cap

@@ -12,7 +12,9 @@ Rules the captured region keeps:
   * inputs are copied into buffers owned by the capture; outputs are buffers owned by the capture (callers get clones);
   * the packed weight copies (engine.PackCache) must all exist before the capture starts (two eager warm-up calls), and the
     capture is dropped when the cache's generation changes (a parameter was reassigned / reloaded and re-packed elsewhere).
-A capture that fails for any reason leaves the caller on the eager path (`Captured.failed`)."""
+A capture that fails for any reason leaves the caller on the eager path (`Captured.failed`).
+One capture at a time per process: the "capture in progress" state below is module-global, as the reference's loops are
+single-threaded (train_objectness_net.py, object_reasoning.py; DataLoader workers are processes that never touch the model)."""
 import os
 import warnings
 

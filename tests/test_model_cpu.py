@@ -137,3 +137,43 @@ def test_xt_views_share_one_cell():
     assert x.mask_source().data_ptr() == f.data_ptr()
     x.drop_f()
     assert v.f is None and v.any().data_ptr() == planes.data_ptr() and v.mask_source().shape == (6, 4)
+
+
+def test_pack_cache_param_groups_and_capture_purge():
+    """engine.PackCache on CPU tensors (no stream, no events): a pack derived from SEVERAL parameters (ParamGroup: the collapsed
+    head's weight algebra reads eight tensors) is rebuilt when any one of them changes in place; packs a failed capture only
+    recorded are purged together with the validity stamps of captures that read them."""
+    import torch
+    from unmore_amd import graphs
+    from unmore_amd.engine import PackCache, ParamGroup
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.full((3,), 2.0))
+    cache = PackCache()
+    built = []
+
+    def build():
+        built.append(1)
+        return (a.detach() + b.detach()).clone()
+    key = ("head", "collapsed", torch.float32)
+    v0 = cache.get(key, ParamGroup([a, b]), build)
+    assert torch.equal(v0, torch.full((3,), 3.0)) and len(built) == 1
+    assert cache.get(key, ParamGroup([a, b]), build) is v0 and len(built) == 1          # hit: same versions, same storages
+    with torch.no_grad():
+        b.add_(1.0)                                                                      # in-place change of the SECOND member
+    v1 = cache.get(key, ParamGroup([a, b]), build)
+    assert len(built) == 2 and torch.equal(v1, torch.full((3,), 4.0))
+    assert key in cache._o and key not in cache._c                                      # no replay recipe: dropped after an optimizer step
+    gen = cache.generation()
+    cache.refresh_done()
+    assert key not in cache._o and cache.generation() != gen
+    # a capture that failed: its entries carry its store
+    store = {}
+    graphs._state.update(capturing=True, store=store)
+    try:
+        cache.get(("x", "lin_t", torch.float32), a, lambda: a.detach().clone())
+    finally:
+        graphs._state.update(capturing=False, store=None)
+    assert ("x", "lin_t", torch.float32) in cache._o and cache._o[("x", "lin_t", torch.float32)][6] is store
+    gen = cache.generation()
+    assert cache.purge_capture(store) == 1 and ("x", "lin_t", torch.float32) not in cache._o
+    assert cache.generation({"hit_o": True}) != (gen[0], gen[1])
+    assert cache.purge_capture(store) == 0

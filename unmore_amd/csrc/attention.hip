@@ -273,7 +273,12 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     constexpr int TK = 64;                 // keys per tile
     constexpr int OPB = TK * 128;          // one operand tile: 8 KiB
     constexpr int STB = 2 * OPB;           // K | V
-    __shared__ __attribute__((aligned(16))) char smem[2 * STB];
+#ifdef UMR_ATTN_PIPE
+    constexpr int RING = 3;                // experiment: QK^T of tile j+1 is issued before the softmax of tile j (needs K[j+1] beside V[j])
+#else
+    constexpr int RING = 2;
+#endif
+    __shared__ __attribute__((aligned(16))) char smem[RING * STB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     }
     const unsigned tile_stride = (unsigned)(TK * (int)ld * 2);
     auto issue_tile = [&](int j) {
-        char* dst = smem + (j & 1) * STB + w * 2048;
+        char* dst = smem + (j % RING) * STB + w * 2048;
         const unsigned so = (unsigned)j * tile_stride;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst), 16, voff[0], so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst + 1024), 16, voff[1], so, 0, 0);
@@ -347,6 +352,117 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     constexpr float DEFER = 8.0f;           // log2 units: raise the running max only when a tile tops it by 2^8
 
     const int ntiles = (N + TK - 1) / TK;
+#ifdef UMR_ATTN_PIPE
+    // ---- experiment: in-wave pipeline.  Iteration j: [tile j+1 landed; barrier] issue tile j+2; S(j+1) = Q K[j+1]^T on the matrix pipe WHILE the
+    // vector unit runs the softmax of S(j); then O += V[j] P(j).  The wave's chain per tile is max(QK^T, softmax) + PV instead of their sum.
+    auto qk_tile = [&](int j, f32x4 (&s)[QB][4]) {
+        const int sb = (j % RING) * STB;
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+            const bf16x8 k0 = *(const bf16x8*)(kad0 + sb + sub * 2048);
+            const bf16x8 k1 = *(const bf16x8*)(kad1 + sb + sub * 2048);
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[qi].v[0], f32x4{-m_run[qi], -m_run[qi], -m_run[qi], -m_run[qi]}, 0, 0, 0);
+                s[qi][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[qi].v[1], s[qi][sub], 0, 0, 0);
+            }
+        }
+        if (j == ntiles - 1) {
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (j * TK + 16 * sub + 4 * g + e >= N) {
+#pragma unroll
+                        for (int qi = 0; qi < QB; ++qi) s[qi][sub][e] = -INFINITY;
+                    }
+        }
+    };
+    f32x4 s[QB][4], sn[QB][4];
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    qk_tile(0, s);
+    for (int j = 0; j < ntiles; ++j) {
+        const bool more = j + 1 < ntiles;
+        if (more) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // tile j+1 landed for everyone; everyone is done with tile j-1's buffer
+            if (j + 2 < ntiles) issue_tile(j + 2);
+            qk_tile(j + 1, sn);                // independent of everything below until the end of the iteration
+        }
+        const int sb = (j % RING) * STB;
+        bool any_up = false;
+        float mxs[QB];
+#pragma unroll
+        for (int qi = 0; qi < QB; ++qi) {
+            float mx = max3f(s[qi][0][0], s[qi][0][1], s[qi][0][2]);
+            mx = max3f(mx, s[qi][0][3], s[qi][1][0]);
+            mx = max3f(mx, s[qi][1][1], s[qi][1][2]);
+            mx = max3f(mx, s[qi][1][3], s[qi][2][0]);
+            mx = max3f(mx, s[qi][2][1], s[qi][2][2]);
+            mx = max3f(mx, s[qi][2][3], s[qi][3][0]);
+            mx = max3f(mx, s[qi][3][1], s[qi][3][2]);
+            mx = max2f(mx, s[qi][3][3]);
+            mx = xor16_max(mx);
+            mx = xor32_max(mx);
+            mxs[qi] = mx;
+            any_up = any_up || (mx > DEFER);
+        }
+        if (j == 0 || __builtin_amdgcn_ballot_w64(any_up) != 0ull) {
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) {
+                const float d = (j == 0 || mxs[qi] > DEFER) ? mxs[qi] : 0.f;
+                const float alpha = j == 0 ? 1.0f : __builtin_amdgcn_exp2f(-d);
+                m_run[qi] += d;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[qi][i] *= alpha;
+                lacc[qi] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) { s[qi][sub] -= d; if (more) sn[qi][sub] -= d; }   // S(j+1) was started from the old reference
+            }
+        }
+        const unsigned vb0 = (unsigned)sb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            u32x2 t0[4], t1[4];
+            if (half == 0) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<0>(vad[dt] + vb0); t1[dt] = ds_tr_b64<2048>(vad[dt] + vb0); }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<4096>(vad[dt] + vb0); t1[dt] = ds_tr_b64<4096 + 2048>(vad[dt] + vb0); }
+            }
+            bf16x8 pb[QB];
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pb[qi][e] = (bf16_t)__builtin_amdgcn_exp2f(s[qi][2 * half][e]);
+                    pb[qi][4 + e] = (bf16_t)__builtin_amdgcn_exp2f(s[qi][2 * half + 1][e]);
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(t0[0]), "+v"(t0[1]), "+v"(t0[2]), "+v"(t0[3]), "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3])
+                         :: "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const u32x4 f = {t0[dt][0], t0[dt][1], t1[dt][0], t1[dt][1]};
+#pragma unroll
+                for (int qi = 0; qi < QB; ++qi)
+                    o[qi][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), pb[qi], o[qi][dt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi) lacc[qi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qi], lacc[qi], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int qi = 0; qi < QB; ++qi)
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) s[qi][sub] = sn[qi][sub];
+        }
+    }
+#else
     issue_tile(0);
 #ifdef UMR_ATTN_PEEL_LAST
     // experiment hook (profiles/r05_attention_experiments.txt): the tile body twice, the key mask only in the copy that runs the last tile
@@ -458,6 +574,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
 #else
     }
 #endif
+#endif   // UMR_ATTN_PIPE
 #pragma unroll
     for (int qi = 0; qi < QB; ++qi) {
         const int q = q0 + 16 * qi;

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     }
     const unsigned tile_stride = (unsigned)(TK * (int)ld * 2);
     auto issue_tile = [&](int j) {
-        char* dst = smem + (j % RING) * STB + w * 2048;
+        char* dst = smem + (RING == 2 ? (j & 1) : (j % RING)) * STB + w * 2048;
         const unsigned so = (unsigned)j * tile_stride;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst), 16, voff[0], so, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, UMR_LDS_PTR(dst + 1024), 16, voff[1], so, 0, 0);

@@ -155,6 +155,10 @@ def test_weight_gradient_stream_does_not_change_results(dtype, graph, monkeypatc
                 lanes = [lane for lane, _ in caps[0].segments]
                 # heads, refine, reassemble, 4 blocks, embed: a side graph per stage except the reassemble stage's update (main lane)
                 assert isinstance(caps[0], graphs.StagedCaptured) and lanes.count("side") >= 7 and lanes[0] == "main", lanes
+                # the join of the weight-gradient lane at the end of backward is part of the chain: what follows it on the main lane
+                # (Adam for the stages updated there) reads gradients the side lane wrote
+                assert lanes.count("join") == 1 and lanes.index("join") > max(i for i, l in enumerate(lanes) if l == "side"), lanes
+                assert lanes[-1] == "main"
     for a, b in zip(res["0"], res["1"]):
         assert torch.equal(a, b)
 
@@ -287,7 +291,7 @@ def test_staged_capture_at_the_reference_recipe_shape(dtype):
         caps = [v for v in step_g._graphs.values() if isinstance(v, graphs.StagedCaptured)]
         assert len(caps) == 1 and caps[0].failed is None and step_g.graph_replays == 3
         lanes = [lane for lane, _ in caps[0].segments]
-        assert lanes.count("side") >= 27 and lanes.count("main") >= 27, (lanes.count("main"), lanes.count("side"))
+        assert lanes.count("side") >= 27 and lanes.count("main") >= 27 and lanes.count("join") == 1, (lanes.count("main"), lanes.count("side"))
 
 
 @pytest.mark.parametrize("eval_graphs", ["off", "on"])

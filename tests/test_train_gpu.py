@@ -399,7 +399,9 @@ def test_batched_repack_equals_lazy_repack(dtype, monkeypatch):
         monkeypatch.setattr(trainer, "_BATCHED_REPACK", mode)
         net, _ = _net("dpt_tiny", "tiny", dtype)
         step = trainer.TrainStep(net, lr=1e-3)
-        losses = [step.step(img, cf, sdf, sal).clone() for _ in range(4)]
+        # (eight steps: from the third on the step is replayed as a chain of graphs on two lanes -- with the lazy re-pack the whole Adam
+        # update runs on the main lane AFTER the join of the weight-gradient lane, a join the chain lacked at first: this test caught it)
+        losses = [step.step(img, cf, sdf, sal).clone() for _ in range(8)]
         if mode:
             eng = net._engine()
             # (one launch for all copies, or -- small problems -- one per stage behind the weight-gradient stream)

@@ -326,6 +326,8 @@ class WgradStream:
     def join(self):
         if self.on and self.staged is None:
             self.main.wait_stream(self.side)
+        elif self.staged is not None:
+            self.staged.join()
 
     @staticmethod
     def wanted(pixels):

@@ -158,7 +158,10 @@ class StagedCaptured:
       * every main-lane tensor a deferred launch reads (`used`, the tensors the eager schedule record_stream()s) is kept alive
         until the whole capture has ended: its block is not handed to a later main-lane allocation while the side lane may
         still read it;
-      * scratch buffers are per lane (ops._workspace).
+      * scratch buffers are per lane (ops._workspace);
+      * where the eager schedule joins its second stream (WgradStream.join at the end of backward) the chain has a join marker: the
+        replay makes the main stream wait for the side lane before the next main graph -- the tail of the step (Adam for the
+        stages that are updated on the main lane) reads gradients the side lane wrote.
     Same kernels on the same operands in the same per-lane order as the eager schedule: bit-identical results (tests/test_graph_gpu.py)."""
 
     def __init__(self, fn, example_inputs, generation_of=None, on_fail=None):
@@ -213,7 +216,12 @@ class StagedCaptured:
 
     def _end(self):
         lane_, g, n0 = self._cur
-        g.capture_end()
+        if _launches[0] > n0:
+            g.capture_end()
+        else:
+            with warnings.catch_warnings():      # a cut right after a cut records nothing: torch warns about an empty graph, which is dropped
+                warnings.simplefilter("ignore")
+                g.capture_end()
         self._cur = None
         _state["lane"] = None
         if _launches[0] > n0:            # (a segment without a launch is not replayed)
@@ -235,6 +243,16 @@ class StagedCaptured:
         self._end()
         self._begin("main")
 
+    def join(self):
+        """the caller's join of its weight-gradient stream (engine.WgradStream.join at the end of backward: what follows on the main
+        lane -- the Adam update and weight refresh of the stages that are not updated on the side lane, e.g. the reassemble stage --
+        READS what the side lane wrote): flush what is pending, cut the main lane here, and make the replay wait for the side lane
+        before it enqueues the next main graph"""
+        self.boundary()
+        self._end()
+        self.segments.append(("join", None))
+        self._begin("main")
+
     # ---- replay side
     def valid(self):
         return bool(self.segments) and (self._gen_of is None or self._gen_of(self.store) == self.generation)
@@ -248,6 +266,8 @@ class StagedCaptured:
         for lane_, g in self.segments:
             if lane_ == "main":
                 g.replay()
+            elif lane_ == "join":
+                main.wait_stream(side)
             else:
                 ev = self._events[k]
                 k += 1

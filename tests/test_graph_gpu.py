@@ -344,3 +344,27 @@ def test_dropped_captures_release_their_pools():
         reserved.append(torch.cuda.memory_reserved())
     assert step.graph_replays == 3 * (graphs.MAX_CAPTURES + 4) * 2
     assert reserved[2] <= 1.25 * reserved[0] + (64 << 20), [r / 2 ** 20 for r in reserved]
+
+
+@pytest.mark.parametrize("batched_repack", [True, False])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_staged_replay_with_a_lagging_side_lane(dtype, batched_repack, monkeypatch):
+    """Dependencies of the main lane on the side lane must be in the chain, not in the timing: every side graph of the replay is held back
+    by ~1 ms of spinning (StagedCaptured.debug_side_delay), so the weight gradients, the per-stage Adam updates and weight refreshes
+    finish long after the main lane has moved on.  The step must stay bit-identical to the eager one -- with the whole Adam update on
+    the main lane (lazy re-pack, batched_repack=False: it reads every gradient the side lane writes) and with the default schedule."""
+    from unmore_amd import graphs, trainer
+    monkeypatch.setattr(trainer, "_BATCHED_REPACK", batched_repack)
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    step_e = trainer.TrainStep(net_e, lr=1e-3).set_graph_mode("off")
+    step_g = trainer.TrainStep(net_g, lr=1e-3).set_graph_mode("on")
+    for it in range(7):
+        batch = _batch(2, 64, 64, seed=900 + it)
+        le, lg = step_e.step(*batch), step_g.step(*batch)
+        assert torch.equal(le, lg), (it, le.tolist(), lg.tolist())
+        assert torch.equal(step_e.flat_p, step_g.flat_p), it
+        for cap in step_g._graphs.values():
+            if isinstance(cap, graphs.StagedCaptured):
+                cap.debug_side_delay = 2_500_000
+    assert step_g.graph_replays == 5

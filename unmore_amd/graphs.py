@@ -166,6 +166,7 @@ class StagedCaptured:
 
     def __init__(self, fn, example_inputs, generation_of=None, on_fail=None):
         self.failed = None
+        self.debug_side_delay = 0
         self.segments = []          # (lane, CUDAGraph) in issue order
         self._gen_of = generation_of
         dev = example_inputs[0].device
@@ -274,6 +275,8 @@ class StagedCaptured:
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
+                    if self.debug_side_delay:          # test hook: hold the side lane back (spin cycles) so that a missing
+                        torch.cuda._sleep(self.debug_side_delay)   # dependency of the main lane on it cannot hide behind timing
                     g.replay()
         main.wait_stream(side)
         return self.outs

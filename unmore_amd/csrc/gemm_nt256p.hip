@@ -501,6 +501,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     }
     __builtin_amdgcn_s_barrier();
 
+    // copy-out of the fast class: a thread moves 16-byte chunks of rows (tid >> 5) + 16 j of a pass; its byte offsets into C / aux,
+    // relative to the tile origin, are constants of the kernel (the tile origin and the row bound go into a buffer descriptor per tile)
+    const unsigned co_lane = ((unsigned)(tid >> 5) * (unsigned)p.ldc + (unsigned)(tid & 31) * 8u) * 2u;
+    const unsigned ax_lane = ((unsigned)(tid >> 5) * (unsigned)p.ldaux + (unsigned)(tid & 31) * 8u) * 2u;
     float* stg = (float*)(smem + STG_OFF);
     // one epilogue pass writes the 32 rows {wr*128 + mt*16 + 0..15} x 256 columns of the tile into the staging region
     auto stage_rows = [&](auto mtag) {
@@ -585,8 +589,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // their fragment layout, the results are staged as bf16 -- 64 tile rows per pass, 4 passes / 8 barriers, half the
             // LDS traffic of an f32 staging -- and leave as plain 16-byte copies.
             fetch_bias(it + 1);
-            // ReLU without a branch: max with 0 or with -inf
-            const float relu_floor = (p.act == UMR_ACT_RELU) ? 0.f : -INFINITY;
+            // ReLU without a branch, on the bf16 pair AFTER rounding: as 16-bit integers positive bf16 values are positive and everything
+            // with the sign bit is negative, so max with (0, 0) is ReLU (rounding keeps the sign: same bits as ReLU before rounding), max
+            // with (-32768, -32768) the identity.  One v_pk_max_i16 per two values instead of two v_max_f32.
+            typedef __attribute__((ext_vector_type(2))) short s16x2;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const short relu_lo = (p.act == UMR_ACT_RELU) ? (short)0 : (short)-32768;
+            const s16x2 relu16 = {relu_lo, relu_lo};
+            auto pack4 = [&](const f32x4& v) -> u32x2 {
+                // (as asm: with the integer max behind it the compiler no longer pairs the two conversions into one instruction)
+                unsigned lo, hi;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+                s16x2 a = __builtin_bit_cast(s16x2, lo), b = __builtin_bit_cast(s16x2, hi);
+                if (AUXM == 0) {   // (an aux operand excludes ReLU: umr_nt256p_fast_epilogue)
+                    a = __builtin_elementwise_max(a, relu16);
+                    b = __builtin_elementwise_max(b, relu16);
+                }
+                return u32x2{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+            };
             // fused row reduction (umr_gemm_desc.red_*): this lane's 16 columns of the reduction weights; the partial dot
             // products of a row are summed over the 4 lanes that share it (fq) and written per 64-column wave slice
             // They were brought into the (idle) staging region by LDS-DMA at the start of the tile -- a global load here would
@@ -598,6 +619,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // 0 / 1 = outputs 0 / 1: no shuffles.  32 MFMAs per wave and tile instead of ~100 conversions + FMAs per lane and pass:
             // the VALU form made this epilogue 26.5 k cycles of a 55 k-cycle tile (s_memtime stamps, profiles/r04_ts_probe_head_1x1.txt).
             bf16x8 rwh[2], rwl[2];
+            float* ro_lane = nullptr;     // this lane's slot of the partial sums for row block 0 (lanes fq == 0 of a live column slice)
             if (RED) {
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
@@ -614,19 +636,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                         rwl[pr][e] = (bf16_t)(x - (float)hi);
                     }
                 }
+                if (fq == 0 && n0 + wc * 64 < p.N)
+                    ro_lane = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + (m0 + wr * 128 + frow)) * p.red_c;
                 __syncthreads();
             }
-            // partial dot products of one 16-row block: t01 / t23 = the lane's bf16 values of column blocks (0,1) / (2,3)
-            auto row_reduce = [&](const bf16x8& t01, const bf16x8& t23, int mt_) {
-                f32x4 red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[0], t01, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[0], t01, red, 0, 0, 0);
-                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[1], t23, red, 0, 0, 0);
-                red = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[1], t23, red, 0, 0, 0);
+            // partial dot products of TWO 16-row blocks (mt_, mt_ + 1): a01 / a23 = the lane's bf16 values of column blocks (0,1) / (2,3)
+            // of the first, b01 / b23 of the second.  Each block's four MFMAs depend on each other (same order as ever: bit-identical);
+            // the two chains are interleaved so that no MFMA waits for its predecessor's result.  (Round 5: one chain per block ended in
+            // `s_nop 7`, and the address of every 4-byte result took two quarter-rate 32-bit multiplies.)
+            auto row_reduce2 = [&](const bf16x8& a01, const bf16x8& a23, const bf16x8& b01, const bf16x8& b23, int mt_) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[0], a01, z, 0, 0, 0);
+                f32x4 rb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[0], b01, z, 0, 0, 0);
+                ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[0], a01, ra, 0, 0, 0);
+                rb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[0], b01, rb, 0, 0, 0);
+                ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[1], a23, ra, 0, 0, 0);
+                rb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwh[1], b23, rb, 0, 0, 0);
+                ra = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[1], a23, ra, 0, 0, 0);
+                rb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rwl[1], b23, rb, 0, 0, 0);
                 const int m = m0 + wr * 128 + mt_ * 16 + frow;
-                if (fq == 0 && m < m_end && n0 + wc * 64 < p.N) {
-                    float* ro = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + m) * p.red_c;
-                    ro[0] = red[0];
-                    if (p.red_c == 2) ro[1] = red[1];
+                if (ro_lane != nullptr) {
+                    float* ro = ro_lane + (int64_t)(mt_ * 16) * p.red_c;
+                    if (p.red_c == 2) {
+                        if (m < m_end) *(f32x2*)ro = f32x2{ra[0], ra[1]};
+                        if (m + 16 < m_end) *(f32x2*)(ro + 32) = f32x2{rb[0], rb[1]};
+                    } else {
+                        if (m < m_end) ro[0] = ra[0];
+                        if (m + 16 < m_end) ro[16] = rb[0];
+                    }
                 }
             };
             // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
@@ -635,18 +672,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             // two passes ahead (their first touch is an HBM round trip, longer than one pass).  ReLU mask (AUXM 2): masking
             // commutes with the rounding -- bit-identical.  Residual add (AUXM 1): bf16(bf16(acc) + aux), i.e. the GEMM result
             // is rounded to the storage type before the residual is added, as a separate Linear + add in bf16 would do.
+            // Round 5: C and aux are addressed through buffer descriptors of the TILE (origin = its first row and column, num_records =
+            // its live rows): rows past the end are dropped / read as zeros by the bounds check, a thread whose 8 columns lie past N gets
+            // an out-of-range offset, and the row of a (pass, j) is a scalar added to the lane offset (in the VECTOR offset: the
+            // instruction's scalar offset is excluded from the bounds check).  Before, every 16-byte store sat in its own branch
+            // behind two quarter-rate multiplies and its own `s_waitcnt lgkmcnt(0)` -- four serial LDS round trips per pass.
+            const bool col_live = n0 + (tid & 31) * 8 < p.N;
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((T2*)p.C + (int64_t)m0 * p.ldc + n0), 0, p.no_store ? 0 : clamp31((int64_t)(m_end - m0) * p.ldc * 2), 0x00020000);
+            const unsigned co_vo = col_live ? co_lane : OOB;
+            __amdgpu_buffer_rsrc_t rsX = rsC;
+            unsigned ax_vo = OOB;
+            if (AUXM != 0) {
+                rsX = __builtin_amdgcn_make_buffer_rsrc((void*)((T2*)p.aux + (int64_t)m0 * p.ldaux + n0), 0,
+                                                        clamp31((int64_t)(m_end - m0) * p.ldaux * 2), 0x00020000);
+                ax_vo = col_live ? ax_lane : OOB;
+            }
             u32x4 axc[3][4];   // loads run two passes ahead of their use
             auto load_auxc = [&](auto ptag) {
                 constexpr int PS = decltype(ptag)::value;
                 if (PS < 4 && AUXM != 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                        u32x4 a = {0u, 0u, 0u, 0u};
-                        if (m < m_end && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                        axc[PS % 3][j] = a;
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        axc[PS % 3][j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ax_vo + (unsigned)(((j >> 1) * 128 + PS * 32 + (j & 1) * 16) * p.ldaux * 2), 0, 0);
                 }
             };
             load_auxc(std::integral_constant<int, 0>{});
@@ -656,50 +704,49 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 constexpr int PS = decltype(ptag)::value;
                 load_auxc(std::integral_constant<int, PS + 2>{});
                 if (PS > 0) __syncthreads();
+                bf16x8 tq[2][2];     // [block][column blocks (0,1) / (2,3)]: the values AS STORED (bf16-rounded)
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
                     const int lr = wr * 32 + mh * 16 + frow;
-                    bf16x8 tq[2];     // the values AS STORED (bf16-rounded), column blocks (0,1) and (2,3)
 #pragma unroll
                     for (int ntl = 0; ntl < 4; ++ntl) {
-                        f32x4 v = acc[PS * 2 + mh][ntl];
-                        if (AUXM == 0) {   // (an aux operand excludes ReLU: umr_nt256p_fast_epilogue)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
-                        }
-                        bf16x4 t;
-                        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+                        const u32x2 pk = pack4(acc[PS * 2 + mh][ntl]);
                         const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
-                        *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
+                        *(u32x2*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = pk;
                         if (RED) {
+                            const bf16x4 t = __builtin_bit_cast(bf16x4, pk);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) tq[ntl >> 1][(ntl & 1) * 4 + e] = t[e];
+                            for (int e = 0; e < 4; ++e) tq[mh][ntl >> 1][(ntl & 1) * 4 + e] = t[e];
                         }
                     }
-                    if (RED) row_reduce(tq[0], tq[1], PS * 2 + mh);
                 }
+                if (RED) row_reduce2(tq[0][0], tq[0][1], tq[1][0], tq[1][1], PS * 2);
                 __syncthreads();
+                u32x4 o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                    const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                    u32x4 o = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                    o[j] = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
                     if (AUXM == 2) {
                         // keep a bf16 where the mask operand is > 0, i.e. where its 16 bits read as a positive integer:
                         // min(a, 1) -> max(.., 0) is 1 or 0 per half, 0 - that is 0xFFFF or 0
                         const u32x4 a = axc[PS % 3][j];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] &= pos_mask_bf16x2(a[e]);
+                        for (int e = 0; e < 4; ++e) o[j][e] &= pos_mask_bf16x2(a[e]);
                     }
                     if (AUXM == 1) {
                         const u32x4 a = axc[PS % 3][j];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = add_bf16x2(o[e], a[e]);
+                        for (int e = 0; e < 4; ++e) o[j][e] = add_bf16x2(o[j][e], a[e]);
                     }
+                    const unsigned so = (unsigned)(((j >> 1) * 128 + PS * 32 + (j & 1) * 16) * p.ldc * 2);
 #ifdef UMR_EXP_NT_STORE   // experiment (tools/energy_probe.py): non-temporal C stores -- C is re-read only by a much later kernel
-                    if (m < m_end && n < p.N && !p.no_store) __builtin_nontemporal_store(o, (u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n));
+                    __builtin_amdgcn_raw_buffer_store_b128(o[j], rsC, co_vo + so, 0, 2);
 #else
-                    if (m < m_end && n < p.N && !p.no_store) *(u32x4*)((T2*)p.C + (int64_t)m * p.ldc + n) = o;
+                    __builtin_amdgcn_raw_buffer_store_b128(o[j], rsC, co_vo + so, 0, 0);
 #endif
                 }
             };
@@ -707,15 +754,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 // inference / algebraic-backward form of the fused output layer: C itself is never stored, so nothing is staged
                 // through LDS and no barrier is needed -- the dot products are taken on the bf16-rounded values in registers
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    bf16x8 tq[2];
+                for (int mt = 0; mt < 8; mt += 2) {
+                    bf16x8 tq[2][2];
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) {
-                        const f32x4 v = acc[mt][ntl];
+                    for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) tq[ntl >> 1][(ntl & 1) * 4 + e] = (bf16_t)fmaxf(v[e], relu_floor);
-                    }
-                    row_reduce(tq[0], tq[1], mt);
+                        for (int ntl = 0; ntl < 4; ++ntl) {
+                            const bf16x4 t = __builtin_bit_cast(bf16x4, pack4(acc[mt + mh][ntl]));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tq[mh][ntl >> 1][(ntl & 1) * 4 + e] = t[e];
+                        }
+                    row_reduce2(tq[0][0], tq[0][1], tq[1][0], tq[1][1], mt);
                 }
             } else {
                 pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});

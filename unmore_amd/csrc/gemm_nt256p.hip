@@ -501,10 +501,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
     }
     __builtin_amdgcn_s_barrier();
 
-    // copy-out of the fast class: a thread moves 16-byte chunks of rows (tid >> 5) + 16 j of a pass; its byte offsets into C / aux,
-    // relative to the tile origin, are constants of the kernel (the tile origin and the row bound go into a buffer descriptor per tile)
-    const unsigned co_lane = ((unsigned)(tid >> 5) * (unsigned)p.ldc + (unsigned)(tid & 31) * 8u) * 2u;
-    const unsigned ax_lane = ((unsigned)(tid >> 5) * (unsigned)p.ldaux + (unsigned)(tid & 31) * 8u) * 2u;
+    // Epilogue of the fast class (round 5): every wave turns ITS 16 x 64 blocks of the tile from the fragment layout into row-contiguous
+    // 16-byte chunks through a private 2-KiB staging block -- no workgroup barrier anywhere in the epilogue (LDS serves one wave's
+    // accesses in order, so a block's writes, its reads and the next block's writes need no wait between them).  Copy-out: lane ->
+    // rows er, er + 8 of the block, chunk ec of the wave's 128-byte row segment (a store instruction writes 8 full 128-byte lines).
+    // Byte offsets into C / aux relative to the tile origin are constants of the kernel; chunks are XOR-swizzled with (row >> 1) & 7.
+    const int er = lane >> 3, ec = lane & 7;
+    const unsigned co_lane = ((unsigned)((w >> 2) * 128 + er) * (unsigned)p.ldc + (unsigned)((w & 3) * 64 + ec * 8)) * 2u;
+    const unsigned ax_lane = ((unsigned)((w >> 2) * 128 + er) * (unsigned)p.ldaux + (unsigned)((w & 3) * 64 + ec * 8)) * 2u;
+    constexpr int WST_BYTES = 2048;              // per wave: 16 rows x 128 bytes
+    constexpr int RW_OFF = 8 * WST_BYTES;        // fused row reduction: its weights, 2 tiles x 2 rows x 1 KiB, behind the waves' blocks
     float* stg = (float*)(smem + STG_OFF);
     // one epilogue pass writes the 32 rows {wr*128 + mt*16 + 0..15} x 256 columns of the tile into the staging region
     auto stage_rows = [&](auto mtag) {
@@ -556,7 +562,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             const int n0_ = (v_ - (v_ / tiles_n) * tiles_n) * BN2;
             const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(p.red_w + (int64_t)w * p.N + n0_), 0, (w < p.red_c) ? clamp31((int64_t)(p.N - n0_) * 4) : 0, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, UMR_LDS_PTR(smem + STG_OFF + w * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
+            // (fast class: double-buffered by tile parity -- its epilogue has no barrier, a wave may start the next tile while another
+            // still reads this tile's weights; the copy two tiles on is separated from those reads by that tile's K-loop barriers)
+            const int rw_off = (EPI == 3) ? RW_OFF + (it & 1) * 2048 : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, UMR_LDS_PTR(smem + STG_OFF + rw_off + w * 1024), 16, (unsigned)(lane * 16), 0, 0, 0);
         }
         if (ahead) {
 #pragma unroll 1
@@ -625,8 +634,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 for (int pr = 0; pr < 2; ++pr) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
                     if (frow < 2) {
-                        a = *(const f32x4*)(smem + STG_OFF + frow * 1024 + (wc * 64 + (2 * pr) * 16 + fq * 4) * 4);
-                        b = *(const f32x4*)(smem + STG_OFF + frow * 1024 + (wc * 64 + (2 * pr + 1) * 16 + fq * 4) * 4);
+                        const char* rwp = smem + STG_OFF + RW_OFF + (it & 1) * 2048 + frow * 1024;
+                        a = *(const f32x4*)(rwp + (wc * 64 + (2 * pr) * 16 + fq * 4) * 4);
+                        b = *(const f32x4*)(rwp + (wc * 64 + (2 * pr + 1) * 16 + fq * 4) * 4);
                     }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -638,7 +648,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                 }
                 if (fq == 0 && n0 + wc * 64 < p.N)
                     ro_lane = p.red_out + ((int64_t)(tn * 4 + wc) * p.M + (m0 + wr * 128 + frow)) * p.red_c;
-                __syncthreads();
             }
             // partial dot products of TWO 16-row blocks (mt_, mt_ + 1): a01 / a23 = the lane's bf16 values of column blocks (0,1) / (2,3)
             // of the first, b01 / b23 of the second.  Each block's four MFMAs depend on each other (same order as ever: bit-identical);
@@ -666,18 +675,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     }
                 }
             };
-            // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads, a wave reads whole
-            // 512-byte row segments (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per
-            // instruction, and the epilogue of a residual-add GEMM took 25 k cycles against 6.7 k without aux).  Loads are issued
-            // two passes ahead (their first touch is an HBM round trip, longer than one pass).  ReLU mask (AUXM 2): masking
-            // commutes with the rounding -- bit-identical.  Residual add (AUXM 1): bf16(bf16(acc) + aux), i.e. the GEMM result
-            // is rounded to the storage type before the residual is added, as a separate Linear + add in bf16 would do.
-            // Round 5: C and aux are addressed through buffer descriptors of the TILE (origin = its first row and column, num_records =
-            // its live rows): rows past the end are dropped / read as zeros by the bounds check, a thread whose 8 columns lie past N gets
-            // an out-of-range offset, and the row of a (pass, j) is a scalar added to the lane offset (in the VECTOR offset: the
-            // instruction's scalar offset is excluded from the bounds check).  Before, every 16-byte store sat in its own branch
-            // behind two quarter-rate multiplies and its own `s_waitcnt lgkmcnt(0)` -- four serial LDS round trips per pass.
-            const bool col_live = n0 + (tid & 31) * 8 < p.N;
+            // The aux operand is applied to the staged bf16 values in the COPY-OUT layout: 16-byte loads of whole 128-byte row segments
+            // (in the fragment layout a lane reads 8 bytes at a row stride: 4x the cache lines per instruction, and the epilogue of a
+            // residual-add GEMM took 25 k cycles against 6.7 k without aux).  Loads are issued two blocks ahead (their first touch is
+            // an HBM round trip).  ReLU mask (AUXM 2): masking commutes with the rounding -- bit-identical.  Residual add (AUXM 1):
+            // bf16(bf16(acc) + aux), i.e. the GEMM result is rounded to the storage type before the residual is added, as a separate
+            // Linear + add in bf16 would do.
+            // C and aux are addressed through buffer descriptors of the TILE (origin = its first row and column, num_records = its live
+            // rows): rows past the end are dropped / read as zeros by the bounds check, a lane whose 8 columns lie past N gets an
+            // out-of-range offset, and the row of a block is a scalar added to the lane offset (in the VECTOR offset: the
+            // instruction's scalar offset is excluded from the bounds check).
+            const bool col_live = n0 + wc * 64 + ec * 8 < p.N;
             const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)((T2*)p.C + (int64_t)m0 * p.ldc + n0), 0, p.no_store ? 0 : clamp31((int64_t)(m_end - m0) * p.ldc * 2), 0x00020000);
             const unsigned co_vo = col_live ? co_lane : OOB;
@@ -688,71 +696,76 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                                                         clamp31((int64_t)(m_end - m0) * p.ldaux * 2), 0x00020000);
                 ax_vo = col_live ? ax_lane : OOB;
             }
-            u32x4 axc[3][4];   // loads run two passes ahead of their use
-            auto load_auxc = [&](auto ptag) {
-                constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && AUXM != 0) {
+            u32x4 axc[4][2];   // ring over row blocks; loads run two blocks ahead of their use
+            auto load_auxc = [&](auto btag) {
+                constexpr int MB = decltype(btag)::value;
+                if (MB < 8 && AUXM != 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        axc[PS % 3][j] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ax_vo + (unsigned)(((j >> 1) * 128 + PS * 32 + (j & 1) * 16) * p.ldaux * 2), 0, 0);
+                    for (int k = 0; k < 2; ++k)
+                        axc[MB & 3][k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ax_vo + (unsigned)((MB * 16 + k * 8) * p.ldaux * 2), 0, 0);
                 }
             };
             load_auxc(std::integral_constant<int, 0>{});
             load_auxc(std::integral_constant<int, 1>{});
-            char* stb = smem + STG_OFF;
-            auto pass3 = [&](auto ptag) {
-                constexpr int PS = decltype(ptag)::value;
-                load_auxc(std::integral_constant<int, PS + 2>{});
-                if (PS > 0) __syncthreads();
-                bf16x8 tq[2][2];     // [block][column blocks (0,1) / (2,3)]: the values AS STORED (bf16-rounded)
+            char* wst = smem + STG_OFF + w * WST_BYTES;
+            const int wsw = (frow >> 1) & 7;
+            char* wst_w = wst + frow * 128 + (fq & 1) * 8;                       // + (((ntl * 2 + (fq >> 1)) ^ wsw) << 4)
+            const char* wst_r0 = wst + er * 128 + ((ec ^ ((er >> 1) & 7)) << 4);
+            const char* wst_r1 = wst + (er + 8) * 128 + ((ec ^ (((er >> 1) + 4) & 7)) << 4);
+            // row blocks MB, MB + 1 of the wave
+            auto blocks2 = [&](auto btag) {
+                constexpr int MB = decltype(btag)::value;
+                load_auxc(std::integral_constant<int, MB + 2>{});
+                load_auxc(std::integral_constant<int, MB + 3>{});
+                u32x2 pk[2][4];      // the values AS STORED (bf16-rounded)
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) pk[mh][ntl] = pack4(acc[MB + mh][ntl]);
+                if (RED) {
+                    bf16x8 tq[2][2];
+#pragma unroll
+                    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            tq[mh][h] = __builtin_bit_cast(bf16x8, u32x4{pk[mh][2 * h][0], pk[mh][2 * h][1], pk[mh][2 * h + 1][0], pk[mh][2 * h + 1][1]});
+                    row_reduce2(tq[0][0], tq[0][1], tq[1][0], tq[1][1], MB);
+                }
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
-                    const int lr = wr * 32 + mh * 16 + frow;
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) {
-                        const u32x2 pk = pack4(acc[PS * 2 + mh][ntl]);
-                        const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
-                        *(u32x2*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = pk;
-                        if (RED) {
-                            const bf16x4 t = __builtin_bit_cast(bf16x4, pk);
+                    for (int ntl = 0; ntl < 4; ++ntl) *(u32x2*)(wst_w + (((ntl * 2 + (fq >> 1)) ^ wsw) << 4)) = pk[mh][ntl];
+                    asm volatile("" ::: "memory");     // (compiler only: the reads below see these writes, the next block's writes follow the reads)
+                    u32x4 o[2];
+                    o[0] = *(const u32x4*)wst_r0;
+                    o[1] = *(const u32x4*)wst_r1;
+                    asm volatile("" ::: "memory");
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) tq[mh][ntl >> 1][(ntl & 1) * 4 + e] = t[e];
+                    for (int k = 0; k < 2; ++k) {
+                        if (AUXM == 2) {
+                            // keep a bf16 where the mask operand is > 0, i.e. where its 16 bits read as a positive integer:
+                            // min(a, 1) -> max(.., 0) is 1 or 0 per half, 0 - that is 0xFFFF or 0
+                            const u32x4 a = axc[(MB + mh) & 3][k];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[k][e] &= pos_mask_bf16x2(a[e]);
                         }
-                    }
-                }
-                if (RED) row_reduce2(tq[0][0], tq[0][1], tq[1][0], tq[1][1], PS * 2);
-                __syncthreads();
-                u32x4 o[4];
+                        if (AUXM == 1) {
+                            const u32x4 a = axc[(MB + mh) & 3][k];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                    o[j] = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (AUXM == 2) {
-                        // keep a bf16 where the mask operand is > 0, i.e. where its 16 bits read as a positive integer:
-                        // min(a, 1) -> max(.., 0) is 1 or 0 per half, 0 - that is 0xFFFF or 0
-                        const u32x4 a = axc[PS % 3][j];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[j][e] &= pos_mask_bf16x2(a[e]);
-                    }
-                    if (AUXM == 1) {
-                        const u32x4 a = axc[PS % 3][j];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[j][e] = add_bf16x2(o[j][e], a[e]);
-                    }
-                    const unsigned so = (unsigned)(((j >> 1) * 128 + PS * 32 + (j & 1) * 16) * p.ldc * 2);
+                            for (int e = 0; e < 4; ++e) o[k][e] = add_bf16x2(o[k][e], a[e]);
+                        }
+                        const unsigned so = (unsigned)(((MB + mh) * 16 + k * 8) * p.ldc * 2);
 #ifdef UMR_EXP_NT_STORE   // experiment (tools/energy_probe.py): non-temporal C stores -- C is re-read only by a much later kernel
-                    __builtin_amdgcn_raw_buffer_store_b128(o[j], rsC, co_vo + so, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b128(o[k], rsC, co_vo + so, 0, 2);
 #else
-                    __builtin_amdgcn_raw_buffer_store_b128(o[j], rsC, co_vo + so, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o[k], rsC, co_vo + so, 0, 0);
 #endif
+                    }
                 }
             };
             if (RED && p.no_store) {
                 // inference / algebraic-backward form of the fused output layer: C itself is never stored, so nothing is staged
-                // through LDS and no barrier is needed -- the dot products are taken on the bf16-rounded values in registers
+                // through LDS -- the dot products are taken on the bf16-rounded values in registers
 #pragma unroll
                 for (int mt = 0; mt < 8; mt += 2) {
                     bf16x8 tq[2][2];
@@ -767,11 +780,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
                     row_reduce2(tq[0][0], tq[0][1], tq[1][0], tq[1][1], mt);
                 }
             } else {
-                pass3(std::integral_constant<int, 0>{}); TS(5); pass3(std::integral_constant<int, 1>{});
-                pass3(std::integral_constant<int, 2>{}); pass3(std::integral_constant<int, 3>{});
+                blocks2(std::integral_constant<int, 0>{}); TS(5); blocks2(std::integral_constant<int, 2>{});
+                blocks2(std::integral_constant<int, 4>{}); blocks2(std::integral_constant<int, 6>{});
             }
             TS(6);
-            __syncthreads();
             TS(7);
         } else if (EPI == 4) {
             // GELU class (the transformer MLP): act == GELU with the pre-activation optionally saved to C2 (c2_mode 2), or

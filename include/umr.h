@@ -201,6 +201,14 @@ int64_t umr_layernorm_bwd_workspace(int M, int D);
 int umr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
                       int64_t workspace_bytes, int M, int D, int dtype, umr_stream_t stream);
+/* The same in two steps.  _rows: dx (+ dres) and the per-workgroup partial sums of dgamma / dbeta -> workspace; _params: dgamma / dbeta
+ * from those partial sums.  The second step is a weight-gradient computation: the caller may run it on the stream that carries the weight
+ * gradients, behind the first, provided `workspace` is left alone until it has run (umr_layernorm_bwd = both on one stream). */
+int umr_layernorm_bwd_rows(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                           const void* dres, void* dx, void* workspace, int64_t workspace_bytes, int M, int D, int dtype,
+                           umr_stream_t stream);
+int umr_layernorm_bwd_params(const void* workspace, int64_t workspace_bytes, float* dgamma, float* dbeta, int accumulate,
+                             int M, int D, umr_stream_t stream);
 
 /* ---- fused attention (timm Attention / F.scaled_dot_product_attention; scale head_dim^-0.5) ----
  * qkv [B*N, 3*heads*64] as produced by the qkv GEMM; out [B*N, heads*64]; lse f32 [B*heads*N].

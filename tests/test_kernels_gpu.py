@@ -46,6 +46,19 @@ def test_layernorm(dtype, M, D):
     t = dict(atol=1e-3, rtol=1e-4) if dtype == torch.float32 else dict(atol=0.3, rtol=5e-2)
     torch.testing.assert_close(dg.double(), gr.grad, **t)
     torch.testing.assert_close(db.double(), br.grad, **t)
+    # the two-step form (umr_layernorm_bwd_rows / _params: the parameter pass handed to a weight-gradient lane -- here another
+    # stream, behind the row pass, with the scratch of the one-step form rewritten in between): the same bits
+    dg2, db2 = torch.full_like(dg, 7.0), torch.full_like(db, 7.0)
+    side = torch.cuda.Stream(device=dev)
+    deferred = []
+    dx2 = ops.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, dres=dres, params_via=lambda fn, *used: deferred.append((fn, used)))
+    ops.layernorm_bwd(dy * 2, x, g, mean, rstd, torch.empty_like(dg), torch.empty_like(db))     # (rewrites the shared scratch)
+    assert torch.equal(dg2, torch.full_like(dg2, 7.0)) and len(deferred) == 1 and deferred[0][1][0].numel() > 0
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        deferred[0][0]()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -81,6 +81,8 @@ _SIGS = {
     "umr_layernorm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _i32, _vp],
     "umr_layernorm_bwd_workspace": [_i32, _i32],
     "umr_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _i32, _i32, _vp],
+    "umr_layernorm_bwd_rows": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "umr_layernorm_bwd_params": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _vp],
     "umr_attention_fwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_attention_bwd_workspace": [_i32, _i32, _i32],

@@ -381,12 +381,8 @@ extern "C" int64_t umr_layernorm_bwd_workspace(int M, int D) {
     return (int64_t)nb * 2 * D * 4;
 }
 
-extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                                 const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                                 int64_t workspace_bytes, int M, int D, int dtype, umr_stream_t stream) {
-    UMR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
-    UMR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D must be a multiple of 8, <= 2048");
-    UMR_CHECK_ARG(workspace_bytes >= umr_layernorm_bwd_workspace(M, D), "layernorm_bwd: workspace too small");
+// workgroups of the row pass and rows per workgroup (the parameter pass reduces exactly that many partial sums)
+static void ln_bwd_plan(int M, int* nb_out, int* rpb_out) {
     int nb = ln_bwd_blocks(M);
     {
         // ONE round of workgroups: the bf16 kernel needs 214 VGPRs (two workgroups per CU), so more than 2 x CUs blocks run as a
@@ -402,7 +398,19 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
         if (nb > wg_per_cu * cus) nb = wg_per_cu * cus;
     }
     const int rpb = (M + nb - 1) / nb;
-    nb = (M + rpb - 1) / rpb;
+    *nb_out = (M + rpb - 1) / rpb;
+    *rpb_out = rpb;
+}
+
+// row pass: dx (+ dres) and, per workgroup, the partial sums of dgamma / dbeta over its rows -> workspace [nb][2][D]
+extern "C" int umr_layernorm_bwd_rows(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                      const void* dres, void* dx, void* workspace, int64_t workspace_bytes, int M, int D, int dtype,
+                                      umr_stream_t stream) {
+    UMR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "layernorm_bwd: null pointer");
+    UMR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D must be a multiple of 8, <= 2048");
+    UMR_CHECK_ARG(workspace_bytes >= umr_layernorm_bwd_workspace(M, D), "layernorm_bwd: workspace too small");
+    int nb, rpb;
+    ln_bwd_plan(M, &nb, &rpb);
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)8 * D * 4;
     if (dtype == UMR_BF16 && D % 8 == 0 && D <= 1024)
@@ -419,7 +427,29 @@ extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gam
                            (const float*)dres, (float*)dx, (float*)workspace, M, D, rpb);
     else return umr_set_error(UMR_ERR_INVALID, "layernorm_bwd: dtype");
     UMR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 63) / 64), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, nb, D, accumulate);
+    return UMR_OK;
+}
+
+// parameter pass: dgamma / dbeta (+=, if accumulate) = sum of the row pass's partial sums.  A weight gradient: the caller may run it on
+// another stream than the data-gradient chain (behind the row pass), as long as `workspace` stays untouched until it has run.
+extern "C" int umr_layernorm_bwd_params(const void* workspace, int64_t workspace_bytes, float* dgamma, float* dbeta, int accumulate,
+                                        int M, int D, umr_stream_t stream) {
+    UMR_CHECK_ARG(workspace && dgamma && dbeta, "layernorm_bwd: null pointer");
+    UMR_CHECK_ARG(M > 0 && D > 0 && D % 8 == 0 && D <= 256 * LN_MAXV, "layernorm_bwd: D must be a multiple of 8, <= 2048");
+    UMR_CHECK_ARG(workspace_bytes >= umr_layernorm_bwd_workspace(M, D), "layernorm_bwd: workspace too small");
+    int nb, rpb;
+    ln_bwd_plan(M, &nb, &rpb);
+    hipLaunchKernelGGL(ln_bwd_reduce, dim3((2 * D + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, dgamma, dbeta, nb, D,
+                       accumulate);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
+}
+
+extern "C" int umr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                                 const void* dres, void* dx, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                                 int64_t workspace_bytes, int M, int D, int dtype, umr_stream_t stream) {
+    UMR_CHECK_ARG(dgamma && dbeta, "layernorm_bwd: null pointer");
+    const int rc = umr_layernorm_bwd_rows(dy, x, gamma, mean, rstd, dres, dx, workspace, workspace_bytes, M, D, dtype, stream);
+    if (rc != UMR_OK) return rc;
+    return umr_layernorm_bwd_params(workspace, workspace_bytes, dgamma, dbeta, accumulate, M, D, stream);
 }

@@ -279,6 +279,8 @@ _LINEAR_HEAD_BWD = os.environ.get("UMR_LINEAR_HEAD_BWD", "algebraic")
 
 
 _WGRAD_STREAM = os.environ.get("UMR_WGRAD_STREAM", "auto")   # weight gradients on a second stream: auto (small problems) | 0 | 1
+# LayerNorm's parameter gradients (the reduction pass of layernorm_bwd) ride on the weight-gradient lane when there is one (A/B switch)
+_LN_PARAMS_SIDE = os.environ.get("UMR_LN_PARAMS_SIDE", "1") != "0"
 _side_streams = {}
 
 
@@ -932,6 +934,10 @@ class Engine(X3Path):
         g, Nt = gh * gw, gh * gw + 1
         dev = d_center.device
         wg = WgradStream(dev, WgradStream.wanted(B * H * W))
+        # LayerNorm's dgamma / dbeta are weight gradients too: in a chain-of-graphs step their reduction pass leaves the data-gradient chain
+        # for the weight-gradient lane (48 launches of the reference recipe's step; +0.7 %).  Not in the eager two-stream schedule, whose
+        # host is the slower side in backward: a hand-over costs it more than the 4-us kernel costs the GPU.
+        ln_via = wg.run if (wg.staged is not None and _LN_PARAMS_SIDE) else None
 
         def cb(name):
             if join_at_stages:
@@ -1075,7 +1081,7 @@ class Engine(X3Path):
             dln2 = ops.gemm_nt(dhp, self._w(P, b + "mlp.fc1.weight", "lin_t"), None)
             del dhp
             dx1 = ops.layernorm_bwd(dln2, bs["x1"], self._f32(P, b + "norm2.weight"), bs["mean2"], bs["rstd2"],
-                                    G[b + "norm2.weight"], G[b + "norm2.bias"], dres=dx)
+                                    G[b + "norm2.weight"], G[b + "norm2.bias"], dres=dx, params_via=ln_via)
             del dln2
             wgrad_lin(b + "attn.proj.weight", dx1, bs["att"], b + "attn.proj.bias")
             datt = ops.gemm_nt(dx1, self._w(P, b + "attn.proj.weight", "lin_t"), None)
@@ -1085,7 +1091,7 @@ class Engine(X3Path):
             dln1 = ops.gemm_nt(dqkv, self._w(P, b + "attn.qkv.weight", "lin_t"), None)
             del dqkv
             dx = ops.layernorm_bwd(dln1, bs["x"], self._f32(P, b + "norm1.weight"), bs["mean1"], bs["rstd1"],
-                                   G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1)
+                                   G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1, params_via=ln_via)
             del dln1, dx1
             S["blocks"][i] = None
             cb(f"block{i}")

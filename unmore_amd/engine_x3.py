@@ -374,13 +374,17 @@ class X3Path:
 
     # ------------------------------------------------------------------ backward
     def backward_x3(self, P, S, d_center, d_sdf, G, stage_cb=None, join_at_stages=False):
-        from .engine import _ACT, _unpack_conv3_grad, WgradStream
+        from .engine import _ACT, _LN_PARAMS_SIDE, _unpack_conv3_grad, WgradStream
         cfg = self.cfg
         B, H, W, gh, gw = S["B"], S["H"], S["W"], S["gh"], S["gw"]
         D, heads, p = cfg["D"], cfg["heads"], cfg["patch"]
         g, Nt = gh * gw, gh * gw + 1
         dev = d_center.device
         wg = WgradStream(dev, WgradStream.wanted(B * H * W))
+        # LayerNorm's dgamma / dbeta are weight gradients too: in a chain-of-graphs step their reduction pass leaves the data-gradient chain
+        # for the weight-gradient lane (48 launches of the reference recipe's step; +0.7 %).  Not in the eager two-stream schedule, whose
+        # host is the slower side in backward: a hand-over costs it more than the 4-us kernel costs the GPU.
+        ln_via = wg.run if (wg.staged is not None and _LN_PARAMS_SIDE) else None
         mm = lambda *a, **k: self._mm(P, *a, **k)
 
         def cb(name):
@@ -574,7 +578,7 @@ class X3Path:
             dln2 = mm(dhp, b + "mlp.fc1.weight", "lin_t", None).F()
             del dhp, dxx
             dx1 = ops.layernorm_bwd(dln2, bs["x1"], self._f32(P, b + "norm2.weight"), bs["mean2"], bs["rstd2"],
-                                    G[b + "norm2.weight"], G[b + "norm2.bias"], dres=dx)
+                                    G[b + "norm2.weight"], G[b + "norm2.bias"], dres=dx, params_via=ln_via)
             del dln2
             dx1x = XT(f=dx1)
             wgrad_lin(b + "attn.proj.weight", dx1x, bs["att"], b + "attn.proj.bias")
@@ -585,7 +589,7 @@ class X3Path:
             dln1 = mm(dqkv, b + "attn.qkv.weight", "lin_t", None).F()
             del dqkv
             dx = ops.layernorm_bwd(dln1, bs["x"], self._f32(P, b + "norm1.weight"), bs["mean1"], bs["rstd1"],
-                                   G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1)
+                                   G[b + "norm1.weight"], G[b + "norm1.bias"], dres=dx1, params_via=ln_via)
             del dln1, dx1
             S["blocks"][i] = None
             cb(f"block{i}")

@@ -438,12 +438,22 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, planes=False):
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, accumulate=False):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dres=None, accumulate=False, params_via=None):
+    """params_via(fn, *tensors): run the parameter pass (dgamma / dbeta from the row pass's partial sums -- a weight gradient) through
+    the caller's weight-gradient lane (engine.WgradStream.run) instead of behind the row pass on the current stream; the partial sums
+    then live in a buffer of their own (the shared scratch would be rewritten by the next call on this stream)."""
     _need_gpu(dy, x)
     D = x.shape[-1]
     M = x.numel() // D
     dx = torch.empty_like(x)
     need = L.lib().umr_layernorm_bwd_workspace(M, D)
+    if params_via is not None:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        L.check(L.lib().umr_layernorm_bwd_rows(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(ws), ws.numel(), M, D,
+                                               _DT[x.dtype], _stream()), "umr_layernorm_bwd_rows")
+        params_via(lambda: L.check(L.lib().umr_layernorm_bwd_params(_p(ws), ws.numel(), _p(dgamma), _p(dbeta), int(accumulate), M, D, _stream()),
+                                   "umr_layernorm_bwd_params"), ws)
+        return dx
     ws = _workspace(need, x.device)
     L.check(L.lib().umr_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dgamma), _p(dbeta),
                                       int(accumulate), _p(ws), ws.numel(), M, D, _DT[x.dtype], _stream()), "umr_layernorm_bwd")

@@ -793,72 +793,87 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256p_kernel(const umr_gemm_desc
             fetch_bias(it + 1);
             constexpr bool dgelu = (AUXM == 2);   // instantiated as <0, 4, 0> (GELU forward) and <0, 4, 2> (GELU'-masked gradient)
             const bool two_out = !dgelu && p.c2_mode == 2;
-            u32x4 axc[3][4];   // loads run two passes ahead of their use
-            auto load_auxc = [&](auto ptag) {
-                constexpr int PS = decltype(ptag)::value;
-                if (PS < 4 && dgelu) {
+            // Round 5: the fast class's barrier-free form (see there) -- wave-private 2-KiB staging blocks, per-tile buffer descriptors
+            // for C / C2 / the pre-activation, row-contiguous 16-byte chunks.  Before: four passes with 2 (4 with C2) workgroup barriers each.
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+            const bool col_live = n0 + wc * 64 + ec * 8 < p.N;
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((T2*)p.C + (int64_t)m0 * p.ldc + n0), 0, clamp31((int64_t)(m_end - m0) * p.ldc * 2), 0x00020000);
+            const unsigned co_vo = col_live ? co_lane : OOB;
+            __amdgpu_buffer_rsrc_t rsC2 = rsC, rsX = rsC;
+            unsigned c2_vo = OOB, ax_vo = OOB;
+            if (two_out) {
+                rsC2 = __builtin_amdgcn_make_buffer_rsrc((void*)((T2*)p.C2 + (int64_t)m0 * p.ldc2 + n0), 0,
+                                                         clamp31((int64_t)(m_end - m0) * p.ldc2 * 2), 0x00020000);
+                c2_vo = col_live ? ((unsigned)(wr * 128 + er) * (unsigned)p.ldc2 + (unsigned)(wc * 64 + ec * 8)) * 2u : OOB;
+            }
+            if (dgelu) {
+                rsX = __builtin_amdgcn_make_buffer_rsrc((void*)((T2*)p.aux + (int64_t)m0 * p.ldaux + n0), 0,
+                                                        clamp31((int64_t)(m_end - m0) * p.ldaux * 2), 0x00020000);
+                ax_vo = col_live ? ax_lane : OOB;
+            }
+            u32x4 axc[4][2];   // ring over row blocks; loads run two blocks ahead of their use
+            auto load_auxc = [&](auto btag) {
+                constexpr int MB = decltype(btag)::value;
+                if (MB < 8 && dgelu) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                        u32x4 a = {0u, 0u, 0u, 0u};
-                        if (m < m_end && n < p.N) a = *(const u32x4*)((const T2*)p.aux + (int64_t)m * p.ldaux + n);
-                        axc[PS % 3][j] = a;
-                    }
+                    for (int k = 0; k < 2; ++k)
+                        axc[MB & 3][k] = __builtin_amdgcn_raw_buffer_load_b128(rsX, ax_vo + (unsigned)((MB * 16 + k * 8) * p.ldaux * 2), 0, 0);
                 }
             };
             load_auxc(std::integral_constant<int, 0>{});
             load_auxc(std::integral_constant<int, 1>{});
-            char* stb = smem + STG_OFF;
-            auto pass4 = [&](auto ptag) {
-                constexpr int PS = decltype(ptag)::value;
-                load_auxc(std::integral_constant<int, PS + 2>{});
-                auto stage = [&](bool gelu) {
-#pragma unroll
-                    for (int mh = 0; mh < 2; ++mh) {
-                        const int lr = wr * 32 + mh * 16 + frow;
-#pragma unroll
-                        for (int ntl = 0; ntl < 4; ++ntl) {
-                            f32x4 v = acc[PS * 2 + mh][ntl];   // bias included (accumulator start value)
-                            if (gelu) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = gelu_sel<T2>(v[e]);
-                            }
-                            bf16x4 t;
-                            t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
-                            const int c16 = wc * 8 + ntl * 2 + (fq >> 1);
-                            *(bf16x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4) + (fq & 1) * 8) = t;
-                        }
-                    }
-                };
-                auto copy_out = [&](T2* dst, int ld, bool scale) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int lr = (tid >> 5) + j * 16, c16 = tid & 31;
-                        const int m = m0 + (lr >> 5) * 128 + PS * 32 + (lr & 31), n = n0 + c16 * 8;
-                        u32x4 o = *(const u32x4*)(stb + lr * 512 + ((c16 ^ (lr & 15)) << 4));
-                        if (scale) {
-                            const u32x4 a = axc[PS % 3][j];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = mul_dgelu_bf16x2(o[e], a[e]);
-                        }
-                        if (m < m_end && n < p.N) *(u32x4*)(dst + (int64_t)m * ld + n) = o;
-                    }
-                };
-                if (PS > 0) __syncthreads();
-                if (two_out) {   // the pre-activation, as the backward pass wants it
-                    stage(false);
-                    __syncthreads();
-                    copy_out((T2*)p.C2, p.ldc2, false);
-                    __syncthreads();
-                }
-                stage(!dgelu);
-                __syncthreads();
-                copy_out((T2*)p.C, p.ldc, dgelu);
+            char* wst = smem + STG_OFF + w * WST_BYTES;
+            const int wsw = (frow >> 1) & 7;
+            char* wst_w = wst + frow * 128 + (fq & 1) * 8;                       // + (((ntl * 2 + (fq >> 1)) ^ wsw) << 4)
+            const char* wst_r0 = wst + er * 128 + ((ec ^ ((er >> 1) & 7)) << 4);
+            const char* wst_r1 = wst + (er + 8) * 128 + ((ec ^ (((er >> 1) + 4) & 7)) << 4);
+            auto pack4g = [&](const f32x4& v) -> u32x2 {
+                unsigned lo, hi;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(v[0]), "v"(v[1]));
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v[2]), "v"(v[3]));
+                return u32x2{lo, hi};
             };
-            pass4(std::integral_constant<int, 0>{}); pass4(std::integral_constant<int, 1>{});
-            pass4(std::integral_constant<int, 2>{}); pass4(std::integral_constant<int, 3>{});
-            __syncthreads();
+            auto block4 = [&](auto btag) {
+                constexpr int MB = decltype(btag)::value;
+                load_auxc(std::integral_constant<int, MB + 2>{});
+                if (two_out) {   // the pre-activation, as the backward pass wants it
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) *(u32x2*)(wst_w + (((ntl * 2 + (fq >> 1)) ^ wsw) << 4)) = pack4g(acc[MB][ntl]);
+                    asm volatile("" ::: "memory");
+                    const u32x4 o0 = *(const u32x4*)wst_r0, o1 = *(const u32x4*)wst_r1;
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_raw_buffer_store_b128(o0, rsC2, c2_vo + (unsigned)((MB * 16) * p.ldc2 * 2), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o1, rsC2, c2_vo + (unsigned)((MB * 16 + 8) * p.ldc2 * 2), 0, 0);
+                }
+#pragma unroll
+                for (int ntl = 0; ntl < 4; ++ntl) {
+                    f32x4 v = acc[MB][ntl];   // bias included (accumulator start value)
+                    if (!dgelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_sel<T2>(v[e]);
+                    }
+                    *(u32x2*)(wst_w + (((ntl * 2 + (fq >> 1)) ^ wsw) << 4)) = pack4g(v);
+                }
+                asm volatile("" ::: "memory");
+                u32x4 o[2];
+                o[0] = *(const u32x4*)wst_r0;
+                o[1] = *(const u32x4*)wst_r1;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (dgelu) {
+                        const u32x4 a = axc[MB & 3][k];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[k][e] = mul_dgelu_bf16x2(o[k][e], a[e]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o[k], rsC, co_vo + (unsigned)((MB * 16 + k * 8) * p.ldc * 2), 0, 0);
+                }
+            };
+            block4(std::integral_constant<int, 0>{}); block4(std::integral_constant<int, 1>{});
+            block4(std::integral_constant<int, 2>{}); block4(std::integral_constant<int, 3>{});
+            block4(std::integral_constant<int, 4>{}); block4(std::integral_constant<int, 5>{});
+            block4(std::integral_constant<int, 6>{}); block4(std::integral_constant<int, 7>{});
         } else if (EPI == 5 || EPI == 6) {
             // X3 classes: (bias already in the accumulators); f32-staged, 8 passes of 32 rows in a runtime loop (one copy of the
             // store code): the K loop is six times longer than the bf16 kernel's, the epilogue's share is small.

@@ -18,6 +18,7 @@
 // (out-of-range rows read as zeros); only the conv halo masks are recomputed per tile.
 #include "umr_common.h"
 #include "gemm_epilogue.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1157,6 +1158,9 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     const int npairs_x3 = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
     int ksplit = 1;
     if (d->dtype == UMR_BF16X3) x3_plan(d, cus, npairs_x3, ws != nullptr ? ws_bytes : 0, &bm, &ksplit);
+    if (d->dtype == UMR_BF16X3 && getenv("UMR_X3_TRACE"))   // one line per plane launch: shape and plan (tools/probe/x3_shapes.py sums them up)
+        fprintf(stderr, "x3 M=%d N=%d K=%d conv=%d Cin=%d ks=%d bm=%d flags=%u act=%d red=%d\n", d->M, d->N, d->K, d->conv, d->Cin, ksplit, bm,
+                (unsigned)d->flags, d->act, d->red_w != nullptr);
     const int tiles_m = (d->M + bm - 1) / bm;
     const int64_t total = (int64_t)tiles_m * tiles_n;
     // One workgroup fits a CU (160 KiB LDS).  The grid is a small multiple of the CU count, not exactly the CU count: if

@@ -61,6 +61,28 @@ def test_layernorm(dtype, M, D):
     assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("B,N,heads", [(20, 65, 16), (3, 100, 2), (2, 17, 1), (1, 127, 3)])
+def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, monkeypatch):
+    """N < 128 in bf16: dQ and dK / dV workgroups in ONE launch, each taking its rows' -lse and rowsum(dO * O) itself
+    (attn_bwd_small_bf16_kernel) -- against the three launches (prep, dQ, dK / dV; UMR_ATTN_BWD_FUSED=0, read per launch).  The same
+    arithmetic per output except the order of the 64 products in rowsum(dO * O): a last-bit difference there flips the bf16 rounding of
+    a few dS entries, so the outputs agree to a few bf16 roundings, and most of them exactly."""
+    from unmore_amd import ops
+    dev = _dev()
+    D = heads * 64
+    qkv = _rnd((B * N, 3 * D), torch.bfloat16, dev, 11, 1.0)
+    dout = _rnd((B * N, D), torch.bfloat16, dev, 12)
+    out, lse = ops.attention_fwd(qkv, B, N, heads)
+    monkeypatch.setenv("UMR_ATTN_BWD_FUSED", "0")
+    ref = ops.attention_bwd(qkv, out, dout, lse, B, N, heads).float()
+    monkeypatch.setenv("UMR_ATTN_BWD_FUSED", "1")
+    got = ops.attention_bwd(qkv, out, dout, lse, B, N, heads).float()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert float(err.max()) <= 2.0 ** -6 * float(ref.abs().max()), (float(err.max()), float(ref.abs().max()))
+    assert (got != ref).float().mean().item() < 0.05, (got != ref).float().mean().item()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,N,heads", [(2, 65, 2), (1, 577, 3), (3, 100, 1), (2, 17, 2), (1, 1370, 2), (2, 128, 1), (1, 129, 2)])
 def test_attention(dtype, B, N, heads):

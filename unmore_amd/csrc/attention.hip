@@ -142,11 +142,10 @@ template <typename T> __device__ __forceinline__ float fexp(float x) { return si
 // rate, not the matrix pipe's (profiles/r05_attention_xcd_map_ab.txt).  Launched 1-D; id -> (XCD, slot) -> a virtual id such
 // that an XCD owns a contiguous run of virtual ids (bijective for any grid size, as in gemm_nt.hip): the workgroups of a head are
 // neighbours on one XCD, dispatched within a few slots of each other.  gx_arg < 0: the old order (A/B).
-__device__ __forceinline__ void attn_block(int gx_arg, int& bx, int& by) {
-    int bid = blockIdx.x;
+__device__ __forceinline__ void attn_block_of(int bid, int nwg, int gx_arg, int& bx, int& by) {
     int gx = gx_arg;
     if (gx_arg > 0) {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
         bid = base + (bid >> 3);
     } else {
@@ -155,6 +154,7 @@ __device__ __forceinline__ void attn_block(int gx_arg, int& bx, int& by) {
     by = bid / gx;
     bx = bid - by * gx;
 }
+__device__ __forceinline__ void attn_block(int gx_arg, int& bx, int& by) { attn_block_of((int)blockIdx.x, (int)gridDim.x, gx_arg, bx, by); }
 
 // ------------------------------------------------------------------ forward
 template <typename T>
@@ -645,25 +645,25 @@ __global__ void attn_bwd_prep_bf16_kernel(const bf16_t* __restrict__ o, const bf
     }
 }
 
-template <int QB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                               const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
-                                                               int Npad, int heads, int gx_arg) {
+// OWN: the workgroup takes its rows' statistics (-lse * log2 e and rowsum(dO * O)) from `lse`, `dout` and `out` itself instead of
+// from the prep kernel's workspace -- the form of the single-launch backward of short sequences (attn_bwd_small_bf16_kernel)
+template <int QB, bool OWN>
+__device__ __forceinline__ void attn_bwd_dq_bf16_body(char* smem, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                      const bf16_t* __restrict__ out, const float* __restrict__ lse,
+                                                      const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N, int Npad, int heads,
+                                                      int bx_, int bh) {
     constexpr int TK = 64, OPB = TK * 128, STB = 2 * OPB;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    int bx_, bh;
-    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
     const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
     const bf16_t* qb = qkv + (int64_t)b * N * ld + h * HD;
     const bf16_t* kb = qb + D;
     const bf16_t* vb = qb + 2 * D;
-    const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
-    const float* dsum_b = nl2_b + Npad;
+    const float* nl2_b = OWN ? nullptr : ws + (int64_t)(bh * 2) * Npad;
+    const float* dsum_b = OWN ? nullptr : nl2_b + Npad;
     const int q0 = bx_ * (64 * QB) + w * (16 * QB) + li;
     RowFrag<bf16_t> qf[QB], dof[QB];
     float nl2q[QB], d_q[QB];
@@ -673,8 +673,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
         const bool qok = q < N;
         qf[qi] = rowfrag_global<bf16_t>(qok ? qb + (int64_t)q * ld : nullptr, g, 0.125f * 1.4426950408889634f);   // as in the forward kernel
         dof[qi] = rowfrag_global<bf16_t>(qok ? dout + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
-        nl2q[qi] = qok ? nl2_b[q] : 0.f;
-        d_q[qi] = qok ? dsum_b[q] : 0.f;
+        if (OWN) {
+            // the row's 64 products dO * O: 16 in this lane, the rest in the three other lane groups of the row
+            const RowFrag<bf16_t> of = rowfrag_global<bf16_t>(qok ? out + ((int64_t)b * N + q) * D + h * HD : nullptr, g, 1.0f);
+            float ds = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds += (float)dof[qi].v[i][e] * (float)of.v[i][e];
+            ds += __shfl_xor(ds, 16, 64);
+            ds += __shfl_xor(ds, 32, 64);
+            nl2q[qi] = qok ? -lse[(int64_t)bh * N + q] * 1.4426950408889634f : 0.f;
+            d_q[qi] = ds;
+        } else {
+            nl2q[qi] = qok ? nl2_b[q] : 0.f;
+            d_q[qi] = qok ? dsum_b[q] : 0.f;
+        }
     }
     const unsigned rec = (unsigned)(((int64_t)(N - 1) * ld + HD) * 2);
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, rec, 0x00020000);
@@ -777,18 +791,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     }
 }
 
-template <int KB>
-__global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
-                                                                const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
-                                                                int Npad, int heads, int gx_arg) {
+template <int QB>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
+                                                               int Npad, int heads, int gx_arg) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 128];
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    attn_bwd_dq_bf16_body<QB, false>(smem, qkv, dout, nullptr, nullptr, ws, dqkv, N, Npad, heads, bx_, bh);
+}
+
+template <int KB, bool OWN>
+__device__ __forceinline__ void attn_bwd_dkv_bf16_body(char* smem, const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                       const bf16_t* __restrict__ out, const float* __restrict__ lse,
+                                                       const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N, int Npad, int heads,
+                                                       int bx_, int bh) {
     constexpr int TQ = 64, OPB = TQ * 128, STB = 2 * OPB;
-    // [stage][Q | dO][64 rows][128 B], then per stage 1 KiB: 64 x -lse*log2e | 64 x dsum | unused (zero-filled by the DMA)
-    __shared__ __attribute__((aligned(16))) char smem[2 * STB + 2 * 1024];
+    // smem: [stage][Q | dO][64 rows][128 B], then per stage 1 KiB: 64 x -lse*log2e | 64 x dsum | unused (zero-filled by the DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    int bx_, bh;
-    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
     const int b = bh / heads, h = bh - b * heads;
     const int D = heads * HD;
     const int64_t ld = 3 * (int64_t)D;
@@ -796,7 +818,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
     const bf16_t* kb = qb + D;
     const bf16_t* vb = qb + 2 * D;
     const bf16_t* dob = dout + (int64_t)b * N * D + h * HD;
-    const float* nl2_b = ws + (int64_t)(bh * 2) * Npad;
+    const float* nl2_b = OWN ? nullptr : ws + (int64_t)(bh * 2) * Npad;
     const int key0 = bx_ * (64 * KB) + w * (16 * KB) + li;
     RowFrag<bf16_t> kf[KB], vf[KB];
 #pragma unroll
@@ -817,7 +839,43 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
     }
     // the tile's 64 + 64 row statistics ride on the same DMA stream (wave 0, one instruction: lanes 0-15 -lse*log2e,
     // 16-31 dsum, the rest out of range): no VMEM load in the loop has to be waited for behind the next tile's DMA
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)nl2_b, 0, (unsigned)(2 * Npad * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)nl2_b, 0, OWN ? 0u : (unsigned)(2 * Npad * 4), 0x00020000);
+    // OWN: the tile's 64 + 64 row statistics are computed here, one tile ahead like the DMA: thread t takes a quarter (16 values) of row
+    // t / 4 of dO and O straight from global memory (loads issued BEFORE the tile's DMA, so that their wait does not drain it), the four
+    // quarters are summed by shuffles, and the results go to the stage's statistics block after the tile's matrix work
+    const bf16_t* ob = OWN ? out + (int64_t)b * N * D + h * HD : nullptr;
+    bf16x8 so_d[2], so_o[2];
+    float so_l = 0.f;
+    auto stats_load = [&](int j) {
+        const int r = j * TQ + (tid >> 2), c = tid & 3;
+        const bool ok = r < N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bf16x8 zd, zo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { zd[e] = (bf16_t)0.f; zo[e] = (bf16_t)0.f; }
+            if (ok) {
+                zd = *(const bf16x8*)(dob + (int64_t)r * D + c * 16 + i * 8);
+                zo = *(const bf16x8*)(ob + (int64_t)r * D + c * 16 + i * 8);
+            }
+            so_d[i] = zd; so_o[i] = zo;
+        }
+        so_l = (ok && c == 0) ? lse[(int64_t)bh * N + r] : 0.f;
+    };
+    auto stats_store = [&](int j) {
+        float ds = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ds += (float)so_d[i][e] * (float)so_o[i][e];
+        ds += __shfl_xor(ds, 1, 64);
+        ds += __shfl_xor(ds, 2, 64);
+        if ((tid & 3) == 0) {
+            float* st = (float*)(smem + 2 * STB + (j & 1) * 1024);
+            st[tid >> 2] = -so_l * 1.4426950408889634f;
+            st[64 + (tid >> 2)] = ds;
+        }
+    };
     const unsigned voffs = lane < 16 ? (unsigned)(lane * 16) : lane < 32 ? (unsigned)(Npad * 4 + (lane - 16) * 16) : 0x80000000u;
     const unsigned strq = (unsigned)(TQ * (int)ld * 2), stro = (unsigned)(TQ * D * 2);
     auto issue_tile = [&](int j) {
@@ -826,7 +884,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, UMR_LDS_PTR(dst + 1024), 16, voffq[1], (unsigned)j * strq, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, UMR_LDS_PTR(dst + OPB), 16, voffo[0], (unsigned)j * stro, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsO, UMR_LDS_PTR(dst + OPB + 1024), 16, voffo[1], (unsigned)j * stro, 0, 0);
-        if (w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, UMR_LDS_PTR(smem + 2 * STB + (j & 1) * 1024), 16, voffs, (unsigned)j * 256u, 0, 0);
+        if (!OWN && w == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, UMR_LDS_PTR(smem + 2 * STB + (j & 1) * 1024), 16, voffs, (unsigned)j * 256u, 0, 0);
     };
     const int swk = kswz<bf16_t>(li);
     const char* rad0 = smem + li * 128 + (((0 + g) ^ swk) << 4);
@@ -845,10 +903,13 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
         for (int i = 0; i < 4; ++i) { accK[ki][i] = f32x4{0.f, 0.f, 0.f, 0.f}; accV[ki][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     constexpr float LOG2E = 1.4426950408889634f;
     const int ntiles = (N + TQ - 1) / TQ;
+    if (OWN) { stats_load(0); stats_store(0); }
     issue_tile(0);
     for (int j = 0; j < ntiles; ++j) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (OWN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the statistics block was written with ds_write)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (OWN && j + 1 < ntiles) stats_load(j + 1);
         if (j + 1 < ntiles) issue_tile(j + 1);
         const int sb = (j & 1) * STB;
 #pragma unroll
@@ -923,6 +984,7 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
                     accK[ki][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), dsb[ki], accK[ki][dt], 0, 0, 0);
             }
         }
+        if (OWN && j + 1 < ntiles) stats_store(j + 1);
     }
 #pragma unroll
     for (int ki = 0; ki < KB; ++ki) {
@@ -937,6 +999,33 @@ __global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16
             }
         }
     }
+}
+
+template <int KB>
+__global__ __launch_bounds__(256, UMR_ATTN_DKV_MIN_WAVES) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ ws, bf16_t* __restrict__ dqkv, int N,
+                                                                int Npad, int heads, int gx_arg) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 128 + 2 * 1024];
+    int bx_, bh;
+    attn_block(gx_arg, bx_, bh);   // XCD-aware: the workgroups of one (batch, head) share an XCD's L2
+    attn_bwd_dkv_bf16_body<KB, false>(smem, qkv, dout, nullptr, nullptr, ws, dqkv, N, Npad, heads, bx_, bh);
+}
+
+// Backward of SHORT sequences in one launch (the reference recipe: 65 tokens per crop, 320 (batch, head) pairs; three launches of 7-16 us
+// each were launch boundaries more than work): workgroups [0, half) are the dQ workgroups, [half, 2 half) the dK / dV workgroups, each
+// with the XCD-aware map over its own half; both take their rows' statistics themselves (OWN), so there is no prep launch and no
+// workspace.  Same arithmetic per output as the three-launch form except the order of the 64 products in rowsum(dO * O).
+__global__ __launch_bounds__(256) void attn_bwd_small_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
+                                                                  const bf16_t* __restrict__ out, const float* __restrict__ lse,
+                                                                  bf16_t* __restrict__ dqkv, int N, int heads, int gx_arg, int half) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 64 * 128 + 2 * 1024];
+    int bid = (int)blockIdx.x;
+    const bool dkv = bid >= half;     // (workgroup-uniform)
+    if (dkv) bid -= half;
+    int bx_, bh;
+    attn_block_of(bid, half, gx_arg, bx_, bh);
+    if (dkv) attn_bwd_dkv_bf16_body<1, true>(smem, qkv, dout, out, lse, nullptr, dqkv, N, 0, heads, bx_, bh);
+    else attn_bwd_dq_bf16_body<1, true>(smem, qkv, dout, out, lse, nullptr, dqkv, N, 0, heads, bx_, bh);
 }
 
 // ------------------------------------------------------------------ backward: dQ
@@ -1107,7 +1196,15 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
     const int a1 = xcd_map ? gx1 : -gx1, a2 = xcd_map ? gx2 : -gx2;
     dim3 gp((unsigned)((total + 255) / 256)), g((unsigned)(gx1 * B * heads)), b(256);
     static const int fast_bwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernels for bf16 too (A/B)
-    if (dtype == UMR_BF16 && fast_bwd) {
+    // short sequences: one launch (dQ and dK / dV workgroups side by side, no prep pass).  UMR_ATTN_BWD_FUSED=0: the three launches (A/B;
+    // read per launch)
+    const char* fe = getenv("UMR_ATTN_BWD_FUSED");
+    if (dtype == UMR_BF16 && fast_bwd && N < 128 && !(fe && fe[0] == '0')) {
+        const int half = gx1 * B * heads;
+        UMR_CHECK_ARG(2ll * half < (1ll << 31), "attention_bwd: grid too large");
+        hipLaunchKernelGGL(attn_bwd_small_bf16_kernel, dim3((unsigned)(2 * half)), b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)out,
+                           lse, (bf16_t*)dqkv, N, heads, a1, half);
+    } else if (dtype == UMR_BF16 && fast_bwd) {
         const int Npad = (N + 63) / 64 * 64;
         const int64_t tp = (int64_t)B * heads * Npad * 8;
         hipLaunchKernelGGL(attn_bwd_prep_bf16_kernel, dim3((unsigned)((tp + 255) / 256)), b, 0, s, (const bf16_t*)out, (const bf16_t*)dout, lse,

@@ -442,6 +442,12 @@ def test_permute4_batched_equals_single_launches():
     record(lambda: engine._pack_linear_t(wl, torch.bfloat16))
     record(lambda: engine._pack_linear_t(wl[:, :768], torch.bfloat16))       # row-strided slice (the readout projection halves)
     record(lambda: engine._pack_linear_t(wl[:, 768:], torch.float32))
+    # the 16-byte form of the 64x64 transpose (R % 4 == 0, C % 8 == 0, aligned): full tiles and ragged edges in both directions
+    for n_, k_ in ((1024, 4096), (200, 1000), (72, 260), (3072, 768)):
+        wv = torch.randn((n_, k_), generator=g).to(dev)
+        record(lambda: engine._pack_linear_t(wv, torch.bfloat16))
+    big8 = torch.randn(8192 * 5 + 2048 * 3, generator=g).to(dev)      # whole 8192-element blocks of a cast + a tail of whole 2048-runs
+    record(lambda: ops.cast(big8, torch.bfloat16))
     wt = torch.randn((96, 96, 4, 4), generator=g).to(dev)
     record(lambda: engine._pack_convT(wt, torch.bfloat16))
     record(lambda: engine._pack_convT_dgrad(wt, torch.bfloat16))

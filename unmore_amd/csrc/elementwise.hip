@@ -432,6 +432,21 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         // a plain cast (the Linear weights: most of the bytes): 16-byte loads
         const bool vec = e.d[0] == 1 && e.d[1] == 1 && e.d[2] == 1 && e.sstride[3] == 1 && e.dtype_in == UMR_F32 && (e.soff & 3) == 0 &&
                          (((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0;
+        if (vec && e.dtype_out == UMR_BF16 && (lb * 4 + 4) * 2048 <= total) {
+            // a whole block of a cast to bf16 (most of a refresh's bytes): all eight 16-byte loads in flight before the first store
+            // (the loop below waits for each repetition's two loads in turn: four memory round trips per block)
+            const float* sp = (const float*)e.src + e.soff + lb * 8192;
+            bf16_t* dp = (bf16_t*)e.dst + lb * 8192;
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(sp + (j * 256 + threadIdx.x) * 4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16x4 t = {(bf16_t)v[j][0], (bf16_t)v[j][1], (bf16_t)v[j][2], (bf16_t)v[j][3]};
+                *(bf16x4*)(dp + (j * 256 + threadIdx.x) * 4) = t;
+            }
+            return;
+        }
 #pragma unroll 1
         for (int rep = 0; rep < 4; ++rep) {      // 4 x 2048 consecutive destination elements per block
             const int64_t base = (lb * 4 + rep) * 2048;
@@ -484,8 +499,39 @@ __global__ __launch_bounds__(256) void permute4_batched_kernel(const PermEntry* 
         // tiles, shifts instead of the generic tile's run-time divisions (three per element, twice), 16 loads in flight per
         // thread.  dst[r][c] = src[soff + r * sstride[2] + c * sstride[3]], sstride[2] == 1: reads run along r, writes along c.
         const int R = e.d[2], C = e.d[3];
-        const int ntc = (C + 63) >> 6;
-        const int r0 = (int)(lb / ntc) << 6, c0 = (int)(lb % ntc) << 6;
+        // r (the source's contiguous direction) fastest: neighbouring blocks read adjacent 256-byte pieces of the same 64 source rows
+        const int ntr = (R + 63) >> 6;
+        const int r0 = (int)(lb % ntr) << 6, c0 = (int)(lb / ntr) << 6;
+        // f32 -> bf16 with 16-byte accesses on both sides: four f32x4 loads per thread along r, the tile transposed through LDS, two
+        // 8 x bf16 stores per thread along c (the scalar form below moves 4-byte loads and 2-byte stores)
+        if (e.dtype_in == UMR_F32 && e.dtype_out == UMR_BF16 && (R & 3) == 0 && (C & 7) == 0 && (e.sstride[3] & 3) == 0 && (e.soff & 3) == 0 &&
+            (((uintptr_t)e.src | (uintptr_t)e.dst) & 15) == 0) {
+            const int t = threadIdx.x;
+            f32x4 v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = c0 + k * 16 + (t >> 4), rr = r0 + (t & 15) * 4;
+                v4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (cc < C && rr < R) v4[k] = *(const f32x4*)((const float*)e.src + e.soff + (int64_t)rr + (int64_t)cc * e.sstride[3]);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[(k * 16 + (t >> 4)) * 65 + (t & 15) * 4 + j] = v4[k][j];     // tile[c local][r local]
+            __syncthreads();
+            const int rl = t >> 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cl = (t & 3) * 8 + h * 32;
+                if (r0 + rl < R && c0 + cl < C) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)tile[(cl + j) * 65 + rl];
+                    *(bf16x8*)((bf16_t*)e.dst + (int64_t)(r0 + rl) * C + c0 + cl) = o;
+                }
+            }
+            return;
+        }
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
         float v[16];
 #pragma unroll

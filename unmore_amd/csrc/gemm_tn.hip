@@ -441,7 +441,18 @@ TnPlan tn_plan(const umr_gemm_tn_desc* d) {
     const int rows = d->dtype == UMR_BF16 ? 64 : 32;
     // 256 CUs x 2 resident workgroups = 512 slots: aim just under 8 full rounds so the last round is full
     int64_t want = 4096 / tiles;
-    const int64_t max_by_rows = ((int64_t)d->M + rows * 8 - 1) / (rows * 8);  // >= 8 stages per split
+    int64_t max_by_rows = ((int64_t)d->M + rows * 8 - 1) / (rows * 8);  // >= 8 stages per split
+    // Short reductions (M <= 4096: the reference recipe's 1300 tokens): about ONE workgroup per CU in all, splits of >= 4 stages.  The
+    // weight-gradient lane of that step is bound by its traffic and by the chip it shares with the data-gradient chain, not by one
+    // launch's latency: three splits of every weight (the rule above) wrote and re-read 8 GB of slabs per step; with ~256 workgroups
+    // per launch the 192- and 256-tile weights take one split (and no reduce pass, below), the 64-tile ones four
+    // (same box: 922.5 -> 945 images/s; UMR_TN_PLAN=<workgroups> to try another target, =-1 the old rule)
+    static const int plan_env = [] { const char* e = getenv("UMR_TN_PLAN"); return e ? atoi(e) : 0; }();
+    if (plan_env >= 0 && d->M <= 4096) {
+        const int target = plan_env > 0 ? plan_env : 256;
+        want = (target + tiles / 2) / tiles;
+        max_by_rows = ((int64_t)d->M + rows * 4 - 1) / (rows * 4);
+    }
     if (want > max_by_rows) want = max_by_rows;
     if (want < 1) want = 1;
     if (want > 4096) want = 4096;
@@ -500,6 +511,9 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     float* slab = (float*)d->workspace;
     float* bslab = slab + (int64_t)pl.splits * d->N * d->K;
+    // one split of the 128x128 kernel, nothing to add to: its "slab" IS dW (and its bias partials dbias) -- no reduce pass
+    const bool direct = !pl.big && pl.splits == 1 && !d->accumulate && d->lddw == d->K;
+    if (direct) { slab = d->dW; bslab = d->dbias; }
     if (pl.big) {
         const int st = umr_launch_gemm_tn256(d, pl.splits, pl.rows_per_split, slab, bslab, s);
         if (st != UMR_OK) return st;
@@ -519,6 +533,7 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
 #undef LAUNCH
     UMR_LAUNCH_CHECK();
     }
+    if (direct) return UMR_OK;
     const int64_t total = (int64_t)d->N * d->K;
     const bool v4 = (d->K % 4 == 0) && (d->lddw % 4 == 0) && (((uintptr_t)d->dW & 15) == 0);
     int rb = (int)((total / (v4 ? 4 : 1) + 255) / 256);

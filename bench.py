@@ -42,7 +42,11 @@ WORKLOADS = {
     "ref": dict(kind="train", backbone="dpt_large", H=128, W=128, batch=20, name="ObjectnessNet ViT-L/16 (dpt_large) 128x128 bf16 batch=20 train (the reference's recipe)"),
     "tiny": dict(kind="train", backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
 }
-SWEEP_CHECK = (600, 620)   # cfg5: the proposals whose peaks the CPU oracle re-derives (20 of 1225: anchors of the 64-pixel grid)
+SWEEP_CHECK = (600, 620)   # cfg5: the proposals the CPU oracle is TIMED on (20 of 1225: a bounded sample)
+# cfg5: the proposals whose peak indices the CPU oracle re-derives (untimed): every sixth anchor of the 32-pixel grid (proposals
+# 0..899) and every anchor of the 64 / 128 / 256 / 512-pixel grids plus the whole image (900..1224, object_reasoning.py:109-137)
+# -- each anchor scale and shape is covered
+SWEEP_CHECK_IDX = sorted(set(range(0, 900, 6)) | set(range(900, 1140, 3)) | set(range(1140, 1225)))
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -180,20 +184,35 @@ def cpu_baseline(wl, hip_peaks=None):
     extra = {}
     if kind == "sweep" and hip_peaks is not None:
         # configs[4]: "peak-picking bit-exact vs CPU" -- the flat argmax of every checked proposal, HIP fp32 sweep vs this CPU
-        # oracle on the same crops; `certified` = proposals whose CPU argmax is provably stable against any field perturbation
-        # below 2e-4 (oracle.peak_certificate): a mismatch there would be a real error, elsewhere it is a near-tie
-        out = kept["out"]
-        amax, arg, cert = orc.peak_certificate(out["sdf_maps"][:, 0].contiguous(), out["center_fields"].contiguous(), 2e-4)
+        # oracle on the same crops (untimed pass over SWEEP_CHECK_IDX: every anchor scale); `certified` = proposals whose CPU argmax
+        # is provably stable against any field perturbation below 2e-4 (oracle.peak_certificate): a mismatch there would be a real
+        # error, elsewhere it is a near-tie
         h_amax, h_arg = hip_peaks
-        has_peak = amax > 0
-        mism = [(int(a) != int(b)) for a, b in zip(arg.tolist(), h_arg.tolist())]
+        all_props = torch.from_numpy(anchors(Hi, Wi))
+        idx = SWEEP_CHECK_IDX
+        n_peak_cpu = n_cert = n_mism = n_mism_cert = 0
+        worst_amax = 0.0
+        print(f"[bench] cpu_baseline: re-deriving the peaks of {len(idx)} proposals on the CPU oracle (untimed) ...", file=sys.stderr, flush=True)
+        for i in range(0, len(idx), 50):
+            sel = idx[i:i + 50]
+            with torch.no_grad():
+                crops = orc.crop_resize(image, all_props[sel], 128)
+                out = orc.forward(sd, crops, cfg)
+            amax, arg, cert = orc.peak_certificate(out["sdf_maps"][:, 0].contiguous(), out["center_fields"].contiguous(), 2e-4, certify_empty=True)
+            for j, k in enumerate(sel):
+                mism = int(arg[j]) != int(h_arg[k])
+                n_peak_cpu += int(float(amax[j]) > 0)
+                n_cert += int(bool(cert[j]))
+                n_mism += int(mism)
+                n_mism_cert += int(mism and bool(cert[j]))
+                worst_amax = max(worst_amax, abs(float(amax[j]) - float(h_amax[k])))
         extra["peak_check"] = {
-            "proposals_checked": int(arg.numel()), "proposal_range": list(SWEEP_CHECK),
-            "maps_with_peak_cpu": int(has_peak.sum()), "maps_with_peak_hip": int((h_amax > 0).sum()),
-            "peak_index_mismatches": int(sum(mism)), "certified": int(cert.sum()),
-            "mismatches_among_certified": int(sum(m for m, c in zip(mism, cert.tolist()) if c)),
-            "max_abs_amax_difference": float((amax - h_amax).abs().max()),
-            "note": "flat argmax of the eroded anti-centre score map per proposal, HIP fp32 sweep vs the CPU oracle (torch fp32) on the same crops"}
+            "proposals_checked": len(idx), "proposal_set": "every 6th anchor of the 32-px grid, every 3rd of the 64-px grid, every anchor of the 128 / 256 / 512-px grids and the whole image",
+            "maps_with_peak_cpu": n_peak_cpu, "maps_with_peak_hip": int((h_amax[idx] > 0).sum()),
+            "peak_index_mismatches": n_mism, "certified": n_cert, "mismatches_among_certified": n_mism_cert,
+            "max_abs_amax_difference": worst_amax,
+            "note": "flat argmax of the eroded anti-centre score map per proposal, the headline HIP fp32 sweep vs the CPU oracle (torch fp32) on the same crops; "
+                    "certified = the oracle's argmax is provably stable under any field perturbation < 2e-4 (maps without a positive score included)"}
     return {**extra, "value": per_iter / med, "unit": "images/sec", "cores": cores, "cpu_model": model, "kind": "port",
             "sample": f"median of {n} timed iterations after 2 warm-ups, each = {what}; fp32, torch CPU, {cores} threads; "
                       f"median {med:.2f} s/iteration"}
@@ -363,6 +382,9 @@ def run_rank(a):
             dist.init_process_group("gloo")
             coll = {"backend": "gloo", "world": dist.get_world_size()}
 
+    if world > 1:
+        coll["gradient_wire"] = a.dp_wire
+
     def barrier():
         if world > 1:
             if a.backend == "nccl" and dev.type == "cuda":
@@ -417,7 +439,8 @@ def run_rank(a):
     if kind == "train":
         net.train()
         step = TrainStep(net, lr=1e-4, center_field_loss_type="l2", sdf_loss_type="l1", use_sdf_gradient_loss=True,
-                         use_sdf_binary_mask_loss=True, lr_milestones=(10000, 20000), lr_gamma=0.1)
+                         use_sdf_binary_mask_loss=True, lr_milestones=(10000, 20000), lr_gamma=0.1,
+                         grad_wire_dtype=(torch.bfloat16 if a.dp_wire == "bf16" else None))
         img, cf, sdf, sal = (torch.from_numpy(x).to(dev) for x in synth.make_batch(B, H, W, seed=rank))
         last = [None]
 
@@ -455,7 +478,11 @@ def run_rank(a):
         def one():
             image = images[counter[0] % n_img]
             counter[0] += 1
-            peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams)
+            inf = {}
+            peaks[0], peaks[1], _ = reasoning.sweep_proposals(net, image, props, 50, n_streams=a.sweep_streams, precision=a.sweep_precision, info=inf)
+            sweep_stats[0] += inf.get("proposals", 0)
+            sweep_stats[1] += inf.get("rerun", 0) or 0
+        sweep_stats = [0, 0]
         units_per_step = 1
 
     # HIP-graph replay (unmore_amd/graphs.py): 'auto' captures the small workloads -- inference calls (cfg1 / cfg5) as one graph, train
@@ -469,7 +496,10 @@ def run_rank(a):
         net.set_graph_mode(a.graphs)
     pixels = (50 if kind == "sweep" else B) * H * W
     from unmore_amd.engine import WgradStream
-    graphed = world == 1 and graphs.wanted(a.graphs, pixels, train=(kind == "train"), two_streams=WgradStream.wanted(pixels))
+    # (data-parallel train steps replay too where the chain-of-graphs form applies -- trainer.TrainStep: the collectives are issued between
+    # the chain's graph launches; inference sweeps with world > 1 are replicas and replay as at world 1)
+    graphed = ((world == 1 or kind != "train" or (graphs.STAGED and WgradStream.wanted(pixels)))
+               and graphs.wanted(a.graphs, pixels, train=(kind == "train"), two_streams=WgradStream.wanted(pixels)))
     warm = a.warmup + (graphs.WARMUP_CALLS + 1 if graphed and kind != "sweep" else 0)   # two eager calls + the capturing call, untimed
     for _ in range(warm):
         one()
@@ -561,8 +591,8 @@ def run_rank(a):
                           if graphed else {"mode": a.graphs, "replayed": False}),
             "roofline": {"bound": "mfma",
                          "kernel": ("umr_gemm_nt implicit-GEMM conv3x3 512->512 of the heads ("
-                                    + ("per step: 2 forward launches + the centre head's ReLU-masked data gradient; the boundary-distance head's "
-                                       "backward is algebraic and the weight gradient is the TN kernel" if kind == "train" else "forward: the centre head's launch of every batch; the boundary-distance head runs collapsed")
+                                    + ("per step: the centre head's forward launch + its ReLU-masked data gradient (+ the boundary-distance head's forward launch "
+                                       "in 'factored' mode); the boundary-distance head is algebraic and the weight gradient is the TN kernel" if kind == "train" else "forward: the centre head's launch of every batch; the boundary-distance head runs collapsed")
                                     + (") bf16" if a.dtype == "bf16" else (") fp32-grade: f32 values as three bf16 planes, six bf16 MFMA products per "
                                                                           "f32 product; peak = 2500 / 6" if x3 else ") f32 MFMA"))),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -577,6 +607,16 @@ def run_rank(a):
             # boundary-distance head's data- and weight-gradient GEMMs (2 x its forward) are not run
             head_fwd_gflop = 2.0 * H * W * (256 * 512 + 9 * 512 * 512 + 512 * 1024 + 1024) / 1e9
             skipped = 2.0 * head_fwd_gflop if net._engine().linear_head_backward == "algebraic" and not net._layouts[1]["relu"] and net._layouts[1]["final"] != "sine" else 0.0
+            sdf_collapsed = net._engine()._collapse(net._layouts[1], True)
+            if sdf_collapsed:
+                # the default since round 6: the head's forward is its collapsed form too -- a 16-column tap GEMM
+                # on the map before the final resize -- so its four convolutions are not executed in forward either
+                skipped += head_fwd_gflop - 2.0 * (H / 2) * (W / 2) * 256 * 16 / 1e9
+            res["sdf_head"] = ("training default 'auto': the boundary-distance head (no non-linearity before its tanh, objectness_net.py:128-135) has an "
+                               "algebraic backward that reads its output only, so its forward is evaluated as one 3x3 conv 256 -> 1 on the map "
+                               "before the final resize (weights stay factored; tests/test_collapsed_train_gpu.py); the four-convolution "
+                               "forward is the 'alt_factored_sdf_head' leg" if sdf_collapsed else
+                               "the boundary-distance head's forward runs its four convolutions (set_sdf_head_mode('factored') or a GEMM backward)")
             from unmore_amd import engine as _eng
             if _eng._COMMUTE_RESIZE:
                 # 1x1 layers that run BEFORE the x2 resize that precedes them in the reference (engine._COMMUTE_RESIZE): a quarter of
@@ -604,6 +644,14 @@ def run_rank(a):
                                            "streams run beside it, so `achieved` is a lower bound of the kernel alone (--sweep-streams 1)")
             res["maps_with_peak"] = int((peaks[0] > 0).sum().item())
             res["config"]["streams"] = a.sweep_streams
+            certified_mode = a.dtype == "fp32" and a.sweep_precision == "certified" and ops.get_f32_mode() == "x3"
+            res["sweep_precision"] = ({"mode": "certified", "rerun_fraction": sweep_stats[1] / max(sweep_stats[0], 1),
+                                       "note": "pass 1: every proposal with three-term fp32 products (maps within ~4e-5 of the six-term ones) + the device-side "
+                                               "argmax certificate at eps = 2e-4 (csrc/reasoning.hip::center_peaks_cert_kernel); pass 2: the uncertified "
+                                               "proposals again with six-term products; rerun_fraction = their share over all sweeps of this run "
+                                               "(warm-up included).  Peak indices equal the full six-term sweep's on every proposal "
+                                               "(alt_fp32_full_precision.peak_index_differs_from_headline; tests/test_certified_sweep_gpu.py)"}
+                                      if certified_mode else {"mode": "full"})
         hip_peaks = None
         if kind == "sweep":
             res["maps_with_peak_share"] = res["maps_with_peak"] / wl["proposals"]
@@ -618,11 +666,24 @@ def run_rank(a):
                 return (time.perf_counter() - t1) / n
             if a.dtype == "fp32":
                 # the peaks the CPU leg re-derives: image 0, proposals SWEEP_CHECK, in the headline (fp32 parity) mode
-                mx0, am0, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams)
-                lo, hi = SWEEP_CHECK
-                hip_peaks = (mx0[lo:hi].cpu(), am0[lo:hi].cpu())
+                mx0, am0, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams, precision=a.sweep_precision)
+                hip_peaks = (mx0.cpu(), am0.cpu())
+                if a.sweep_precision == "certified":
+                    # beside the headline: EVERY proposal with six-term products (the headline of rounds 2-5), and its peak indices
+                    saved = a.sweep_precision
+                    a.sweep_precision = "full"
+                    try:
+                        dt6 = timed_sweeps(2)
+                        mx6, am6, _ = reasoning.sweep_proposals(net, images[0], props, 50, n_streams=a.sweep_streams, precision="full")
+                    finally:
+                        a.sweep_precision = saved
+                    res["alt_fp32_full_precision"] = {"value": 1.0 / dt6, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt6,
+                                                      "peak_index_differs_from_headline": int((am6 != am0).sum().item()),
+                                                      "max_abs_amax_difference_vs_headline": float((mx6 - mx0).abs().max().item()),
+                                                      "note": "sweep_proposals(precision='full'): six-term fp32-grade products for every proposal, no certificate"}
                 # beside the headline, never `value`: the opt-in three-term plane products (UMR_F32_X3_FAST: products to 2^-16, half
                 # the matrix work) with what they cost in the maps and in the peak indices, measured on the same image
+                saved_prec, a.sweep_precision = a.sweep_precision, "full"     # the legs below time ONE arithmetic mode each
                 ops.set_f32_mode("x3_fast")
                 try:
                     dtf = timed_sweeps(2)
@@ -669,6 +730,7 @@ def run_rank(a):
                 res["alt_bf16_factored_sdf_head"] = {"value": 1.0 / dt3, "unit": "images/sec", "crops_per_sec": wl["proposals"] / dt3,
                                                      "note": "bf16 with set_sdf_head_mode('factored')"}
                 net.set_compute_dtype(dt)
+                a.sweep_precision = saved_prec
             else:
                 net.set_compute_dtype(torch.float32)
                 dt2 = timed_sweeps(1)
@@ -693,39 +755,31 @@ def run_rank(a):
             res["alt_factored_sdf_head"] = {"value": B / dtf, "unit": "images/sec", "ms_per_step": 1e3 * dtf,
                                             "note": "set_sdf_head_mode('factored'): the head's four convolutions as the reference runs them"}
         if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
-            # outside the timed region, reported BESIDE the headline (never as `value`): the same step with the opt-in
-            # algebraic form of the linear boundary-distance head (identical function and gradients
-            # up to rounding, tests/test_train_gpu.py::test_collapsed_sdf_head_equals_factored)
+            # outside the timed region, reported BESIDE the headline: the same step with the boundary-distance head in its other forms
+            # (identical function and gradients up to rounding, tests/test_train_gpu.py::
+            # test_collapsed_sdf_head_equals_factored, tests/test_collapsed_train_gpu.py)
             del step
-            # (1) the boundary-distance head's backward as layer-by-layer GEMMs (the round-1 form) instead of the exact algebraic
-            #     one the headline uses: same forward, same gradients up to rounding
+
+            def alt_leg(note):
+                st = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
+                for _ in range(2):
+                    st.step(img, cf, sdf, sal)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    st.step(img, cf, sdf, sal)
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t1) / 3
+                return {"value": B / d, "unit": "images/sec", "ms_per_step": 1e3 * d, "note": note}
+            # (1) the head's forward as the reference's four convolutions (rounds 2-5's headline form; backward algebraic as in `value`)
+            net.set_sdf_head_mode("factored")
+            res["alt_factored_sdf_head"] = alt_leg("set_sdf_head_mode('factored'): the head's four convolutions in forward as the reference runs them "
+                                                   "(their 512/512/1024-channel maps are not read by the algebraic backward); the headline of rounds 2-5")
+            # (2) and its backward as layer-by-layer GEMMs too (the round-1 form)
             net.set_linear_head_backward("gemm")
-            step1 = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
-            for _ in range(2):
-                step1.step(img, cf, sdf, sal)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                step1.step(img, cf, sdf, sal)
-            torch.cuda.synchronize()
-            dt1 = (time.perf_counter() - t1) / 3
-            res["alt_gemm_backward_sdf_head"] = {"value": B / dt1, "unit": "images/sec", "ms_per_step": 1e3 * dt1,
-                                                 "note": "boundary-distance head backward as layer-by-layer GEMMs (A/B of the default algebraic backward)"}
-            del step1
+            res["alt_gemm_backward_sdf_head"] = alt_leg("factored forward + boundary-distance head backward as layer-by-layer GEMMs (the reference's own schedule of operations)")
             net.set_linear_head_backward("algebraic")
-            # (2) the opt-in collapsed FORWARD of the same head
-            net.set_sdf_head_mode("collapsed")
-            step2 = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1)
-            for _ in range(2):
-                step2.step(img, cf, sdf, sal)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                step2.step(img, cf, sdf, sal)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / 3
-            res["alt_collapsed_sdf_head"] = {"value": B / dt2, "unit": "images/sec", "ms_per_step": 1e3 * dt2,
-                                             "note": "opt-in algebraic fast path; not the headline configuration"}
+            net.set_sdf_head_mode("auto")
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, hip_peaks)
         print(json.dumps(res), flush=True)
@@ -749,7 +803,8 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_rank
     _, bounds, _ = flat_layout(ObjectnessNet("cpu", wl["H"], wl["backbone"], Namespace(use_bg_sdf=True, sdf_activation="tanh")))
     n, nb = bounds[-1], len(bounds) - 1
     flat = torch.full((n,), float(rank + 1))
-    comm = BucketedAllReduce(flat, bounds)
+    wire = a.dp_wire == "bf16"
+    comm = BucketedAllReduce(flat, bounds, wire_dtype=(torch.bfloat16 if wire else None))
     for _ in range(a.warmup):
         for k in range(nb):
             comm.ready(k)
@@ -764,8 +819,12 @@ def rehearse(a, wl, world, rank, coll, barrier, max_over_ranks, gather_over_rank
     barrier()
     own = gather_over_ranks(time.perf_counter() - t0)
     elapsed = max_over_ranks(own[rank] if world > 1 else own[0])
-    expect = float(sum(range(1, world + 1))) * (world ** (a.steps - 1))
-    ok = bool(torch.all(flat == expect)) and scale == 1.0 / world
+    if wire:     # the bf16 wire exchanges means (1/world before the rounding): (world + 1) / 2 after the first step and ever after -- exact in bf16
+        expect = (world + 1) / 2.0
+        ok = bool(torch.all(flat == expect)) and scale == 1.0
+    else:
+        expect = float(sum(range(1, world + 1))) * (world ** (a.steps - 1))
+        ok = bool(torch.all(flat == expect)) and scale == 1.0 / world
     if rank == 0:
         print(json.dumps({"rehearsal": True, "metric": "distributed plumbing only (no model)", "value": None, "n_gpus": world, "steps": a.steps,
                           "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "collective": coll, "allreduce_elements": n, "allreduce_buckets": nb,
@@ -789,14 +848,20 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI; gloo = rehearsal transport (ranks may share a GPU)")
     ap.add_argument("--rehearse", action="store_true", help="CPU-only: run the multi-process plumbing without the model")
     ap.add_argument("--sweep-streams", type=int, default=3, help="cfg5: HIP streams the independent 50-crop batches are dealt to")
+    ap.add_argument("--sweep-precision", default="certified", choices=["certified", "full"],
+                    help="cfg5, fp32: 'certified' (default) = three-term products + device-side argmax certificate, six-term re-run of the "
+                         "uncertified proposals (unmore_amd/reasoning.py::sweep_proposals); 'full' = six-term products for every proposal")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="plain --gpus N launch: overall deadline in seconds, counted from the launch")
     ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)   # launcher test hook
     ap.add_argument("--graphs", default="auto", choices=["auto", "on", "off"],
                     help="HIP-graph replay: auto = small inference workloads only (B*H*W <= 2^20 pixels), on = also train steps")
+    ap.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"],
+                    help="data-parallel gradient exchange: f32 buckets as they are (default) or bf16 copies (half the bytes per link; "
+                         "unmore_amd/parallel.py, DESIGN.md section 6)")
     ap.add_argument("--cu-budget", type=int, default=0,
                     help="CUs the persistent GEMM grids occupy (umr_set_cu_budget; 0 = all): leaves the rest to RCCL's kernels when world > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) collapsed-sdf-head measurement")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (non-headline) factored-sdf-head / GEMM-backward measurements")
     a = ap.parse_args()
     if a.dtype is None:
         a.dtype = "fp32" if WORKLOADS[a.workload]["kind"] == "sweep" else "bf16"

@@ -56,6 +56,15 @@ int umr_get_f32_mode(void);
 int umr_set_cu_budget(int cus);   /* returns UMR_OK or UMR_ERR_INVALID */
 int umr_get_cu_budget(void);
 
+/* Debug / A-B options (forced tile sizes, split-K factors, kernel variants: the UMR_* names csrc/umr_common.h lists).  Process-wide.
+ * The environment variable of the same name is read ONCE, when the library is loaded -- no entry point calls getenv() on its launch
+ * path, so the library's behaviour never depends on environment changes made while it runs and is safe beside a host that calls
+ * setenv(); tests and probes switch an option between launches with this call instead.  value: the text the environment variable
+ * would hold ("256", "0", "m"), NULL = unset (the library's own default).  Unknown names return UMR_ERR_INVALID.  None of these
+ * options changes WHAT is computed beyond rounding order where the option's test says so; they exist to compare forms. */
+int umr_set_debug_option(const char* name, const char* value);
+int umr_get_debug_option(const char* name, int* value, int* is_set);   /* letter options report the character code */
+
 /* ---- GEMM "NT" with implicit 3x3 convolution and fused epilogue ------------
  * C[M,N] = epi(A[M,K] . B[N,K]^T), fp32 accumulate on MFMA.
  * Replaces torch.nn.Linear / 1x1 nn.Conv2d (models/dpt/vit.py:84,263-327,
@@ -141,15 +150,21 @@ int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream);
  * ordering it relies on): (1) its first 16 KiB are zero before the first launch that uses it; (2) it belongs to ONE stream -- two
  * launches that may run concurrently must not share it (results would be silently wrong); (3) a launch that was enqueued and then
  * aborted (device fault, reset) leaves counters undefined: zero them again before reuse (umr_gemm_nt_ws does so itself when the
- * launch call reports an error).  An out-of-range ticket traps in every build.  The textbook agent-scope release / acquire hand-over
- * -- the slow reference form the default is tested against, bit for bit -- is available at run time (environment
- * UMR_SPLITK_FENCE=1, read per launch) and as a build (libumr_fence.so, make fence).  The default form's reliance on sc1 write-through
+ * launch call reports an error).  A ticket outside [0, splits) -- i.e. a violated precondition -- does NOT trap (no entry point of
+ * this library aborts the process or the device context): the kernel counts it in the workspace's error word (the last of the 4096
+ * counter ints), heals the counter and leaves that output tile unwritten; umr_gemm_nt_ws_status reads and clears the word.  The
+ * textbook agent-scope release / acquire hand-over -- the slow reference form the default is tested against, bit for bit -- is
+ * available at run time (umr_set_debug_option("UMR_SPLITK_FENCE", "1"); the environment variable of that name is read once, when the
+ * library is loaded) and as a build (libumr_fence.so, make fence).  The default form's reliance on sc1 write-through
  * stores and sc1 loads is the chip's documented behaviour, not a promise of the HIP memory model: DESIGN.md section 4 quotes the guide.
  * umr_gemm_nt_splits: the number of K ranges umr_gemm_nt_ws would use for d with a workspace of that size (1 = not split). */
 int64_t umr_gemm_nt_workspace(void);
 int umr_gemm_nt_splits(const umr_gemm_desc* d, int64_t workspace_bytes);
 int64_t umr_gemm_nt_x3_workspace(const umr_gemm_desc* d);   /* extra bytes a UMR_BF16X3 problem wants for its K-split slabs */
 int umr_gemm_nt_ws(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
+/* Diagnostic, and the ONE entry point that synchronises (it waits for `stream`): *bad_tickets = the number of out-of-range split-K
+ * tickets seen on this workspace since the last call (0 = every split GEMM that used it wrote all of its tiles); clears the count. */
+int umr_gemm_nt_ws_status(void* workspace, umr_stream_t stream, int* bad_tickets);
 /* rows x K f32 (row stride ld_src elements) -> rows x [h(K) | m(K) | l(K)] bf16 (row stride ld_dst >= 3K elements):
  * h = bf16(x), m = bf16(x - h), l = bf16(x - h - m), round-to-nearest-even each.  K % 4 == 0. */
 int umr_split3(const float* src, void* dst, int64_t rows, int K, int64_t ld_src, int64_t ld_dst, umr_stream_t stream);
@@ -312,6 +327,16 @@ int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* ou
 int umr_center_peaks(const float* sdf_maps, const float* center_fields, const double* filter50, double* score_out,
                      double* max_values, int64_t* argmax, int B, int H, int W, int border, int erode_kernel, int erode_rounds,
                      umr_stream_t stream);
+/* center_peaks with an argmax certificate: the same max / first flat argmax, plus certified[b] = 1 when the argmax is PROVABLY the
+ * one that ANY pair of fields within `eps` (max-norm) of these would give -- the peak survives in erode(union & ~F), beats every
+ * other pixel of erode(union | F) by more than 2 sqrt(2) eps (F = the pixels whose mask decision such a perturbation can flip) and
+ * stays on its side of `singular_threshold` (object_reasoning.py:541); or, for a map without a positive score, no pixel of the
+ * largest mask can reach one.  Lets a sweep run in a cheaper arithmetic mode and re-run only what it cannot certify
+ * (unmore_amd/reasoning.py::sweep_proposals; the argument is oracle/objectness_oracle.py::peak_certificate's).  Maps up to
+ * H*W = 25,600 pixels (six mask planes in LDS). */
+int umr_center_peaks_certified(const float* sdf_maps, const float* center_fields, const double* filter50, double* max_values,
+                               int64_t* argmax, int32_t* certified, int B, int H, int W, int border, int erode_kernel, int erode_rounds,
+                               float eps, double singular_threshold, umr_stream_t stream);
 int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream);
 
 /* ---- collapsed linear head (opt-in; SURVEY.md section 7 "the sdf head has no nonlinearity before tanh") ------

@@ -449,13 +449,17 @@ def peak_pick(sdf_maps, center_fields, border=10):
     return score, flat.amax(dim=1), flat.argmax(dim=1)
 
 
-def peak_certificate(sdf_maps, center_fields, eps, thres=0.009, border=10):
+def peak_certificate(sdf_maps, center_fields, eps, thres=0.009, border=10, certify_empty=False):
     """Is the flat argmax of `peak_pick` provably unchanged by ANY perturbation of the fields below `eps` (max-norm)?
     (tests/golden/make_golden_r2.py computes the same certificate for the committed peak fixtures.)  Erosion is monotone, so
     with F = the pixels such a perturbation can move across a threshold of the union mask (object_reasoning.py:528-533), every
     reachable eroded mask lies between erode(union & ~F) and erode(union | F); a score moves by at most sqrt(2)*eps (24
     unit-vector taps / 24).  Certified when the peak survives in the smallest mask, beats every pixel of the largest mask by
     more than 2*sqrt(2)*eps and amax stays on its side of the singularity threshold (:541).
+    certify_empty (round 6; the committed fixtures were made without it): a map WITHOUT a positive score -- amax == 0 at flat index 0, a
+    border pixel whose score is exactly zero under any perturbation -- is certified too when no pixel of the largest mask can reach a
+    positive score (all of them below -2*sqrt(2)*eps, or that mask empty inside the border): the checker of the device-side
+    certificate unmore_amd/csrc/reasoning.hip::center_peaks_cert_kernel, which needs it because most sweep proposals have no peak.
     Returns (amax [B] f64, flat argmax [B] i64, certified [B] bool)."""
     sdf_bin = torch.where(torch.sigmoid(sdf_maps) > 0.5, 1, 0)
     cnorm = torch.norm(center_fields, dim=1)
@@ -478,7 +482,14 @@ def peak_certificate(sdf_maps, center_fields, eps, thres=0.009, border=10):
     cert = torch.zeros(B, dtype=torch.bool)
     for b in range(B):
         p_ = int(arg[b])
-        if float(amax[b]) <= 0 or int(er_min[b].reshape(-1)[p_]) != 1:
+        if float(amax[b]) <= 0:
+            if certify_empty and float(amax[b]) == 0.0 and p_ == 0 and border >= 1 and abs(thres) > bound:
+                inside = torch.zeros_like(er_max[b], dtype=torch.bool)
+                inside[border:-border, border:-border] = True
+                live = (er_max[b] == 1) & inside
+                cert[b] = (not bool(live.any())) or bool(float(fg_max[b][live].max()) < -bound)
+            continue
+        if int(er_min[b].reshape(-1)[p_]) != 1:
             continue
         others = fg_max[b].reshape(-1).clone()
         others[p_] = -1e300

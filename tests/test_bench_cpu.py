@@ -39,7 +39,7 @@ def test_bench_spawns_its_own_ranks_when_called_plainly():
     assert r.returncode == 0, r.stderr[-2000:]
     res = _one_json_line(r.stdout)
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["rehearsal"] is True
-    assert res["collective"] == {"backend": "gloo", "world": 2}
+    assert res["collective"] == {"backend": "gloo", "world": 2, "gradient_wire": "f32"}
     assert res["allreduce_correct"] is True and res["ms_per_step"] > 0
 
 
@@ -96,7 +96,7 @@ def test_eight_rank_rehearsal_exchanges_the_full_gradient_buffer():
                         "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = _one_json_line(r.stdout)
-    assert res["n_gpus"] == 8 and res["collective"] == {"backend": "gloo", "world": 8}
+    assert res["n_gpus"] == 8 and res["collective"] == {"backend": "gloo", "world": 8, "gradient_wire": "f32"}
     assert res["allreduce_correct"] is True and res["allreduce_buckets"] == 16
     assert 115_000_000 < res["allreduce_elements"] < 116_000_000
     assert len(res["per_rank_ms_per_step"]) == 8 and all(t > 0 for t in res["per_rank_ms_per_step"])

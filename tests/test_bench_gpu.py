@@ -49,3 +49,7 @@ def test_single_gpu_lines_carry_the_contract(workload, extra):
         # NOT empty (at least half of the proposals have a peak), bf16 is reported beside it
         assert res["dtype"] == "fp32" and res["maps_with_peak"] >= 1225 // 2
         assert res["alt_bf16"]["value"] > res["value"]
+        # round 6: the headline is the certificate-driven sweep; it returns the full six-term sweep's peak index for EVERY proposal
+        sp, full = res["sweep_precision"], res["alt_fp32_full_precision"]
+        assert sp["mode"] == "certified" and 0.0 <= sp["rerun_fraction"] < 0.5, sp
+        assert full["peak_index_differs_from_headline"] == 0 and full["max_abs_amax_difference_vs_headline"] <= 1.5e-4, full

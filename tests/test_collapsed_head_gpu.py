@@ -133,18 +133,24 @@ def test_collapsed_equals_factored_inference_all_linear_variants(dtype, tol, act
         assert (outs["collapsed"]["sdf_maps"].cpu().double() - ref["sdf_maps"]).abs().max().item() <= 1e-4
 
 
-def test_relu_variants_never_collapse_and_training_stays_factored():
+def test_relu_variants_never_collapse_and_gemm_backward_training_stays_factored():
     for args in (Namespace(use_bg_sdf=True, sdf_activation="relu"), Namespace(use_bg_sdf=False, sdf_activation="tanh")):
         net, _ = _net("dpt_tiny", "tiny", args=args, mode="collapsed", size=64)
         eng = net._engine()
         assert not eng._collapse(eng.sdf_layout, False) and not eng._collapse(eng.center_layout, False)
+    # the default: collapsed at inference and -- since round 6 -- in training when the backward is the algebraic one (it reads the
+    # head's output only; tests/test_collapsed_train_gpu.py).  With the layer-by-layer GEMM backward, which reads the four
+    # convolutions' activations, training under autograd runs them: bit-identical to 'factored'
     net, _ = _net("dpt_tiny", "tiny", mode="auto", size=64)
     eng = net._engine()
-    assert eng._collapse(eng.sdf_layout, save=False) and not eng._collapse(eng.sdf_layout, save=True)
+    assert eng._collapse(eng.sdf_layout, save=False) and eng._collapse(eng.sdf_layout, save=True)
     assert not eng._collapse(eng.center_layout, save=False)
-    # under autograd (training) the default runs the four convolutions: bit-identical to 'factored'
+    net.set_linear_head_backward("gemm")
+    eng = net._engine()
+    assert eng._collapse(eng.sdf_layout, save=False) and not eng._collapse(eng.sdf_layout, save=True)
     x = torch.from_numpy(uniform01("img:tf", (2, 3, 64, 64))).cuda()
     net_f, _ = _net("dpt_tiny", "tiny", mode="factored", size=64)
+    net_f.set_linear_head_backward("gemm")
     net.train()
     net_f.train()
     o_a, o_f = net(images=x), net_f(images=x)

@@ -428,10 +428,10 @@ def test_gemm_nt_x3_planes(M, N, K, relu, f32_mode_restored):
 
 
 @pytest.mark.parametrize("nb,H,W,Cin,N", [(2, 20, 24, 64, 128), (1, 37, 19, 128, 72), (5, 128, 128, 64, 256)])
-def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored, monkeypatch):
+def test_conv3x3_x3_planes(nb, H, W, Cin, N, f32_mode_restored, umr_opts):
     from unmore_amd import ops, _lib as L
     dev = _dev()
-    monkeypatch.setenv("UMR_NT_SPLITK", "0")   # the yardstick is ONE f32 accumulation chain per output (split-K shortens the chains)
+    umr_opts.setenv("UMR_NT_SPLITK", "0")   # the yardstick is ONE f32 accumulation chain per output (split-K shortens the chains)
     x = _rnd((nb, H, W, Cin), torch.float32, dev, 41)
     w = _rnd((N, 3, 3, Cin), torch.float32, dev, 42, (9 * Cin) ** -0.5)
     bias = _rnd((N,), torch.float32, dev, 43)
@@ -492,7 +492,7 @@ def test_gemm_nt_x3_refuses_what_it_does_not_implement():
 
 
 @pytest.mark.parametrize("M", [64 * 577, 1000, 224 * 3 + 5])
-def test_tile_height_does_not_change_results(M, monkeypatch):
+def test_tile_height_does_not_change_results(M, umr_opts):
     """The persistent 256x256 kernel picks 256, 224 or 192 output rows per tile for plain GEMMs so that the tile count fills whole
     rounds of the chip (csrc/gemm_nt256p.hip, `bm`).  Every output element's K sum is the same instruction sequence whatever the
     tile it lands in, so all epilogue classes must give BIT-IDENTICAL results for the three heights -- and match torch."""
@@ -506,7 +506,7 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
     b4 = _rnd((4 * D,), torch.float32, dev, 75)
     aux = _rnd((M, D), torch.bfloat16, dev, 76)
     redw = _rnd((2, 4 * D), torch.float32, dev, 77)
-    monkeypatch.setenv("UMR_GEMM_TILE", "256")   # small M would otherwise go to the 128x128 kernel
+    umr_opts.setenv("UMR_GEMM_TILE", "256")   # small M would otherwise go to the 128x128 kernel
 
     def run():
         outs = [ops.gemm_nt(x, w, bias, act=L.ACT_RELU),                      # fast class
@@ -522,9 +522,9 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
 
     res = {}
     for bm in (256, 224, 192):
-        monkeypatch.setenv("UMR_NT256_BM", str(bm))
+        umr_opts.setenv("UMR_NT256_BM", str(bm))
         res[bm] = run()
-    monkeypatch.delenv("UMR_NT256_BM")
+    umr_opts.delenv("UMR_NT256_BM")
     res[0] = run()   # the library's own choice
     for bm in (224, 192, 0):
         for a, b in zip(res[256], res[bm]):
@@ -533,7 +533,7 @@ def test_tile_height_does_not_change_results(M, monkeypatch):
     torch.testing.assert_close(res[224][0].float(), ref, atol=3e-2, rtol=3e-2)
 
 
-def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
+def test_randomized_large_tile_vs_small_tile_kernels(umr_opts):
     """40 random plain-GEMM problems (ragged M and N, K a multiple of 64, every epilogue class) through the persistent 256x256
     kernel -- every tile height it may choose -- against the 128x128 kernel (the one the fixture tests exercise): bf16 results
     within two output ulps of each other and of torch fp32; the fp32 plane kernel against the in-register-split kernel to 2e-6."""
@@ -574,32 +574,32 @@ def test_randomized_large_tile_vs_small_tile_kernels(monkeypatch):
             torch.testing.assert_close(a, b, atol=2e-6 * float(b.abs().max() + 1), rtol=0)
             continue
         if kind == "red":
-            monkeypatch.setenv("UMR_GEMM_TILE", "256")
+            umr_opts.setenv("UMR_GEMM_TILE", "256")
             h, parts = ops.gemm_nt(x, w, bias, act=L.ACT_RELU, red_w=redw)
             out = ops.head_out_finish(parts, torch.zeros(2, device=dev), 1, 1, M, L.ACT_NONE)[0, :, 0, :].t()
             ref = h.float() @ redw.t()
             torch.testing.assert_close(out, ref, atol=2e-3, rtol=2e-3)
             continue
-        monkeypatch.setenv("UMR_GEMM_TILE", "128")
+        umr_opts.setenv("UMR_GEMM_TILE", "128")
         small = run()
         for bm in ("0", "256", "224", "192"):
-            monkeypatch.setenv("UMR_GEMM_TILE", "256")
+            umr_opts.setenv("UMR_GEMM_TILE", "256")
             if bm == "0":
-                monkeypatch.delenv("UMR_NT256_BM", raising=False)
+                umr_opts.delenv("UMR_NT256_BM", raising=False)
             else:
-                monkeypatch.setenv("UMR_NT256_BM", bm)
+                umr_opts.setenv("UMR_NT256_BM", bm)
             big = run()
             for a, b in zip(small, big):
                 # bf16: the large-tile path rounds acc + bias to bf16 before a residual add / mask (documented in include/umr.h): two output ulps
                 tol = 1e-5 if a.dtype == torch.float32 else 2.0 ** -6
                 assert ((a.float() - b.float()).abs() <= tol * (b.float().abs() + 1)).all(), (case, kind, M, N, K, bm)
-        monkeypatch.delenv("UMR_NT256_BM", raising=False)
+        umr_opts.delenv("UMR_NT256_BM", raising=False)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,force", [(1300, 1024, 4096, None), (1300, 1024, 1024, None), (300, 200, 1096, "3"), (129, 136, 776, "8"),
                                          (700, 3072, 1024, "2")])
-def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
+def test_gemm_nt_split_k(dtype, M, N, K, force, f32_mode_restored, umr_opts):
     """Split-K of the 128x128 kernel (umr_gemm_nt_ws: few tiles, long K -- the reference recipe's 1300-token projections): against
     fp64, against the unsplit launch, twice in a row (counters are left zero; the fixed-order slab sum is bitwise reproducible),
     through every epilogue class (bias, residual, ReLU mask, GELU + saved pre-activation), with ragged M / N and a K tail."""
@@ -619,9 +619,9 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
         return [t for t in (o1, o2, pre, o3, o4) if t is not None]
 
     if force:
-        monkeypatch.setenv("UMR_NT_SPLITK", force)
+        umr_opts.setenv("UMR_NT_SPLITK", force)
     else:
-        monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+        umr_opts.delenv("UMR_NT_SPLITK", raising=False)
     for mode in (("x3", "exact") if dtype == torch.float32 else (None,)):
         if mode:
             ops.set_f32_mode(mode)
@@ -635,12 +635,12 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
         second = run()
         for a, b in zip(first, second):
             assert torch.equal(a, b)
-        monkeypatch.setenv("UMR_NT_SPLITK", "0")
+        umr_opts.setenv("UMR_NT_SPLITK", "0")
         unsplit = run()
         if force:
-            monkeypatch.setenv("UMR_NT_SPLITK", force)
+            umr_opts.setenv("UMR_NT_SPLITK", force)
         else:
-            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+            umr_opts.delenv("UMR_NT_SPLITK", raising=False)
         torch.testing.assert_close(first[0].double(), ref, **_tol(dtype))
         torch.testing.assert_close(first[-2].double(), ref + aux.double(), **_tol(dtype))
         torch.testing.assert_close(first[-1].double(), (ref - bias.double()) * (aux.double() > 0), **_tol(dtype))
@@ -653,12 +653,12 @@ def test_gemm_nt_split_k(dtype, M, N, K, force, monkeypatch, f32_mode_restored):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_split_k_back_to_back_with_different_operands(dtype, monkeypatch):
+def test_split_k_back_to_back_with_different_operands(dtype, umr_opts):
     """Two split launches in a row on the SAME workspace with different A, each checked against float64: a last arriver that read a
     slab of the previous launch (stale line, counter not back at zero) would reproduce the first result or mix the two."""
     from unmore_amd import ops
     dev = _dev()
-    monkeypatch.setenv("UMR_NT_SPLITK", "4")
+    umr_opts.setenv("UMR_NT_SPLITK", "4")
     M, N, K = 300, 264, 2048
     B = _rnd((N, K), dtype, dev, 2, K ** -0.5)
     outs, refs = [], []
@@ -669,6 +669,31 @@ def test_split_k_back_to_back_with_different_operands(dtype, monkeypatch):
     for A, o in zip(As, outs):
         torch.testing.assert_close(o.double(), A.double() @ B.double().t(), **_tol(dtype))
     assert not torch.equal(outs[0], outs[1])
+
+
+def test_split_k_bad_ticket_is_counted_not_trapped(umr_opts):
+    """A violated workspace precondition (a tile counter that is not zero on first use) used to end in __builtin_trap(), i.e. in the
+    loss of the process's device context.  Now (include/umr.h): the kernel counts the out-of-range ticket in the workspace's error word,
+    heals the counter and leaves that ONE tile unwritten; umr_gemm_nt_ws_status reads and clears the count; the next launch is clean."""
+    from unmore_amd import ops
+    umr_opts.setenv("UMR_GEMM_TILE", "128")
+    umr_opts.setenv("UMR_NT_SPLITK", "2")
+    dev = _dev()
+    A, B = _rnd((300, 2048), torch.bfloat16, dev, 1), _rnd((200, 2048), torch.bfloat16, dev, 2, 2048 ** -0.5)
+    assert ops.gemm_nt(A, B, None, query_splits=True) == 2
+    ref = ops.gemm_nt(A, B, None)
+    assert ops.splitk_bad_tickets() == 0
+    ws = ops._splitk_workspace(A.device)
+    ws[:4].view(torch.int32)[0] = 1000                      # counter of one tile: garbage, as after an aborted launch
+    out = ops.gemm_nt(A, B, None)
+    torch.cuda.synchronize()                                # the context survives
+    assert ops.splitk_bad_tickets() in (1, 2)               # one or both workgroups of the tile drew a ticket before the counter was healed
+    assert ops.splitk_bad_tickets() == 0                    # read-and-clear
+    bad_tiles = sum(int(not torch.equal(out[r:r + 128, c:c + 128], ref[r:r + 128, c:c + 128])) for r in range(0, 300, 128) for c in range(0, 200, 128))
+    assert bad_tiles <= 1                                   # only the poisoned tile may be unwritten
+    assert int(ws[:16384].view(torch.int32).abs().sum()) == 0   # every counter healed, error word cleared
+    assert torch.equal(ops.gemm_nt(A, B, None), ref)
+    assert ops.splitk_bad_tickets() == 0
 
 
 def test_split_k_equals_the_fence_build(tmp_path):
@@ -692,14 +717,14 @@ def rnd(shape, dtype, seed, scale=1.0):
 outs = []
 for dtype in (torch.float32, torch.bfloat16):
     for (M, N, K, force) in ((1300, 1024, 4096, None), (300, 200, 1096, "3"), (129, 136, 776, "8")):
-        if force: os.environ["UMR_NT_SPLITK"] = force
-        else: os.environ.pop("UMR_NT_SPLITK", None)
+        if force: ops.set_debug_option("UMR_NT_SPLITK", force)
+        else: ops.set_debug_option("UMR_NT_SPLITK", None)
         A, B, bias, aux = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5), rnd((N,), torch.float32, 3), rnd((M, N), dtype, 4)
         assert ops.gemm_nt(A, B, bias, query_splits=True) > 1
         for rep in range(3):
             outs.append(ops.gemm_nt(A, B, bias).float().cpu())
             outs.append(ops.gemm_nt(A, B, None, aux=aux, mask_relu=True).float().cpu())
-    os.environ["UMR_NT_SPLITK"] = "5"
+    ops.set_debug_option("UMR_NT_SPLITK", "5")
     x, w = rnd((2, 14, 9, 128), dtype, 5), rnd((200, 9 * 128), dtype, 6, 0.03)
     outs.append(ops.gemm_nt(x, w, None, conv=1).float().cpu())
 torch.save(outs, sys.argv[1])
@@ -724,7 +749,7 @@ torch.save(outs, sys.argv[1])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("nb,H,W,Cin,N,stride,force", [(2, 7, 7, 256, 256, 1, None), (2, 14, 9, 128, 200, 1, "5"), (3, 12, 12, 128, 128, 2, "3"),
                                                         (20, 16, 16, 256, 256, 1, None)])
-def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, monkeypatch, f32_mode_restored):
+def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, f32_mode_restored, umr_opts):
     """Split-K of the implicit 3x3 conv on small maps (a K range starts in the middle of the tap sequence): against torch conv2d in
     fp64, twice (bitwise reproducible), and against the unsplit launch."""
     from unmore_amd import ops
@@ -735,9 +760,9 @@ def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, monkeypatch, f3
     wp = w.permute(0, 2, 3, 1).reshape(N, 9 * Cin).contiguous()
     ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, N)
     if force:
-        monkeypatch.setenv("UMR_NT_SPLITK", force)
+        umr_opts.setenv("UMR_NT_SPLITK", force)
     else:
-        monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+        umr_opts.delenv("UMR_NT_SPLITK", raising=False)
     for mode in (("x3", "exact") if dtype == torch.float32 else (None,)):
         if mode:
             ops.set_f32_mode(mode)
@@ -745,16 +770,16 @@ def test_conv3x3_split_k(dtype, nb, H, W, Cin, N, stride, force, monkeypatch, f3
         b = ops.gemm_nt(x, wp, bias, conv=stride)
         assert torch.equal(a, b)
         torch.testing.assert_close(a.double().reshape(-1, N), ref, **_tol(dtype))
-        monkeypatch.setenv("UMR_NT_SPLITK", "0")
+        umr_opts.setenv("UMR_NT_SPLITK", "0")
         c = ops.gemm_nt(x, wp, bias, conv=stride)
         if force:
-            monkeypatch.setenv("UMR_NT_SPLITK", force)
+            umr_opts.setenv("UMR_NT_SPLITK", force)
         else:
-            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+            umr_opts.delenv("UMR_NT_SPLITK", raising=False)
         torch.testing.assert_close(a.float(), c.float(), atol=2e-5 if dtype == torch.float32 else 2e-2, rtol=2 ** -7 if dtype == torch.bfloat16 else 2e-5)
 
 
-def test_cu_budget_does_not_change_results(monkeypatch):
+def test_cu_budget_does_not_change_results(umr_opts):
     """umr_set_cu_budget (include/umr.h): the persistent 256x256 grids launch exactly `budget` workgroups, leaving the other CUs to
     kernels that run beside them (RCCL's bucket all-reduces during a data-parallel backward).  Tile height and K-split are planned on
     the device's CU count, every output element's K sum is the same instruction sequence in any workgroup: plain GEMMs of every
@@ -776,7 +801,7 @@ def test_cu_budget_does_not_change_results(monkeypatch):
     xf = _rnd((1300, 1024), torch.float32, dev, 181)
     wf = _rnd((1024, 1024), torch.float32, dev, 182, 1024 ** -0.5)
     xp, wp = ops.split3(xf), ops.split3(wf)
-    monkeypatch.setenv("UMR_GEMM_TILE", "256")
+    umr_opts.setenv("UMR_GEMM_TILE", "256")
 
     def run():
         outs = [ops.gemm_nt(x, w, bias, act=L.ACT_RELU), ops.gemm_nt(x, w, bias, aux=aux), ops.gemm_nt(x, w, None, aux=aux, mask_relu=True),
@@ -806,26 +831,26 @@ def test_cu_budget_does_not_change_results(monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-def test_xcd_tile_order_does_not_change_results(dtype, monkeypatch):
+def test_xcd_tile_order_does_not_change_results(dtype, umr_opts):
     """The 128x128 NT kernel walks an XCD's run of tiles n-fastest or m-fastest (csrc/gemm_nt.hip: the operand every XCD has to fetch
     whole should be the smaller one; UMR_NT_ORDER forces an order per launch).  Which workgroup computes a tile never changes the
     tile's arithmetic: both orders and the library's own choice are bit-identical, with and without split-K, ragged edges included."""
     from unmore_amd import ops, _lib as L
     dev = _dev()
-    monkeypatch.setenv("UMR_GEMM_TILE", "128")
+    umr_opts.setenv("UMR_GEMM_TILE", "128")
     for (M, N, K, force) in ((1300, 4096, 1024, None), (1300, 1024, 4096, None), (300, 200, 1096, "3"), (129, 136, 776, None), (70, 1544, 136, None)):
         if force:
-            monkeypatch.setenv("UMR_NT_SPLITK", force)
+            umr_opts.setenv("UMR_NT_SPLITK", force)
         else:
-            monkeypatch.delenv("UMR_NT_SPLITK", raising=False)
+            umr_opts.delenv("UMR_NT_SPLITK", raising=False)
         A, B = _rnd((M, K), dtype, dev, 11), _rnd((N, K), dtype, dev, 12, K ** -0.5)
         bias, aux = _rnd((N,), torch.float32, dev, 13), _rnd((M, N), dtype, dev, 14)
         res = {}
         for order in ("n", "m", None):
             if order:
-                monkeypatch.setenv("UMR_NT_ORDER", order)
+                umr_opts.setenv("UMR_NT_ORDER", order)
             else:
-                monkeypatch.delenv("UMR_NT_ORDER", raising=False)
+                umr_opts.delenv("UMR_NT_ORDER", raising=False)
             res[order] = (ops.gemm_nt(A, B, bias, act=L.ACT_RELU), ops.gemm_nt(A, B, None, aux=aux, mask_relu=True), ops.gemm_nt(A, B, bias, out_f32=True))
             torch.cuda.synchronize()
         for order in ("m", None):

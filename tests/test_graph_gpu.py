@@ -323,6 +323,35 @@ def test_evaluation_between_replayed_train_steps_sees_the_new_weights(dtype, eva
     assert step_g.graph_replays == 6
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_second_evaluation_shape_after_replayed_train_steps_sees_the_new_weights(dtype):
+    """Round-5 advisor: once train steps replay, an evaluation capture builds the collapsed head's weights INSIDE itself (the copies
+    of its warm-up calls were dropped by the replays), and that entry used to stay in the host-side cache under an unchanged version
+    key.  An eager evaluation of ANOTHER shape right after the next replayed step -- and, on its third call, a second capture -- then
+    hit it and read the weights the first graph's last replay had written: one step old.  Every evaluation of both shapes is compared
+    with a twin that trains and evaluates eagerly; the second shape is evaluated FIRST after each step (before the first graph's replay
+    rewrites its buffer)."""
+    from unmore_amd.trainer import TrainStep
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    step_e = TrainStep(net_e, lr=2e-4).set_graph_mode("off")
+    step_g = TrainStep(net_g, lr=2e-4).set_graph_mode("on")
+    net_e.set_graph_mode("off")
+    net_g.set_graph_mode("on")
+    xa, xb = _batch(3, 64, 64, seed=7)[0], _batch(2, 64, 96, seed=8)[0]
+    for it in range(11):
+        batch = _batch(2, 64, 64, seed=900 + it)
+        assert torch.equal(step_e.step(*batch), step_g.step(*batch)), it
+        with torch.no_grad():
+            for tag, x in (("b", xb), ("a", xa)) if it >= 5 else (("a", xa),):
+                oe, og = net_e.get_prediction(x), net_g.get_prediction(x)
+                for k in ("center_fields", "sdf_maps"):
+                    assert torch.equal(oe[k], og[k]), (it, tag, k)
+    assert step_g.graph_replays >= 8
+    from unmore_amd import graphs
+    assert sum(isinstance(v, graphs.Captured) for v in net_g._inf_graphs.values()) >= 1
+
+
 def test_dropped_captures_release_their_pools():
     """A loop whose batch size keeps changing (the reference's batch filter, train_objectness_net.py:190-207) captures every shape on
     its third step and holds at most graphs.MAX_CAPTURES captures; every capture owns private memory pools, and a new capture never
@@ -367,4 +396,28 @@ def test_staged_replay_with_a_lagging_side_lane(dtype, batched_repack, monkeypat
         for cap in step_g._graphs.values():
             if isinstance(cap, graphs.StagedCaptured):
                 cap.debug_side_delay = 2_500_000
+    assert step_g.graph_replays == 5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_staged_replay_with_a_lagging_main_lane(dtype):
+    """The mirror image: the MAIN lane is held back ~1 ms before every segment (StagedCaptured.debug_main_delay), so side graph B_k --
+    stage k's weight gradients, its Adam update and the refresh of its packed weight copies -- has long finished when the main lane
+    runs A_k+1, A_k+2, ...  Any later main-lane kernel that still read stage k's weights (the hazard trainer.py keeps the reassemble
+    stage off the side lane for: the readout projections are read again when the transformer's backward reaches a hooked block,
+    models/dpt/vit.py:86-90) would read UPDATED weights and the step would differ from the eager one.  dpt_tiny has all four hooks
+    (blocks 0-3) and the two-input fusion blocks, i.e. every such re-read the wiring has."""
+    from unmore_amd import graphs, trainer
+    net_e, _ = _net(dtype=dtype)
+    net_g, _ = _net(dtype=dtype)
+    step_e = trainer.TrainStep(net_e, lr=1e-3).set_graph_mode("off")
+    step_g = trainer.TrainStep(net_g, lr=1e-3).set_graph_mode("on")
+    for it in range(7):
+        batch = _batch(2, 64, 64, seed=950 + it)
+        le, lg = step_e.step(*batch), step_g.step(*batch)
+        assert torch.equal(le, lg), (it, le.tolist(), lg.tolist())
+        assert torch.equal(step_e.flat_p, step_g.flat_p), it
+        for cap in step_g._graphs.values():
+            if isinstance(cap, graphs.StagedCaptured):
+                cap.debug_main_delay = 2_500_000
     assert step_g.graph_replays == 5

@@ -62,7 +62,7 @@ def test_layernorm(dtype, M, D):
 
 
 @pytest.mark.parametrize("B,N,heads", [(20, 65, 16), (3, 100, 2), (2, 17, 1), (1, 127, 3)])
-def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, monkeypatch):
+def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, umr_opts):
     """N < 128 in bf16: dQ and dK / dV workgroups in ONE launch, each taking its rows' -lse and rowsum(dO * O) itself
     (attn_bwd_small_bf16_kernel) -- against the three launches (prep, dQ, dK / dV; UMR_ATTN_BWD_FUSED=0, read per launch).  The same
     arithmetic per output except the order of the 64 products in rowsum(dO * O): a last-bit difference there flips the bf16 rounding of
@@ -73,9 +73,9 @@ def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, monkey
     qkv = _rnd((B * N, 3 * D), torch.bfloat16, dev, 11, 1.0)
     dout = _rnd((B * N, D), torch.bfloat16, dev, 12)
     out, lse = ops.attention_fwd(qkv, B, N, heads)
-    monkeypatch.setenv("UMR_ATTN_BWD_FUSED", "0")
+    umr_opts.setenv("UMR_ATTN_BWD_FUSED", "0")
     ref = ops.attention_bwd(qkv, out, dout, lse, B, N, heads).float()
-    monkeypatch.setenv("UMR_ATTN_BWD_FUSED", "1")
+    umr_opts.setenv("UMR_ATTN_BWD_FUSED", "1")
     got = ops.attention_bwd(qkv, out, dout, lse, B, N, heads).float()
     assert torch.isfinite(got).all()
     err = (got - ref).abs()
@@ -242,7 +242,7 @@ def test_head_out(dtype, Cout, act):
 
 
 @pytest.mark.parametrize("Cout,act,relu_mask", [(2, 3, True), (1, 0, False), (2, 0, True)])
-def test_head_out_bwd_k1024_kernel_against_generic_and_fp64(Cout, act, relu_mask, monkeypatch):
+def test_head_out_bwd_k1024_kernel_against_generic_and_fp64(Cout, act, relu_mask, umr_opts):
     """The 1024-channel bf16 kernel (64-row runs, two row streams per block, ragged last runs, runs that straddle an image
     boundary) against the generic kernel and an fp64 reference."""
     from unmore_amd import ops
@@ -255,9 +255,9 @@ def test_head_out_bwd_k1024_kernel_against_generic_and_fp64(Cout, act, relu_mask
     got = {}
     for name in ("k1024", "generic"):
         if name == "generic":
-            monkeypatch.setenv("UMR_HEAD_OUT_BWD_GENERIC", "1")
+            umr_opts.setenv("UMR_HEAD_OUT_BWD_GENERIC", "1")
         else:
-            monkeypatch.delenv("UMR_HEAD_OUT_BWD_GENERIC", raising=False)
+            umr_opts.delenv("UMR_HEAD_OUT_BWD_GENERIC", raising=False)
         dw = torch.full_like(w, float("nan"))
         db = torch.full((Cout,), float("nan"), device=dev)
         dh = ops.head_out_bwd(h, w, dout, yout, act, relu_mask, dw, db)

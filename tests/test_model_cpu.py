@@ -88,6 +88,47 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert b"workspace" in lib.umr_last_error_string()
 
 
+def test_debug_options_are_read_at_load_and_changed_only_through_the_entry_point():
+    """No entry point reads the environment on its launch path (round-5 review): the UMR_* A/B options are read once, when the
+    library is loaded, and changed through umr_set_debug_option.  A child process checks both halves: an option present in the
+    environment at load is seen; changing the environment afterwards changes nothing; the setter does; unknown names are refused."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys
+sys.path.insert(0, %r)
+from unmore_amd import _lib, ops
+import ctypes
+lib = _lib.lib()
+def get(name):
+    v, s = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.umr_get_debug_option(name.encode(), ctypes.byref(v), ctypes.byref(s)) == 0
+    return v.value if s.value else None
+assert get("UMR_NT_SPLITK") == 3 and get("UMR_NT_ORDER") == ord("m") and get("UMR_GEMM_TILE") is None
+os.environ["UMR_NT_SPLITK"] = "7"
+os.environ["UMR_GEMM_TILE"] = "128"
+assert get("UMR_NT_SPLITK") == 3 and get("UMR_GEMM_TILE") is None          # the environment is not consulted again
+assert ops.set_debug_option("UMR_GEMM_TILE", 256) is None and get("UMR_GEMM_TILE") == 256
+assert ops.set_debug_option("UMR_GEMM_TILE", None) == 256 and get("UMR_GEMM_TILE") is None
+assert ops.set_debug_option("UMR_NT_ORDER", "n") == ord("m") and get("UMR_NT_ORDER") == ord("n")
+assert lib.umr_set_debug_option(b"UMR_NO_SUCH_OPTION", b"1") != 0 and b"unknown option" in lib.umr_last_error_string()
+assert lib.umr_set_debug_option(None, b"1") != 0
+print("ok")
+""" % root
+    env = dict(os.environ, UMR_NT_SPLITK="3", UMR_NT_ORDER="m")
+    env.pop("UMR_GEMM_TILE", None)
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+    # and the sources themselves: getenv only in once-per-process initialisers (static locals / first-use atomics), never in a launch path
+    csrc = os.path.join(root, "unmore_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for ln in open(os.path.join(csrc, f)):
+                if "getenv(" in ln and not ln.lstrip().startswith("//"):
+                    assert ("static const" in ln or "static inline int umr_env_int" in ln or f == "umr_api.hip"), (f, ln.strip())
+
+
 def test_flat_layout_buckets_follow_backward_completion_order():
     """trainer.flat_layout (shared by TrainStep and bench.py --rehearse): every grad-receiving parameter has a 256-byte aligned
     slot, parameters the reference never back-propagates into have none, and the bucket boundaries follow the order in which

@@ -69,3 +69,46 @@ def test_single_process_is_a_noop():
     comm.ready(1)
     assert comm.finish() == 1.0
     assert torch.equal(flat, torch.arange(10.0))
+
+
+def _worker_wire(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unmore_amd.parallel import BucketedAllReduce
+    n = 100_000
+    g = torch.Generator().manual_seed(200 + rank)
+    # gradient-like values over ten binades, the ranks' values correlated (same sign mostly, as gradients of two half-batches are)
+    base = torch.randn(n, generator=torch.Generator().manual_seed(7)) * torch.exp2(torch.randint(-10, 1, (n,), generator=torch.Generator().manual_seed(8)).float())
+    flat = base * (1.0 + 0.3 * torch.randn(n, generator=g))
+    local = flat.clone()
+    bounds = [0, 4096, 4096, 50_000, n]
+    comm = BucketedAllReduce(flat, bounds, wire_dtype=torch.bfloat16)
+    assert comm.enabled and comm.wire is not None and comm.wire.dtype == torch.bfloat16 and comm.grad_scale == 1.0
+    comm.trace = True
+    for k in range(comm.num_buckets):
+        comm.ready(k)
+    scale = comm.finish()
+    rep = comm.trace_report()
+    assert scale == 1.0 and rep["buckets"][0]["mbytes"] == round(4096 * 2 / 2 ** 20, 2)      # two bytes per element on the wire
+    torch.save({"local": local, "reduced": flat.clone()}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_exchange_against_the_f32_exchange_world2(tmp_path):
+    """the bf16 gradient wire (BucketedAllReduce(wire_dtype=torch.bfloat16)): every rank ends with the same buffer, equal to the mean of
+    the ranks' f32 gradients -- what the f32 exchange x 1/world gives -- to bf16 rounding: relative L2 <= 6e-3 over the buffer and per
+    bucket, every element within 2^-7 of its value (three roundings of 2^-9 each), and the scale handed to the optimizer is 1"""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_wire, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"r{i}.pt")) for i in range(world)]
+    assert torch.equal(r[0]["reduced"], r[1]["reduced"])
+    mean = ((r[0]["local"].double() + r[1]["local"].double()) / 2)
+    got = r[0]["reduced"].double()
+    rel = float((got - mean).norm() / mean.norm())
+    assert rel <= 6e-3, rel
+    for lo, hi in ((0, 4096), (4096, 50_000), (50_000, 100_000)):
+        assert float((got[lo:hi] - mean[lo:hi]).norm() / mean[lo:hi].norm()) <= 6e-3
+    tol = 2.0 ** -7 * torch.maximum(r[0]["local"].abs(), r[1]["local"].abs()).double() / 2 * 2
+    assert bool(((got - mean).abs() <= tol + 1e-30).all())

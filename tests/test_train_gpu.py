@@ -204,7 +204,8 @@ def test_collapsed_sdf_head_equals_factored(dtype, H, W):
 
 @pytest.mark.parametrize("dtype,H,W", [(torch.float32, 64, 96), (torch.bfloat16, 64, 64), (torch.float32, 64, 32), (torch.float32, 96, 160)])
 def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
-    """Default training path: the boundary-distance head's forward runs its four convolutions (identical outputs), its backward
+    """The boundary-distance head's two BACKWARD forms behind the same four-convolution forward ('factored' mode; since round 6 the
+    default mode collapses that forward when the backward is algebraic, tests/test_collapsed_train_gpu.py): its backward
     takes the exact gradients of all eight factored tensors from three pixel reductions instead of layer-by-layer GEMMs
     (engine._linear_head_backward).  Both backward forms against each other for EVERY parameter of the net (fp32: 2e-4 *
     max|g|; the fp64-oracle bar of 5e-4 is asserted on the default path by tests/test_model_gpu.py); bf16: cosine."""
@@ -214,6 +215,7 @@ def test_linear_head_algebraic_backward_equals_gemm_backward(dtype, H, W):
     res = {}
     for mode in ("gemm", "algebraic"):
         net, _ = _net("dpt_tiny", "tiny", dtype)
+        net.set_sdf_head_mode("factored")
         net.set_linear_head_backward(mode)
         net.train()
         out = net(images=img.cuda())

@@ -14,9 +14,9 @@ x = torch.randn(64, 192, 192, 256, device=dev).bfloat16()
 dy = torch.randn(64, 384, 384, 256, device=dev).bfloat16()
 for cap in (None, "0", "8192", "4096", "2048", "1024", "512", None):      # None = the library's defaults
     if cap is None:
-        os.environ.pop("UMR_BILINEAR_GY", None)
+        ops.set_debug_option("UMR_BILINEAR_GY", None)
     else:
-        os.environ["UMR_BILINEAR_GY"] = cap
+        ops.set_debug_option("UMR_BILINEAR_GY", cap)
     cap = cap or "dflt"
     tf = timeit(lambda: ops.bilinear_fwd(x, 384, 384, True), n=9, warm=2)
     tb = timeit(lambda: ops.bilinear_bwd(dy, 192, 192, True), n=9, warm=2)

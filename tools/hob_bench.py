@@ -22,9 +22,9 @@ yout = torch.tanh(torch.randn(B, 2, H, W, device=dev))
 res = {}
 for name, env in (("k1024", None), ("generic", "1")):
     if env:
-        os.environ["UMR_HEAD_OUT_BWD_GENERIC"] = env
+        ops.set_debug_option("UMR_HEAD_OUT_BWD_GENERIC", env)
     else:
-        os.environ.pop("UMR_HEAD_OUT_BWD_GENERIC", None)
+        ops.set_debug_option("UMR_HEAD_OUT_BWD_GENERIC", None)
     dw = torch.zeros(2, K, device=dev)
     db = torch.zeros(2, device=dev)
     dh = ops.head_out_bwd(h, w, dout, yout, L.ACT_TANH, True, dw, db)

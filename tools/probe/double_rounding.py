@@ -13,6 +13,7 @@ from unmore_amd import synth  # noqa: E402
 from unmore_amd.hashrng import hash_init  # noqa: E402
 from unmore_amd.objectness_net import ObjectnessNet  # noqa: E402
 from unmore_amd.trainer import TrainStep  # noqa: E402
+from unmore_amd import ops  # noqa: E402
 
 B, H, W = 4, 384, 384
 _, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=9))
@@ -21,9 +22,9 @@ img = torch.from_numpy(synth.blob_images(B, H, W, seed=9)).cuda()
 
 def step(dtype, tile):
     if tile:
-        os.environ["UMR_GEMM_TILE"] = tile
+        ops.set_debug_option("UMR_GEMM_TILE", tile)
     else:
-        os.environ.pop("UMR_GEMM_TILE", None)
+        ops.set_debug_option("UMR_GEMM_TILE", None)
     net = ObjectnessNet("cuda:0", H, "dpt_base", Namespace(use_bg_sdf=True, sdf_activation="tanh"))
     net.load_state_dict({k: torch.from_numpy(hash_init(k, tuple(v.shape), "base")) for k, v in net.state_dict().items()}, strict=True)
     net = net.to("cuda:0")
@@ -31,7 +32,7 @@ def step(dtype, tile):
     st = TrainStep(net, lr=0.0).set_graph_mode("off")
     loss = st.step(img, cf, sdf, sal)[0].item()
     g = {n: t.clone() for n, t in st.G.items()}
-    os.environ.pop("UMR_GEMM_TILE", None)
+    ops.set_debug_option("UMR_GEMM_TILE", None)
     return loss, g
 
 

@@ -32,8 +32,8 @@ for (M, N, K) in [(1300, 4096, 1024), (1300, 3072, 1024), (1300, 1024, 1024), (1
     res = {"n": [], "m": []}
     for rnd in range(3):
         for order in ("n", "m"):
-            os.environ["UMR_NT_ORDER"] = order
+            ops.set_debug_option("UMR_NT_ORDER", order)
             res[order].append(bench(lambda i: ops.gemm_nt(A, Bs[i % len(Bs)], bias, out=out)))
-    os.environ.pop("UMR_NT_ORDER", None)
+    ops.set_debug_option("UMR_NT_ORDER", None)
     auto = bench(lambda i: ops.gemm_nt(A, Bs[i % len(Bs)], bias, out=out))
     print(f"M={M} N={N} K={K} ({len(Bs)} weight sets)  us per launch  n-fastest {[round(v, 1) for v in res['n']]}  m-fastest {[round(v, 1) for v in res['m']]}  default {auto:.1f}", flush=True)

@@ -61,12 +61,12 @@ def main():
         ts = []
         for v in ("0", "1", None):
             if v is None:
-                os.environ.pop("UMR_NT256_PH2", None)
+                ops.set_debug_option("UMR_NT256_PH2", None)
             else:
-                os.environ["UMR_NT256_PH2"] = v
+                ops.set_debug_option("UMR_NT256_PH2", v)
             ts.append(timeit(fn, n=9, warm=3))
         print(f"{name:62s} {ts[0] * 1e3:9.1f} us {ts[1] * 1e3:9.1f} us {ts[2] * 1e3:9.1f} us   two/four {ts[1] / ts[0]:.3f}", flush=True)
-    os.environ.pop("UMR_NT256_PH2", None)
+    ops.set_debug_option("UMR_NT256_PH2", None)
 
 
 if __name__ == "__main__":

@@ -31,11 +31,11 @@ for dt in (torch.bfloat16, torch.float32):
         res = []
         for env in ("0", None, "2", "3", "5", "8"):
             if env is None:
-                os.environ.pop("UMR_NT_SPLITK", None)
+                ops.set_debug_option("UMR_NT_SPLITK", None)
             else:
-                os.environ["UMR_NT_SPLITK"] = env
+                ops.set_debug_option("UMR_NT_SPLITK", env)
             res.append(f"{env or 'auto'}: {bench(lambda: ops.gemm_nt(A, B, bias, out=out)):6.1f}")
-        os.environ.pop("UMR_NT_SPLITK", None)
+        ops.set_debug_option("UMR_NT_SPLITK", None)
         print(f"{str(dt)[6:]:9s} M={M} N={N} K={K}  us per launch  " + "  ".join(res), flush=True)
 
 
@@ -48,10 +48,10 @@ for dt in (torch.bfloat16, torch.float32):
         res = []
         for env in ("0", None, "2", "3", "4", "6", "8"):
             if env is None:
-                os.environ.pop("UMR_NT_SPLITK", None)
+                ops.set_debug_option("UMR_NT_SPLITK", None)
             else:
-                os.environ["UMR_NT_SPLITK"] = env
+                ops.set_debug_option("UMR_NT_SPLITK", env)
             res.append(f"{env or 'auto'}: {bench(lambda: ops.gemm_nt(A, B, bias, conv=1)):6.1f}")
-        os.environ.pop("UMR_NT_SPLITK", None)
+        ops.set_debug_option("UMR_NT_SPLITK", None)
         tiles = ((nb * H * W + 127) // 128) * ((N + 127) // 128)
         print(f"{str(dt)[6:]:9s} conv3x3 [{nb},{H},{W},{Cin}]->{N} ({tiles} tiles)  us per launch, UMR_NT_SPLITK =  " + "  ".join(res), flush=True)

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from unmore_amd import ops
 dev = torch.device("cuda:0")
-os.environ["UMR_NT_SPLITK"] = "0"
+ops.set_debug_option("UMR_NT_SPLITK", "0")
 
 
 def bench(fn, n=300):

@@ -108,6 +108,7 @@ _SIGS = {
     "umr_adam_step_hyper": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
     "umr_crop_resize_bilinear": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "umr_center_peaks_certified": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, ctypes.c_double, _vp],
     "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],
     "umr_linear_head_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_linear_head_bwd_data": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
@@ -126,6 +127,9 @@ _SIGS = {
     "umr_get_f32_mode": [],
     "umr_set_cu_budget": [_i32],
     "umr_get_cu_budget": [],
+    "umr_set_debug_option": [ctypes.c_char_p, ctypes.c_char_p],
+    "umr_get_debug_option": [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "umr_gemm_nt_ws_status": [_vp, _vp, ctypes.POINTER(ctypes.c_int)],
     "umr_version": [],
     "umr_last_error_string": [],
 }

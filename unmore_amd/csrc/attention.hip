@@ -1197,9 +1197,8 @@ extern "C" int umr_attention_bwd(const void* qkv, const void* out, const void* d
     dim3 gp((unsigned)((total + 255) / 256)), g((unsigned)(gx1 * B * heads)), b(256);
     static const int fast_bwd = umr_env_int("UMR_ATTN_FAST", 1);   // 0: the generic kernels for bf16 too (A/B)
     // short sequences: one launch (dQ and dK / dV workgroups side by side, no prep pass).  UMR_ATTN_BWD_FUSED=0: the three launches (A/B;
-    // read per launch)
-    const char* fe = getenv("UMR_ATTN_BWD_FUSED");
-    if (dtype == UMR_BF16 && fast_bwd && N < 128 && !(fe && fe[0] == '0')) {
+    // umr_set_debug_option)
+    if (dtype == UMR_BF16 && fast_bwd && N < 128 && umr_opt_or(UMR_OPT_ATTN_BWD_FUSED, 1) != 0) {
         const int half = gx1 * B * heads;
         UMR_CHECK_ARG(2ll * half < (1ll << 31), "attention_bwd: grid too large");
         hipLaunchKernelGGL(attn_bwd_small_bf16_kernel, dim3((unsigned)(2 * half)), b, 0, s, (const bf16_t*)qkv, (const bf16_t*)dout, (const bf16_t*)out,

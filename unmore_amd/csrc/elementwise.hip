@@ -1056,8 +1056,7 @@ extern "C" int umr_patchify(const float* images, void* out, int B, int H, int W,
 // rows of blocks of the resize kernels: a block loops over (image, row) pairs at stride gridDim.y.  UMR_BILINEAR_GY (read per
 // launch) caps it: one output row per block is 1.2 M blocks of one element per thread at the cfg2 feature map
 static int bilinear_gy_cap() {
-    const char* e = getenv("UMR_BILINEAR_GY");
-    const int v = e ? atoi(e) : 0;
+    const int v = umr_opt_or(UMR_OPT_BILINEAR_GY, 0);
     return v > 0 ? v : 65535;
 }
 
@@ -1292,7 +1291,7 @@ extern "C" int umr_head_out_bwd(const void* h, const float* w, const float* dout
     const int rpb = (int)((M + nb - 1) / nb);
     nb = (int)((M + rpb - 1) / rpb);
     hipStream_t s = (hipStream_t)stream;
-    const bool generic_only = getenv("UMR_HEAD_OUT_BWD_GENERIC") != nullptr;   // A/B hook, read per launch (tests compare both forms)
+    const bool generic_only = umr_opt(UMR_OPT_HEAD_OUT_BWD_GENERIC) != UMR_OPT_UNSET;   // A/B hook (tests compare both forms: umr_set_debug_option)
     if (dtype == UMR_BF16 && K == 1024 && act != 4 && !generic_only) {
         hipLaunchKernelGGL(head_out_bwd_k1024_kernel, dim3(nb), dim3(256), 0, s, (const bf16_t*)h, w, dout, yout, (bf16_t*)dh, (float*)workspace, M, Cout, HW, act, relu_mask, rpb);
     } else {

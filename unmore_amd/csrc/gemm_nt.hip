@@ -366,14 +366,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             }
             const int old = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old < 0 || old >= splits) __builtin_trap();   // a counter that was not zero on first use / was left by an aborted launch
+            // a counter that was not zero on first use / was left by an aborted launch.  No trap (it would kill the context of every
+            // stream of the process; include/umr.h: no entry point aborts): the event is counted in the workspace's error word
+            // (umr_gemm_nt_ws_status), the counter is healed for the next launch, and this workgroup stands down -- the tile's
+            // output is NOT written and must not be trusted until the status call returns zero bad tickets
+            const bool bad = old < 0 || old >= splits;
+            if (bad) {
+                __hip_atomic_fetch_add(counters + (UMR_SPLITK_COUNTERS - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             if (fenced) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            const int last = old == splits - 1;
+            const int last = !bad && old == splits - 1;
             if (last) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *(int*)smem = last;
         }
@@ -527,9 +535,8 @@ int umr_launch_gemm_nt256p(const umr_gemm_desc* d, hipStream_t s);  // gemm_nt25
 int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes, hipStream_t s);
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d);
 
-static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch
-    const char* e = getenv("UMR_GEMM_TILE");
-    return e ? atoi(e) : 0;
+static int tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); umr_set_debug_option switches it at run time
+    return umr_opt_or(UMR_OPT_GEMM_TILE, 0);
 }
 
 static bool uses_256(const umr_gemm_desc* d) {
@@ -557,6 +564,22 @@ extern "C" int umr_gemm_nt_rowreduce_ok(const umr_gemm_desc* d) {
 static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspace_bytes, umr_stream_t stream);
 
 extern "C" int umr_gemm_nt(const umr_gemm_desc* d, umr_stream_t stream) { return gemm_nt_impl(d, nullptr, 0, stream); }
+
+// The one diagnostic entry point that synchronises (include/umr.h): how many split-K tickets were out of range since the word was
+// last read (each one = an output tile that was not written), and the word is cleared.  The ticket counters of a launch use at most
+// the first 256 of the UMR_SPLITK_COUNTERS ints (pick_splits: tiles x splits <= 512, splits >= 2); the LAST int is this error word.
+extern "C" int umr_gemm_nt_ws_status(void* workspace, umr_stream_t stream, int* bad_tickets) {
+    UMR_CHECK_ARG(workspace != nullptr && bad_tickets != nullptr, "gemm_nt_ws_status: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int* word = (int*)workspace + (UMR_SPLITK_COUNTERS - 1);
+    int v = 0;
+    hipError_t e_ = hipMemcpyAsync(&v, word, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e_ == hipSuccess) e_ = hipStreamSynchronize(s);
+    if (e_ == hipSuccess && v != 0) e_ = hipMemsetAsync(word, 0, sizeof(int), s);
+    if (e_ != hipSuccess) return umr_set_error(UMR_ERR_HIP - (int)e_, hipGetErrorString(e_));
+    *bad_tickets = v;
+    return UMR_OK;
+}
 
 extern "C" int64_t umr_gemm_nt_workspace(void) { return (int64_t)UMR_SPLITK_COUNTERS * 4 + (int64_t)512 * BM * BN * 4; }   // 16 KiB + 32 MiB
 
@@ -586,9 +609,9 @@ static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
     const int bk = d->dtype == UMR_BF16 ? 64 : 32;
     const int nt = d->conv == 0 ? (d->K + bk - 1) / bk : 9 * ((d->Cin + bk - 1) / bk);   // K-tiles, as the kernel counts them
     int want;
-    const char* e = getenv("UMR_NT_SPLITK");
-    if (e) {
-        want = atoi(e);
+    const int forced = umr_opt(UMR_OPT_NT_SPLITK);
+    if (forced != UMR_OPT_UNSET) {
+        want = forced;
     } else {
         // measured (tools/probe/small_gemm.py, 1300 tokens): bf16 pays ~10 us for the slab round trip -- two ranges from
         // K = 2048 on (43 -> 33 us at K = 4096), never more; the f32 forms do 6-8x the matrix work per K-tile -- up to five
@@ -613,9 +636,8 @@ static int pick_splits(const umr_gemm_desc* d, int64_t tiles, bool have_ws) {
 
 template <typename T, int CV, int EPI, bool X3>
 static void launch_nt(dim3 g, hipStream_t s, const umr_gemm_desc* d, int tiles_n, int splits, float* skws) {
-    // UMR_SPLITK_FENCE=1 (read per launch): the textbook agent-scope release / acquire hand-over without a rebuild
-    const char* fe = splits > 1 ? getenv("UMR_SPLITK_FENCE") : nullptr;
-    const int splits_arg = (fe && atoi(fe) != 0) ? -splits : splits;
+    // UMR_SPLITK_FENCE=1 (umr_set_debug_option): the textbook agent-scope release / acquire hand-over without a rebuild
+    const int splits_arg = (splits > 1 && umr_opt_or(UMR_OPT_SPLITK_FENCE, 0) != 0) ? -splits : splits;
     hipLaunchKernelGGL((gemm_nt_kernel<T, CV, EPI, X3>), g, dim3(256), LDS_BYTES, s, *d, tiles_n, splits_arg, skws);
 }
 
@@ -685,10 +707,10 @@ static int gemm_nt_impl(const umr_gemm_desc* d, void* workspace, int64_t workspa
     if (uses_256(d)) return umr_launch_gemm_nt256(d, s);
     const int splits = pick_splits(d, grid, workspace != nullptr);
     float* skws = (float*)workspace;
-    // tile order per XCD (see the kernel): m fastest when the B operand is the larger one.  UMR_NT_ORDER=n|m forces an order (A/B; read per launch)
+    // tile order per XCD (see the kernel): m fastest when the B operand is the larger one.  UMR_NT_ORDER=n|m forces an order (A/B; umr_set_debug_option)
     {
-        const char* oe = getenv("UMR_NT_ORDER");
-        const bool mfast = oe ? (oe[0] == 'm') : (d->conv == 0 && d->a_rows_in <= 0 && (int64_t)d->N > (int64_t)d->M);
+        const int oe = umr_opt(UMR_OPT_NT_ORDER);
+        const bool mfast = oe != UMR_OPT_UNSET ? (oe == 'm') : (d->conv == 0 && d->a_rows_in <= 0 && (int64_t)d->N > (int64_t)d->M);
         if (mfast) tiles_n_arg = -tiles_m;
     }
     dim3 g((unsigned)(grid * splits)), b(256);

@@ -327,15 +327,14 @@ bool umr_nt256p_plain_epilogue(const umr_gemm_desc* d);
 
 // would umr_launch_gemm_nt256 hand d to the persistent kernel's fast epilogue?
 bool umr_nt256_rowreduce_path(const umr_gemm_desc* d) {
-    const char* e = getenv("UMR_NT256_PERSIST");
-    if (e && atoi(e) == 0) return false;
+    if (umr_opt_or(UMR_OPT_NT256_PERSIST, 1) == 0) return false;
     return ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1) && umr_nt256p_plain_epilogue(d);
 }
 
 // launched from umr_gemm_nt (gemm_nt.hip) for bf16 problems large enough to fill the chip with 256x256 tiles
 int umr_launch_gemm_nt256(const umr_gemm_desc* d, hipStream_t s) {
     {   // the persistent kernel covers plain GEMMs without A-row remap and stride-1 convs; UMR_NT256_PERSIST=0 disables it
-        static const int persist = umr_env_int("UMR_NT256_PERSIST", 1);
+        const int persist = umr_opt_or(UMR_OPT_NT256_PERSIST, 1);
         if (persist && ((d->conv == 0 && d->a_rows_in <= 0) || d->conv == 1)) return umr_launch_gemm_nt256p(d, s);
     }
     if (d->red_w || d->no_store) return umr_set_error(UMR_ERR_UNSUPPORTED, "gemm_nt: fused row reduction / no_store is only implemented by the persistent 256x256 path");

@@ -1091,8 +1091,7 @@ static void x3_plan(const umr_gemm_desc* d, int cus, int npairs, int64_t ws_byte
     const int tiles_n = (d->N + BN2 - 1) / BN2;
     const int kt = d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2);
     static const int forced = umr_env_int("UMR_X3_KSPLIT", 0);   // 0 = cost model; n = at most n runs (1 disables)
-    const char* bm_e = getenv("UMR_NT256_BM");                   // read per launch: tests switch it inside one process
-    const int bm_env = bm_e ? atoi(bm_e) : 0;
+    const int bm_env = umr_opt_or(UMR_OPT_NT256_BM, 0);          // tests switch it inside one process (umr_set_debug_option)
     const int64_t slab = (int64_t)d->M * d->N * 4;
     int best_ks = 1, best_bm = BM2;
     double best_cost = 1e300;
@@ -1141,8 +1140,7 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     // rounds x tile time (tile time ~ a fixed quarter -- epilogue, first-load latency -- plus the K loop, which scales with bm);
     // the waves that skip blocks are the non-ahead half, so the stagger has to be on.  UMR_NT256_BM forces a value.
     static const int stagger = umr_env_int("UMR_NT256_STAGGER", 1);   // A/B switch (0 = all waves in lock-step)
-    const char* bm_e = getenv("UMR_NT256_BM");   // read per launch: tests switch it inside one process
-    const int bm_env = bm_e ? atoi(bm_e) : 0;
+    const int bm_env = umr_opt_or(UMR_OPT_NT256_BM, 0);   // tests switch it inside one process (umr_set_debug_option)
     int bm = BM2;
     if (d->conv == 0 && d->dtype == UMR_BF16) {
         if (bm_env == 256 || bm_env == 224 || bm_env == 192) bm = bm_env;
@@ -1158,7 +1156,7 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     const int npairs_x3 = umr_f32_mode_now() == UMR_F32_X3_FAST ? 3 : 6;
     int ksplit = 1;
     if (d->dtype == UMR_BF16X3) x3_plan(d, cus, npairs_x3, ws != nullptr ? ws_bytes : 0, &bm, &ksplit);
-    if (d->dtype == UMR_BF16X3 && getenv("UMR_X3_TRACE"))   // one line per plane launch: shape and plan (tools/probe/x3_shapes.py sums them up)
+    if (d->dtype == UMR_BF16X3 && umr_opt(UMR_OPT_X3_TRACE) != UMR_OPT_UNSET)   // one line per plane launch: shape and plan (tools/probe/x3_shapes.py sums them up)
         fprintf(stderr, "x3 M=%d N=%d K=%d conv=%d Cin=%d ks=%d bm=%d flags=%u act=%d red=%d\n", d->M, d->N, d->K, d->conv, d->Cin, ksplit, bm,
                 (unsigned)d->flags, d->act, d->red_w != nullptr);
     const int tiles_m = (d->M + bm - 1) / bm;
@@ -1186,10 +1184,10 @@ int umr_launch_gemm_nt256p_ws(const umr_gemm_desc* d, void* ws, int64_t ws_bytes
     // fast class = bias / aux add / ReLU mask / ReLU with bf16 output and 16-B aligned strides
     const bool fast_ep = umr_nt256p_fast_epilogue(d);
     // K-tile form of a plain GEMM (see the kernel): two-phase from 8 K-tiles (X3: plane-pair steps) per output tile on.
-    // UMR_NT256_PH2=0|1 forces a form (read per launch: A/B, tests)
-    const char* ph_e = getenv("UMR_NT256_PH2");
+    // UMR_NT256_PH2=0|1 forces a form (A/B, tests: umr_set_debug_option)
+    const int ph_e = umr_opt(UMR_OPT_NT256_PH2);
     const int kt_steps = (d->conv == 0 ? d->K / BK2 : 9 * (d->Cin / BK2)) * (d->dtype == UMR_BF16X3 ? npairs_x3 : 1) / (ksplit > 1 ? ksplit : 1);
-    const bool two = ph_e ? (atoi(ph_e) != 0) : (kt_steps >= 8);
+    const bool two = ph_e != UMR_OPT_UNSET ? (ph_e != 0) : (kt_steps >= 8);
 #define L256P(CV, EP, AX, RD)                                                                                          \
     do {                                                                                                               \
         if (CV == 1 || two) {                                                                                          \

@@ -420,9 +420,8 @@ void umr_tn256_plan(const umr_gemm_tn_desc* d, int* splits, int* rows_per_split)
 int umr_launch_gemm_tn256(const umr_gemm_tn_desc* d, int splits, int rows_per_split, float* slab, float* bslab, hipStream_t s);
 namespace {
 
-static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests); read per launch, as umr_gemm_nt does
-    const char* e = getenv("UMR_GEMM_TILE");
-    return e ? atoi(e) : 0;
+static int tn_tile_override() {  // UMR_GEMM_TILE=128|256 forces a tile size (benchmarking, tests), as umr_gemm_nt does
+    return umr_opt_or(UMR_OPT_GEMM_TILE, 0);
 }
 
 TnPlan tn_plan(const umr_gemm_tn_desc* d) {
@@ -512,7 +511,8 @@ extern "C" int umr_gemm_tn(const umr_gemm_tn_desc* d, umr_stream_t stream) {
     float* slab = (float*)d->workspace;
     float* bslab = slab + (int64_t)pl.splits * d->N * d->K;
     // one split of the 128x128 kernel, nothing to add to: its "slab" IS dW (and its bias partials dbias) -- no reduce pass
-    const bool direct = !pl.big && pl.splits == 1 && !d->accumulate && d->lddw == d->K;
+    const bool direct = !pl.big && pl.splits == 1 && !d->accumulate && d->lddw == d->K &&
+                        ((uintptr_t)d->dW & 15) == 0;   // the kernel stores f32x4 (the reduce pass it replaces checks the same)
     if (direct) { slab = d->dW; bslab = d->dbias; }
     if (pl.big) {
         const int st = umr_launch_gemm_tn256(d, pl.splits, pl.rows_per_split, slab, bslab, s);

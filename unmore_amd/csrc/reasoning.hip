@@ -125,6 +125,140 @@ __global__ __launch_bounds__(256) void center_peaks_kernel(const float* __restri
     if (tid == 0) { maxval[b] = red_v[0]; argmax[b] = red_i[0]; }
 }
 
+// ---------------------------------------------------------------- centre peaks with an argmax certificate
+// The same peak picking, plus: is the flat argmax PROVABLY the one any pair of fields within `eps` (max-norm) of these would give?
+// (the argument of oracle/objectness_oracle.py::peak_certificate, restated on the device so that a sweep can run in a cheaper
+// arithmetic mode and re-run only what it cannot certify -- object_reasoning.py:525-557 is what consumes the index.)
+// Erosion is monotone: with F = the pixels whose union-mask decision (object_reasoning.py:528-533) a perturbation < eps can flip,
+// every reachable eroded mask lies between erode(union & ~F) and erode(union | F); a score moves by at most sqrt(2) * eps (24
+// unit-vector taps / 24).  Certified when
+//   (positive peak)  amax > 0, the peak survives in the SMALLEST mask, beats every other pixel of the LARGEST mask (and the zeros
+//                    outside it) by more than 2 sqrt(2) eps, and amax stays on its side of the singularity threshold (:541);
+//   (no peak)        amax == 0 at index 0 (a border pixel: exactly zero under any perturbation) and every pixel of the largest mask
+//                    scores below -2 sqrt(2) eps (or that mask is empty inside the border): the map stays without a positive score.
+// Six byte planes of H*W in LDS (three masks x two erosion buffers).
+__global__ __launch_bounds__(256) void center_peaks_cert_kernel(const float* __restrict__ sdf, const float* __restrict__ center,
+                                                                const double* __restrict__ filt, double* __restrict__ maxval,
+                                                                int64_t* __restrict__ argmax, int32_t* __restrict__ certified, PeakCfg cfg,
+                                                                float eps, double thres) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ double red_v[256], red_a[256], red_b[256];
+    __shared__ int red_i[256], red_ai[256];
+    const int H = cfg.H, W = cfg.W, HW = H * W;
+    unsigned char* mk[3][2];
+    for (int k = 0; k < 3; ++k) { mk[k][0] = lds + (2 * k) * HW; mk[k][1] = lds + (2 * k + 1) * HW; }
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* s = sdf + (int64_t)b * HW;
+    const float* c0 = center + (int64_t)b * 2 * HW;
+    const float* c1 = c0 + HW;
+    for (int i = tid; i < HW; i += 256) {
+        const float sv = s[i];
+        const float sg = 1.0f / (1.0f + expf(-sv));
+        const float nr = sqrtf(c0[i] * c0[i] + c1[i] * c1[i]);
+        const bool sb = sg > 0.5f, cb = nr > 0.5f;
+        const unsigned char u = (sb || cb) ? 1 : 0;
+        // distance of this pixel's decision to its threshold, in field units: |sdf| (sigmoid(s) > 0.5 <=> s > 0), | ||c|| - 0.5 |
+        const float ds = fabsf(sv), dc = fabsf(nr - 0.5f);
+        const float flip = (sb && cb) ? fmaxf(ds, dc) : sb ? ds : cb ? dc : fminf(ds, dc);
+        const bool f = flip < eps;
+        mk[0][0][i] = u;
+        mk[1][0][i] = f ? 0 : u;
+        mk[2][0][i] = f ? 1 : u;
+    }
+    __syncthreads();
+    const int rad = (cfg.erode_k - 1) / 2;
+    for (int round = 0; round < cfg.erode_rounds; ++round) {
+        for (int i = tid; i < HW; i += 256) {  // horizontal
+            const int y = i / W, x = i - y * W;
+            unsigned char ok0 = 1, ok1 = 1, ok2 = 1;
+            for (int d = -rad; d <= rad; ++d) {
+                const int xx = x + d;
+                const bool in = xx >= 0 && xx < W;
+                ok0 &= in ? mk[0][0][y * W + xx] : 0;
+                ok1 &= in ? mk[1][0][y * W + xx] : 0;
+                ok2 &= in ? mk[2][0][y * W + xx] : 0;
+            }
+            mk[0][1][i] = ok0; mk[1][1][i] = ok1; mk[2][1][i] = ok2;
+        }
+        __syncthreads();
+        for (int i = tid; i < HW; i += 256) {  // vertical
+            const int y = i / W, x = i - y * W;
+            unsigned char ok0 = 1, ok1 = 1, ok2 = 1;
+            for (int d = -rad; d <= rad; ++d) {
+                const int yy = y + d;
+                const bool in = yy >= 0 && yy < H;
+                ok0 &= in ? mk[0][1][yy * W + x] : 0;
+                ok1 &= in ? mk[1][1][yy * W + x] : 0;
+                ok2 &= in ? mk[2][1][yy * W + x] : 0;
+            }
+            mk[0][0][i] = ok0; mk[1][0][i] = ok1; mk[2][0][i] = ok2;
+        }
+        __syncthreads();
+    }
+    // scores on the largest mask (a superset of the actual one).  Per thread: the actual map's first maximum (as center_peaks_kernel),
+    // and the two largest scores of the largest mask with the first one's index
+    double best = -1.0e300, top1 = -1.0e300, top2 = -1.0e300;
+    int besti = 0, top1i = -1;
+    bool any = false;
+    for (int i = tid; i < HW; i += 256) {
+        const int y = i / W, x = i - y * W;
+        const bool inb = y >= cfg.border && y < H - cfg.border && x >= cfg.border && x < W - cfg.border;
+        double acc = 0.0;
+        const bool in_max = mk[2][0][i] && inb;
+        if (in_max) {
+            for (int ch = 0; ch < 2; ++ch) {
+                const float* cp = ch == 0 ? c0 : c1;
+                for (int fi = 0; fi < 5; ++fi) {
+                    const int yy = y + fi - 2;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int fj = 0; fj < 5; ++fj) {
+                        const int xx = x + fj - 2;
+                        if (xx < 0 || xx >= W) continue;
+                        acc += (double)cp[yy * W + xx] * filt[(ch * 5 + fi) * 5 + fj];
+                    }
+                }
+            }
+            acc = acc / 24.0;
+            if (acc > top1) { top2 = top1; top1 = acc; top1i = i; } else if (acc > top2) { top2 = acc; }
+        }
+        const double actual = mk[0][0][i] ? acc : 0.0;      // (the actual mask is inside the largest one)
+        if (!any || actual > best) { best = actual; besti = i; any = true; }
+    }
+    red_v[tid] = any ? best : -1.0e300;
+    red_i[tid] = any ? besti : 0x7FFFFFFF;
+    red_a[tid] = top1; red_ai[tid] = top1i; red_b[tid] = top2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double v2 = red_v[tid + off];
+            const int i2 = red_i[tid + off];
+            if (v2 > red_v[tid] || (v2 == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v2; red_i[tid] = i2; }
+            // merge two (top1, top2) pairs
+            const double a1 = red_a[tid], b1 = red_b[tid], a2 = red_a[tid + off], b2 = red_b[tid + off];
+            if (a2 > a1) { red_a[tid] = a2; red_ai[tid] = red_ai[tid + off]; red_b[tid] = a1 > b2 ? a1 : b2; }
+            else         { red_b[tid] = a2 > b1 ? a2 : b1; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double amax = red_v[0];
+        const int p = red_i[0];
+        maxval[b] = amax;
+        argmax[b] = p;
+        const double bound = 2.0 * 1.4142135623730951 * (double)eps;
+        int cert = 0;
+        if (amax > 0.0) {
+            // every other pixel of the largest mask, and the exact zeros outside it
+            double runner = red_ai[0] == p ? red_b[0] : red_a[0];
+            if (runner < 0.0 && HW > 1) runner = 0.0;
+            cert = mk[1][0][p] && (amax - runner > bound) && (fabs(amax - thres) > bound);
+        } else {
+            cert = amax == 0.0 && p == 0 && cfg.border >= 1 && (red_ai[0] < 0 || red_a[0] < -bound) && (fabs(thres) > bound);
+        }
+        certified[b] = cert;
+    }
+}
+
 // ---------------------------------------------------------------- boundary-field box deltas (object_reasoning.py:139-174)
 __global__ __launch_bounds__(256) void boundary_deltas_kernel(const float* __restrict__ sdf, float* __restrict__ deltas, int H, int W) {
     __shared__ float red[4][256];
@@ -196,6 +330,22 @@ extern "C" int umr_center_peaks(const float* sdf_maps, const float* center_field
     UMR_SET_MAX_LDS_ONCE(center_peaks_kernel, 150 * 1024);
     hipLaunchKernelGGL(center_peaks_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sdf_maps, center_fields, filter50, score_out,
                        max_values, argmax, cfg);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_center_peaks_certified(const float* sdf_maps, const float* center_fields, const double* filter50, double* max_values,
+                                          int64_t* argmax, int32_t* certified, int B, int H, int W, int border, int erode_kernel,
+                                          int erode_rounds, float eps, double singular_threshold, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && center_fields && filter50 && max_values && argmax && certified, "center_peaks_certified: null pointer");
+    UMR_CHECK_ARG(B > 0 && H > 0 && W > 0 && border >= 0 && erode_kernel >= 1 && (erode_kernel & 1) && erode_rounds >= 0 && eps >= 0.f,
+                  "center_peaks_certified: bad arguments");
+    if ((int64_t)H * W * 6 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "center_peaks_certified: map larger than the LDS mask planes (H*W <= 25600)");
+    PeakCfg cfg{H, W, border, erode_kernel, erode_rounds};
+    const size_t lds = (size_t)H * W * 6;
+    UMR_SET_MAX_LDS_ONCE(center_peaks_cert_kernel, 150 * 1024);
+    hipLaunchKernelGGL(center_peaks_cert_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sdf_maps, center_fields, filter50, max_values,
+                       argmax, certified, cfg, eps, singular_threshold);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -115,6 +115,20 @@ static __device__ uint4 umr_zero_page[16];
 #include <stdlib.h>
 static inline int umr_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+// Debug / A-B options that can change WHILE the process runs (tests and probes switch them between launches): include/umr.h,
+// umr_set_debug_option.  Each is read from the environment once, when the library is loaded; on the launch path an option costs one
+// relaxed atomic load -- no getenv per launch (round-5 review: getenv is not thread-safe against setenv and made the library's
+// behaviour depend on process-global state read 650-950 times per step).  umr_opt(): the value (an integer option: atoi of its
+// text; a letter option such as UMR_NT_ORDER=n|m: the first character's code) or UMR_OPT_UNSET.
+#include <limits.h>
+enum {
+    UMR_OPT_GEMM_TILE = 0, UMR_OPT_NT_SPLITK, UMR_OPT_SPLITK_FENCE, UMR_OPT_NT_ORDER, UMR_OPT_NT256_PERSIST, UMR_OPT_NT256_BM,
+    UMR_OPT_X3_TRACE, UMR_OPT_NT256_PH2, UMR_OPT_ATTN_BWD_FUSED, UMR_OPT_BILINEAR_GY, UMR_OPT_HEAD_OUT_BWD_GENERIC, UMR_OPT_COUNT
+};
+#define UMR_OPT_UNSET INT_MIN
+int umr_opt(int id);                                    // umr_api.hip
+static inline int umr_opt_or(int id, int dflt) { const int v = umr_opt(id); return v == UMR_OPT_UNSET ? dflt : v; }
+
 // host-side error plumbing (umr_api.hip)
 int umr_set_error(int code, const char* msg);
 int umr_f32_mode_now();   // umr_api.hip: UMR_F32_EXACT / UMR_F32_X3

@@ -185,10 +185,15 @@ class PackCache:
             e[2], e[3] = ev, {st.cuda_stream}
 
     def refresh_done(self):
-        """after the last (partial) refresh of a round: the copies that cannot be replayed are dropped (rebuilt on next use)"""
+        """after the last (partial) refresh of a round: the copies that cannot be replayed are dropped (rebuilt on next use).
+        Inside a capture, entries the capture built itself go silently (each of its replays rebuilds them); every OTHER dropped entry
+        -- e.g. the collapsed head's weights an evaluation call cached between a TrainStep's warm-up and its capturing step -- counts
+        as a change of the set, so an inference capture that read it (hit_o) is invalidated instead of replaying from freed memory."""
         if self._o:
+            cur = graphs.capture_store() if graphs.capturing() else None
+            foreign = cur is None or any(e[6] is not cur for e in self._o.values())
             self._o.clear()
-            if not graphs.capturing():   # (inside a capture every such entry was built by the capture itself and is rebuilt by each replay)
+            if foreign:
                 self.gen_o += 1
 
     def synced_with(self, stream):
@@ -200,13 +205,13 @@ class PackCache:
     def refreshed_by_replay(self, device):
         """A graph replay on the current stream has just re-run the optimizer step and the refresh: a consumer on another stream
         orders itself after it (one event for the whole cache instead of one per entry).  The replay updated the parameters on
-        the device without running this class's host code, so what refresh_done() does after an eager step is done here: copies
-        that cannot be replayed and were built OUTSIDE a capture (e.g. the collapsed head's weights an evaluation call cached
-        between two training steps) are stale now and are dropped; those a capture built itself are rewritten by each of its replays."""
-        stale = [k for k, e in self._o.items() if e[6] is None]
-        for k in stale:
-            del self._o[k]
-        if stale:
+        the device without running this class's host code, so what refresh_done() does after an eager step is done here: EVERY copy
+        that cannot be replayed is stale in this host-side dict now and is dropped -- those built outside a capture (the collapsed head's
+        weights an evaluation call cached between two training steps) and those an inference capture built inside itself: that capture
+        holds the addresses and rewrites them on each of its replays, but a cache HIT by anybody else (an eager call of another shape,
+        a second capture) would read what the first graph's LAST replay wrote, i.e. weights one or more steps old (round-5 advisor)."""
+        if self._o:
+            self._o.clear()
             self.gen_o += 1
         st = torch.cuda.current_stream(device)
         ev = torch.cuda.Event()
@@ -347,8 +352,8 @@ class Engine(X3Path):
         self.dt = compute_dtype
         self.cache = PackCache()
         # algebraic fast path for heads without non-linearities between their convs: "auto" (the net's
-        # default) = inference calls (no saved activations) evaluate such a head as ONE 3x3 convolution, training runs the four
-        # convolutions as the reference does; True = always (opt-in for training); False = never
+        # default) = such a head is evaluated as ONE 3x3 convolution at inference and, since round 6, in training whenever its
+        # backward is the algebraic one (_collapse); True = always; False = never (the four convolutions as the reference runs them)
         assert collapse_linear_heads in (False, True, "auto")
         self.collapse_linear_heads = collapse_linear_heads
 
@@ -380,7 +385,13 @@ class Engine(X3Path):
         its value, so its training step keeps the factored form whose backward gets the pre-activation)"""
         if lay["relu"] or (save and lay["final"] == "sine"):
             return False
-        return (not save) if self.collapse_linear_heads == "auto" else bool(self.collapse_linear_heads)
+        if self.collapse_linear_heads == "auto":
+            # inference: always.  Training: when the head's backward is the algebraic one (the default) -- that backward reads the
+            # head's OUTPUT only, so the 512 / 512 / 1024-channel maps of the four-convolution forward would be computed and thrown
+            # away (DESIGN.md section 7, round 6; qualified by tests/test_collapsed_train_gpu.py).  With the layer-by-layer GEMM
+            # backward (set_linear_head_backward('gemm')) the forward keeps the four convolutions whose activations it reads.
+            return (not save) or self.linear_head_backward == "algebraic"
+        return bool(self.collapse_linear_heads)
 
     def _linear_head_weights_cached(self, P, name, idx, dev):
         """inference: the collapsed weights (and the 16-row tap matrix in the compute dtype) per version of the head's eight

@@ -137,6 +137,11 @@ class Captured:
         return self.outs
 
 
+class _HostCall:
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class StagedCaptured:
     """A train step of a small problem captured as a CHAIN of graphs instead of one graph with forks.
 
@@ -167,6 +172,7 @@ class StagedCaptured:
     def __init__(self, fn, example_inputs, generation_of=None, on_fail=None):
         self.failed = None
         self.debug_side_delay = 0
+        self.debug_main_delay = 0
         self.segments = []          # (lane, CUDAGraph) in issue order
         self._gen_of = generation_of
         dev = example_inputs[0].device
@@ -205,7 +211,7 @@ class StagedCaptured:
             _state.update(capturing=False, store=None, forks=[], staged=None, lane=None)
             self._pending, self._keep = [], []       # the captures have ended: the kept tensors' blocks stay reserved in the graphs' pools
         self.generation = generation_of(self.store) if generation_of else None
-        self._events = [torch.cuda.Event() for lane_, _ in self.segments if lane_ == "side"]
+        self._events = [torch.cuda.Event() for lane_, _ in self.segments if lane_ in ("side", "scall")]
         torch.cuda.synchronize(dev)
 
     # ---- capture side (called through engine.WgradStream while fn runs)
@@ -217,30 +223,55 @@ class StagedCaptured:
 
     def _end(self):
         lane_, g, n0 = self._cur
-        if _launches[0] > n0:
+        # a cut right after a cut records nothing: torch warns about the empty graph, and that warning -- not the count of libumr
+        # launches -- is what says a segment may be dropped: a segment holding only torch kernels (.copy_ / .zero_ / torch.zeros of
+        # engine.backward) is work too and is replayed like any other
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
             g.capture_end()
-        else:
-            with warnings.catch_warnings():      # a cut right after a cut records nothing: torch warns about an empty graph, which is dropped
-                warnings.simplefilter("ignore")
-                g.capture_end()
+        empty = _launches[0] == n0 and any("empty" in str(w.message).lower() for w in caught)
+        for w in caught:
+            if "empty" not in str(w.message).lower():
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
         self._cur = None
         _state["lane"] = None
-        if _launches[0] > n0:            # (a segment without a launch is not replayed)
+        if not empty:
             self.segments.append((lane_, g))
 
     def defer(self, fn, used):
         self._pending.append(fn)
         self._keep.extend(t for t in used if t is not None)
 
+    def defer_host(self, fn):
+        """a HOST action that belongs behind the side-lane work deferred so far -- a collective on the gradient bucket those launches
+        complete (data-parallel steps: trainer.TrainStep, parallel.BucketedAllReduce.ready).  Collectives are not captured: the chain is
+        cut here, and a replay calls fn() between two graph launches with the SIDE stream current, so the collective's own stream
+        orders itself behind the stage's weight gradients and the main lane never waits for it."""
+        self._pending.append(_HostCall(fn))
+
+    def host_call(self, fn):
+        """a host action on the MAIN lane between two graphs of the chain (BucketedAllReduce.finish: the main stream waits for every
+        collective before the optimizer update)"""
+        self.boundary()
+        self._end()
+        self.segments.append(("call", fn))
+        self._begin("main")
+
     def boundary(self):
-        """end of a stage of backward: what was deferred since the last boundary becomes the stage's side graph"""
+        """end of a stage of backward: what was deferred since the last boundary becomes the stage's side graph (host actions deferred
+        among it cut that graph: launches before -- graph -- host call -- launches after)"""
         if not self._pending:
             return
         self._end()
-        self._begin("side")
         pend, self._pending = self._pending, []
+        self._begin("side")
         for fn in pend:
-            fn()
+            if isinstance(fn, _HostCall):
+                self._end()
+                self.segments.append(("scall", fn.fn))
+                self._begin("side")
+            else:
+                fn()
         self._end()
         self._begin("main")
 
@@ -266,9 +297,20 @@ class StagedCaptured:
         k = 0
         for lane_, g in self.segments:
             if lane_ == "main":
-                g.replay()
+                if self.debug_main_delay:              # test hook, the mirror image of debug_side_delay: the main lane is held back before
+                    torch.cuda._sleep(self.debug_main_delay)   # every segment, so the side lane's updates of stage k are long done when the
+                g.replay()                             # main lane runs stage k+1.. -- which must therefore not read stage k's weights again
             elif lane_ == "join":
                 main.wait_stream(side)
+            elif lane_ == "call":
+                g()                                    # host action with the main stream current (BucketedAllReduce.finish)
+            elif lane_ == "scall":
+                ev = self._events[k]                   # host action with the side stream current, behind everything the main lane has
+                k += 1                                 # enqueued so far (a collective on a bucket whose last producers may be main-lane kernels)
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    g()
             else:
                 ev = self._events[k]
                 k += 1

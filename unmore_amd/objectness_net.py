@@ -213,10 +213,14 @@ class ObjectnessNet(nn.Module):
         objectness_net.py:119-142,128-135) is evaluated.  Its four convolutions compose to ONE 3x3 conv 256 -> 1 plus a
         border-dependent bias (csrc/linear_head.hip).
         'auto' (default): inference calls (torch.no_grad() / no parameter requires grad -- object_reasoning.py:326,351,413) use
-        that collapsed form; training runs the four convolutions as the reference does.  Qualified against every reference-made
-        forward fixture at the 1e-4 contract and through the peak chain (tests/test_collapsed_head_gpu.py).
-        'factored': always the four convolutions (the A/B switch).  'collapsed': the collapsed form in training too (exact
-        gradients of all factored weights; ~45 % fewer step FLOPs; opt-in, never the benchmark's `value`)."""
+        that collapsed form (round 5; qualified against every reference-made forward fixture at the 1e-4 contract and through the
+        peak chain, tests/test_collapsed_head_gpu.py), and so do training steps whose backward of that head is the algebraic one
+        (the default, set_linear_head_backward): that backward reads the head's output only, so the four convolutions' 512 / 512 /
+        1024-channel maps would be computed and thrown away (round 6; loss and every gradient against the float64 oracle at the
+        suite's bars, tests/test_collapsed_train_gpu.py).  'sine' in training and every ReLU variant run the four convolutions.
+        The weights stay factored: same state_dict schema, same eight gradient tensors.
+        'factored': always the four convolutions as the reference runs them (the A/B switch; bench.py's alt_factored_sdf_head).
+        'collapsed': the collapsed form wherever the head allows it, whatever the backward mode."""
         assert mode in ("auto", "factored", "collapsed")
         self.sdf_head_mode = mode
         self._eng = None

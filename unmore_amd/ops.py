@@ -67,6 +67,28 @@ def set_cu_budget(cus):
     return prev
 
 
+def set_debug_option(name, value):
+    """A debug / A-B option of the library (include/umr.h, umr_set_debug_option; names: csrc/umr_common.h): value = the text the
+    environment variable of that name would hold, None = unset.  The library reads the environment once, when it is loaded; this is
+    how tests and probes switch an option between launches.  Returns the previous value (int, or None if it was unset)."""
+    import ctypes
+    v, isset = ctypes.c_int(0), ctypes.c_int(0)
+    L.check(L.lib().umr_get_debug_option(name.encode(), ctypes.byref(v), ctypes.byref(isset)), "umr_get_debug_option")
+    L.check(L.lib().umr_set_debug_option(name.encode(), None if value is None else str(value).encode()), "umr_set_debug_option")
+    return v.value if isset.value else None
+
+
+def splitk_bad_tickets(device=None):
+    """Diagnostic (synchronises the current stream): out-of-range split-K tickets counted on the current stream's GEMM workspace
+    since the last call (include/umr.h, umr_gemm_nt_ws_status); 0 = every split GEMM wrote all of its tiles."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    ws = _splitk_workspace(dev)
+    n = ctypes.c_int(0)
+    L.check(L.lib().umr_gemm_nt_ws_status(ctypes.c_void_p(ws.data_ptr()), ctypes.c_void_p(_stream_id(dev.index)), ctypes.byref(n)), "umr_gemm_nt_ws_status")
+    return n.value
+
+
 _ws_cache = {}
 
 

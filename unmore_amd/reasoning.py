@@ -64,6 +64,23 @@ def center_peaks(sdf_maps, center_fields, border=10, erode_kernel=9, erode_round
     return (mx, am, sc) if return_scores else (mx, am)
 
 
+def center_peaks_certified(sdf_maps, center_fields, eps, singular_threshold=0.009, border=10, erode_kernel=9, erode_rounds=3):
+    """center_peaks plus, per map, whether its flat argmax is provably what ANY fields within `eps` (max-norm) of these would give
+    (include/umr.h, umr_center_peaks_certified; singular_threshold: object_reasoning.py:541).
+    Returns (max score [B] f64, flat argmax [B] int64, certified [B] bool)."""
+    _need_gpu(sdf_maps, center_fields)
+    sdf = sdf_maps.contiguous().float()
+    cen = center_fields.contiguous().float()
+    B, H, W = sdf.shape
+    mx = torch.empty(B, dtype=torch.float64, device=sdf.device)
+    am = torch.empty(B, dtype=torch.int64, device=sdf.device)
+    ce = torch.empty(B, dtype=torch.int32, device=sdf.device)
+    L.check(L.lib().umr_center_peaks_certified(_p(sdf), _p(cen), _p(_anti_center_filter(sdf.device)), _p(mx), _p(am), _p(ce), B, H, W, border,
+                                               erode_kernel, erode_rounds, float(eps), float(singular_threshold), _stream()),
+            "umr_center_peaks_certified")
+    return mx, am, ce != 0
+
+
 def update_bbox_with_boundary_fields(sdf_maps):
     """object_reasoning.py:139-174: (delta_x1, delta_y1, delta_x2, delta_y2), each [B]."""
     _need_gpu(sdf_maps)
@@ -110,13 +127,52 @@ def get_prediction_with_proposals(objectness_model, binary_classifier_model, ima
 _sweep_streams = {}
 
 
-def sweep_proposals(objectness_model, image, proposals, num_img_per_batch=50, n_streams=3):
+CERT_EPS = 2e-4     # the field perturbation the certificate covers: twice the 1e-4 parity contract (tests/golden/make_golden_r2.py: CERT_EPS)
+
+
+def _sweep_pass(objectness_model, image, props, num_img_per_batch, streams, cur, certify):
+    outs = []
+    for s in streams:
+        s.wait_stream(cur)
+    for bi, i in enumerate(range(0, len(props), num_img_per_batch)):
+        st = streams[bi % len(streams)]
+        with torch.cuda.stream(st):
+            crops, _ = crop_resize(image, props[i:i + num_img_per_batch], 128)
+            with torch.no_grad():
+                pred = objectness_model.get_prediction(crops)
+            sdf = pred["sdf_maps"].squeeze(1)
+            if certify:
+                mx, am, ce = center_peaks_certified(sdf, pred["center_fields"], CERT_EPS)
+            else:
+                mx, am = center_peaks(sdf, pred["center_fields"])
+                ce = torch.ones_like(am, dtype=torch.bool)
+            d = torch.stack(update_bbox_with_boundary_fields(sdf), 1)
+            # the results are consumed (torch.cat) on the caller's stream after cur.wait_stream(st): tell the allocator, so the
+            # blocks are not handed to the next batch of this side stream before that read has run
+            for t in (mx, am, d, ce):
+                t.record_stream(cur)
+            outs.append((mx, am, d, ce))
+    for s in streams:
+        cur.wait_stream(s)
+    return tuple(torch.cat([o[k] for o in outs]) for k in range(4))
+
+
+def sweep_proposals(objectness_model, image, proposals, num_img_per_batch=50, n_streams=3, precision="full", info=None):
     """The per-proposal part of `center_reasoning` + the first half of `optimize_one_image_single_round` for ALL proposals of an
     image (object_reasoning.py:301-337,528-550,139-174): crop + resize, ObjectnessNet maps, centre peaks, boundary box deltas,
     in the reference's batches of 50.  Batches are independent, so consecutive batches are enqueued on `n_streams` HIP streams
     in turn: one batch's chain of ~330 small dependent kernels overlaps the other's large head convolutions (results are
     identical to the sequential order -- every batch runs the same kernels on the same data).
+    precision (fp32 compute mode only; bf16 nets ignore it):
+      'full'      every proposal in the library's current f32 product mode (default: six-term fp32-grade products);
+      'certified' certificate-driven (round 6): pass 1 runs every proposal with THREE-term products (ops.set_f32_mode('x3_fast'):
+                  maps within ~4e-5 of the six-term ones, half the matrix work) and asks the device, per proposal, whether its peak
+                  index is provably the one ANY fields within CERT_EPS = 2e-4 of these maps would give (center_peaks_certified); pass 2
+                  re-runs only the proposals without that certificate in the full mode and takes their results from there.  Costs one
+                  host synchronisation per image (the reference synchronises per proposal, object_reasoning.py:546-550).
+    info: an optional dict that receives {'proposals', 'rerun', 'certified_in_pass1'}.
     Returns (max_values [N] f64, flat_argmax [N] i64, deltas [N,4] f32) on the device."""
+    from . import ops
     _need_gpu(image)
     dev = image.device
     key = (dev.index, n_streams)
@@ -125,23 +181,24 @@ def sweep_proposals(objectness_model, image, proposals, num_img_per_batch=50, n_
     streams = _sweep_streams[key]
     props = torch.as_tensor(proposals, dtype=torch.float64)
     cur = torch.cuda.current_stream(dev)
-    outs = []
-    for s in streams:
-        s.wait_stream(cur)
-    for bi, i in enumerate(range(0, len(props), num_img_per_batch)):
-        st = streams[bi % n_streams]
-        with torch.cuda.stream(st):
-            crops, _ = crop_resize(image, props[i:i + num_img_per_batch], 128)
-            with torch.no_grad():
-                pred = objectness_model.get_prediction(crops)
-            sdf = pred["sdf_maps"].squeeze(1)
-            mx, am = center_peaks(sdf, pred["center_fields"])
-            d = torch.stack(update_bbox_with_boundary_fields(sdf), 1)
-            # the results are consumed (torch.cat) on the caller's stream after cur.wait_stream(st): tell the allocator, so the
-            # blocks are not handed to the next batch of this side stream before that read has run
-            for t in (mx, am, d):
-                t.record_stream(cur)
-            outs.append((mx, am, d))
-    for s in streams:
-        cur.wait_stream(s)
-    return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs]), torch.cat([o[2] for o in outs])
+    certified_mode = (precision == "certified" and getattr(objectness_model, "compute_dtype", torch.float32) == torch.float32
+                      and ops.get_f32_mode() == "x3")
+    assert precision in ("full", "certified")
+    if not certified_mode:
+        mx, am, d, _ = _sweep_pass(objectness_model, image, props, num_img_per_batch, streams, cur, certify=False)
+        if info is not None:
+            info.update(proposals=len(props), rerun=0, certified_in_pass1=None)
+        return mx, am, d
+    prev = ops.set_f32_mode("x3_fast")
+    try:
+        mx, am, d, ce = _sweep_pass(objectness_model, image, props, num_img_per_batch, streams, cur, certify=True)
+    finally:
+        ops.set_f32_mode(prev)
+    redo = torch.nonzero(~ce).flatten().cpu()          # the one host synchronisation of the image
+    if info is not None:
+        info.update(proposals=len(props), rerun=int(redo.numel()), certified_in_pass1=int(len(props) - redo.numel()))
+    if redo.numel():
+        mx2, am2, d2, _ = _sweep_pass(objectness_model, image, props[redo], num_img_per_batch, streams, cur, certify=False)
+        idx = redo.to(dev)
+        mx[idx], am[idx], d[idx] = mx2, am2, d2
+    return mx, am, d

@@ -65,7 +65,10 @@ def filter_batch(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps):
 
 class TrainStep:
     def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, center_field_loss_type="l2", sdf_loss_type="l1",
-                 use_sdf_gradient_loss=True, use_sdf_binary_mask_loss=True, lr_milestones=(), lr_gamma=1.0, group=None):
+                 use_sdf_gradient_loss=True, use_sdf_binary_mask_loss=True, lr_milestones=(), lr_gamma=1.0, group=None,
+                 grad_wire_dtype=None):
+        """grad_wire_dtype (data-parallel runs only): None / env UMR_DP_WIRE unset = the f32 gradient buckets are all-reduced as they
+        are; torch.bfloat16 / UMR_DP_WIRE=bf16 = bf16 copies are exchanged (parallel.BucketedAllReduce: half the bytes per link)."""
         self.net = net
         self.lr0, self.betas, self.eps = lr, betas, eps
         self.milestones, self.gamma = tuple(lr_milestones), lr_gamma
@@ -91,11 +94,14 @@ class TrainStep:
                 self.G[n] = self.flat_g[o:o + p.numel()].view(p.shape)
         self.P = {n: p for n, p in net.named_parameters()}
         self._offs = offs
-        self.comm = BucketedAllReduce(self.flat_g, bounds, group)
+        if grad_wire_dtype is None and os.environ.get("UMR_DP_WIRE", "") == "bf16":
+            grad_wire_dtype = torch.bfloat16
+        self.comm = BucketedAllReduce(self.flat_g, bounds, group, wire_dtype=grad_wire_dtype)
         self._hyper = torch.zeros(8, dtype=torch.float32, device=dev)   # Adam's per-step scalars (ops.adam_set_hyper)
         self.graph_mode = graphs.DEFAULT_MODE
         self._graphs = {}           # (input shape, dtype, f32 mode, stream) -> eager-call count, then graphs.Captured
         self.graph_replays = 0
+        self.poisoned = None        # set when a step raised in mid-flight (step()); cleared by load_optimizer_state_dict
         net._engine().cache.clear()
 
     def current_lr(self):
@@ -119,9 +125,17 @@ class TrainStep:
             if hi > lo:
                 ops.adam_step_hyper(self.flat_p[lo:hi], self.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], self._hyper)
 
+        # a staged capture in progress (graphs.StagedCaptured): collectives are not captured -- the chain is cut at the bucket
+        # boundaries it already has, and a replay issues each bucket's all-reduce between two graph launches (on the side lane,
+        # behind the stage's weight gradients; the main lane waits for the exchange only in finish(), before the optimizer update)
+        staged = graphs.staged() if self.comm.enabled else None
+
         def stage_done(stage, wg):
             k = self.stage_bucket[stage]
-            self.comm.ready(k)
+            if staged is not None:
+                staged.defer_host(lambda k=k: self.comm.ready(k))
+            else:
+                self.comm.ready(k)
             # (not the reassemble stage: the readout projections are read again when the transformer's backward reaches a hooked
             # block -- the token gradient goes through them, models/dpt/vit.py:86-90 -- so they are updated after backward)
             if wg.on and not self.comm.enabled and _BATCHED_REPACK and stage != "reassemble":
@@ -134,8 +148,11 @@ class TrainStep:
                 wg.run(launch)
                 updated.add(k)
 
-        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=stage_done, join_at_stages=self.comm.enabled)
-        self.comm.finish()
+        eng.backward(self.P, S, dpc, dps, self.G, stage_cb=stage_done, join_at_stages=self.comm.enabled and staged is None)
+        if staged is not None:
+            staged.host_call(self.comm.finish)
+        else:
+            self.comm.finish()
         if not updated:
             ops.adam_step_hyper(self.flat_p, self.flat_g, self.m, self.v, self._hyper)
             # the packed (kernel-layout) weight copies are stale after the in-place update: refreshed in one launch
@@ -158,7 +175,9 @@ class TrainStep:
         two eager steps of the same shape as a chain of per-stage HIP graphs and replayed on two streams (graphs.StagedCaptured:
         bit-identical to the eager step, host enqueue 18.7 -> 1.0 ms, 873 -> 904 images/s on the reference recipe); large ones run
         eagerly (GPU-bound, < 3 % of the step is host time).  'on' captures any size, 'off' nothing.  Data-parallel runs
-        (world > 1) always run eagerly: their collectives are not captured."""
+        (world > 1) replay the same chain where the chain form applies (small problems): the gradient all-reduces are not captured
+        but issued between the chain's graph launches at the bucket boundaries it is cut at (round 6); larger data-parallel steps
+        run eagerly."""
         assert mode in ("auto", "on", "off")
         self.graph_mode = mode
         self._graphs.clear()
@@ -169,11 +188,23 @@ class TrainStep:
         if images.shape[0] == 0:
             # the reference would take the mean of empty maps (NaN) and push NaN gradients into Adam; refuse instead
             raise ValueError("TrainStep.step: empty batch (every image was filtered out); skip this iteration")
-        # the step count and the schedule advance only once the step's launches are enqueued: a body or capture that raises leaves
-        # `iter` (and with it the checkpoint's 'iter' and the learning-rate schedule) where the last applied update put it
+        # the step count and the schedule advance only once the step's launches are enqueued: a body that raises leaves `iter` (and
+        # with it the checkpoint's 'iter' and the learning-rate schedule) where the last COMPLETE update put it -- and poisons this
+        # object, because finished stages of the failed step may already have been updated (a failed CAPTURE does not raise: it
+        # falls back to the eager body within the same call)
+        if self.poisoned is not None:
+            raise RuntimeError("TrainStep: an earlier step raised after part of its optimizer update was enqueued (" + self.poisoned +
+                               "); weights and Adam state no longer match `iter` -- reload a checkpoint (model.load_state_dict, "
+                               "load_optimizer_state_dict, sync_from_model) before the next step")
         it = self.iter + 1
-        ops.adam_set_hyper(self._hyper, it, self.lr_of_step(it), self.betas[0], self.betas[1], self.eps, 1.0 / self.comm.world)
-        out5 = self._launch_step(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
+        ops.adam_set_hyper(self._hyper, it, self.lr_of_step(it), self.betas[0], self.betas[1], self.eps, self.comm.grad_scale)
+        try:
+            out5 = self._launch_step(images, gt_center_fields, gt_sdf_maps, gt_saliency_maps)
+        except BaseException as e:
+            # an eager two-stream body that raises in mid-backward has already enqueued the Adam updates of the stages it finished
+            # (with step index `it`): a retried step would apply that index to those stages a second time.  Refuse to continue.
+            self.poisoned = f"{type(e).__name__}: {e}"
+            raise
         self.iter = it
         return out5
 
@@ -183,7 +214,10 @@ class TrainStep:
         B, _, H, W = images.shape
         from .engine import WgradStream
         two = WgradStream.wanted(B * H * W)
-        if not self.comm.enabled and graphs.wanted(self.graph_mode, B * H * W, train=True, two_streams=two) and ops._timer["select"] is None:
+        # data-parallel steps replay only as a chain of per-stage graphs (its cuts are where the collectives go); a single graph cannot
+        # hold them and such a step stays eager
+        if ((not self.comm.enabled or (graphs.STAGED and two)) and graphs.wanted(self.graph_mode, B * H * W, train=True, two_streams=two)
+                and ops._timer["select"] is None):
             key = (tuple(images.shape), eng.dt, ops.get_f32_mode(), torch.cuda.current_stream(images.device).cuda_stream)
             ent = self._graphs.get(key)
             if isinstance(ent, graphs.CAPTURE_TYPES):
@@ -255,6 +289,7 @@ class TrainStep:
             step = max(step, int(float(st["step"])))
         self.iter = int(iteration) if iteration is not None else step
         assert self.iter == step or not sd["state"], "Adam step count and checkpoint iteration disagree"
+        self.poisoned = None
 
     def sync_from_model(self):
         """Call after model.load_state_dict(): the flat parameter buffer is the storage of the parameters, so loading writes

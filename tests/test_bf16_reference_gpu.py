@@ -46,8 +46,10 @@ def _err(a, ref):
 # bars: (max, rms) per map -- measured on the MI355X (printed below), ~2x head-room; the maps are O(1) (tanh output, unit vectors)
 @pytest.mark.parametrize("mode", ["auto", "factored"])
 @pytest.mark.parametrize("backbone,tag,fname,B,size,seed,bars", [
-    ("dpt_base", "base", "fwd_dpt_base_384_sampled.npz", 1, 384, 11, dict(center=(3e-2, 6e-3), sdf=(3e-2, 6e-3))),
-    ("dpt_small", "dpt_small", "fwd_dpt_small_224_sampled.npz", 2, 224, 12, dict(center=(3e-2, 6e-3), sdf=(3e-2, 6e-3))),
+    # measured (round 6, MI355X): 384x384 ViT-B -- centre field max 1.73e-2 / rms 5.6e-3, boundary distance 8.6e-3 / 2.5e-3 (collapsed head;
+    # four convolutions 9.1e-3 / 2.9e-3); 224x224 ViT-S -- 1.64e-2 / 4.3e-3 and 1.02e-2 / 3.5e-3
+    ("dpt_base", "base", "fwd_dpt_base_384_sampled.npz", 1, 384, 11, dict(center=(3.5e-2, 1.2e-2), sdf=(2e-2, 7e-3))),
+    ("dpt_small", "dpt_small", "fwd_dpt_small_224_sampled.npz", 2, 224, 12, dict(center=(3.5e-2, 1.0e-2), sdf=(2e-2, 7e-3))),
 ])
 def test_bf16_forward_against_reference_made_sampled_fixtures(golden_dir, backbone, tag, fname, B, size, seed, bars, mode):
     g = np.load(os.path.join(golden_dir, fname))
@@ -127,9 +129,11 @@ def test_bf16_gradients_against_the_float64_oracle_at_dpt_base():
           f"{n_flip} of {n_sites} ReLU decisions differ from float64's own ({n_flip / n_sites:.2e}); "
           f"on the bf16 path's linear piece: global cosine {cm[0]:.6f}, worst per-tensor cosine {cm[1]:.4f} ({cm[2]}), worst relative L2 {cm[3]:.3f}; "
           f"un-masked: global cosine {um[0]:.6f}, worst per-tensor cosine {um[1]:.4f} ({um[2]}), worst relative L2 {um[3]:.3f}")
-    # bars from measurement on the MI355X (see the printed line), with head-room
-    assert cm[0] > 0.999 and cm[1] > 0.99 and cm[3] < 0.12, cm
-    assert um[0] > 0.995 and um[1] > 0.97, um
+    # bars from measurement on the MI355X (round 6: on the bf16 path's linear piece global cosine 0.999956, worst per-tensor cosine 0.9998,
+    # worst relative L2 0.017; un-masked 0.999940 / 0.9995 / 0.033; 2.9e-3 of the ReLU decisions differ from float64's own), ~2x head-room
+    # on 1 - cosine and on the relative L2
+    assert cm[0] > 0.9999 and cm[1] > 0.9995 and cm[3] < 0.035, cm
+    assert um[0] > 0.9998 and um[1] > 0.999 and um[3] < 0.07, um
 
 
 def test_bf16_vs_fp32_hip_at_the_cfg4_batch():

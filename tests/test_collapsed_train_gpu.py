@@ -76,8 +76,8 @@ def test_variants_that_must_stay_factored_train_bit_identically_to_factored_mode
         assert (g is None and ga is None) or torch.equal(g, ga), n
 
 
-@pytest.mark.parametrize("act", ["tanh", None])
-@pytest.mark.parametrize("backbone,tag,B,H,W", [("dpt_tiny", "tiny", 2, 64, 96), ("dpt_base", "base", 2, 128, 128)])
+@pytest.mark.parametrize("backbone,tag,B,H,W,act", [("dpt_tiny", "tiny", 2, 64, 96, "tanh"), ("dpt_tiny", "tiny", 2, 64, 96, None),
+                                                     ("dpt_base", "base", 2, 128, 128, "tanh"), ("dpt_base", "base", 1, 128, 96, None)])
 def test_three_default_train_steps_against_the_float64_oracle(backbone, tag, B, H, W, act):
     """TrainStep in the default mode (collapsed forward, algebraic backward).  Before each of three optimizer steps the net's CURRENT
     weights go through tests/grad_common.masked_gradient_check: loss within 1e-4 of the float64 oracle's, both maps within 1e-4,

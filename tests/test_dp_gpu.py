@@ -101,35 +101,48 @@ def test_two_rank_step_equals_single_process_on_global_batch(tmp_path, backbone,
     assert bad <= 2e-3 * p_1.numel(), (bad, p_1.numel())
 
 
-def _worker_chain(rank, world, port, out_dir, backbone, tag, B, H, W, dtype_name, mode, wire):
+def _worker_chain(rank, world, port, out_dir, backbone, tag, B, H, W, dtype_name):
+    """the three variants one after the other in ONE process group (a process start + import per variant costs more than its steps)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from argparse import Namespace
     from unmore_amd import graphs, synth
+    from unmore_amd.objectness_net import ObjectnessNet
     from unmore_amd.trainer import TrainStep
-    net = _make_net(backbone, tag)
-    net.set_compute_dtype(getattr(torch, dtype_name))
-    step = TrainStep(net, lr=1e-4, grad_wire_dtype=(torch.bfloat16 if wire == "bf16" else None)).set_graph_mode(mode)
-    assert step.comm.enabled and step.comm.world == world
-    losses = []
-    for it in range(6):
-        img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(world * B, H, W, seed=40 + it))
-        sl = slice(rank * B, (rank + 1) * B)
-        losses.append(step.step(img[sl], cf[sl], sdf[sl], sal[sl]).cpu())
-    torch.cuda.synchronize()
-    ref = step.flat_p.clone()
-    dist.broadcast(ref, 0)
-    assert torch.equal(ref, step.flat_p), "ranks diverged"
-    if mode != "off":
-        assert step.graph_replays == 4, step.graph_replays                       # two eager warm-ups, then the chain
-        caps = [c for c in step._graphs.values() if isinstance(c, graphs.StagedCaptured)]
-        assert len(caps) == 1 and any(l == "scall" for l, _ in caps[0].segments) and any(l == "call" for l, _ in caps[0].segments)
-    else:
-        assert step.graph_replays == 0
-    if rank == 0:
-        torch.save({"flat_p": step.flat_p.cpu(), "flat_g": step.flat_g.cpu(), "losses": torch.stack(losses)}, os.path.join(out_dir, f"{mode}_{wire}.pt"))
-    dist.barrier()
+    torch.manual_seed(0)                         # identical initial weights on both ranks and in every variant (default nn init)
+    init = {k: v.clone() for k, v in ObjectnessNet("cpu", H, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh")).state_dict().items()}
+    for mode, wire in (("off", "f32"), ("auto", "f32"), ("auto", "bf16")):
+        net = ObjectnessNet("cuda:0", H, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+        net.load_state_dict(init, strict=True)
+        net = net.to("cuda:0")
+        net.set_compute_dtype(getattr(torch, dtype_name))
+        step = TrainStep(net, lr=1e-4, grad_wire_dtype=(torch.bfloat16 if wire == "bf16" else None)).set_graph_mode(mode)
+        assert step.comm.enabled and step.comm.world == world
+        losses, first_g = [], None
+        for it in range(6):
+            img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(world * B, H, W, seed=40 + it))
+            sl = slice(rank * B, (rank + 1) * B)
+            losses.append(step.step(img[sl], cf[sl], sdf[sl], sal[sl]).cpu())
+            if it == 0:
+                first_g = step.flat_g.cpu()          # the first step's exchanged gradient: same weights in every variant
+        torch.cuda.synchronize()
+        ref = step.flat_p.clone()
+        dist.broadcast(ref, 0)
+        assert torch.equal(ref, step.flat_p), "ranks diverged"
+        if mode != "off":
+            assert step.graph_replays == 4, step.graph_replays                       # two eager warm-ups, then the chain
+            caps = [c for c in step._graphs.values() if isinstance(c, graphs.StagedCaptured)]
+            assert len(caps) == 1 and any(l == "scall" for l, _ in caps[0].segments) and any(l == "call" for l, _ in caps[0].segments)
+        else:
+            assert step.graph_replays == 0
+        if rank == 0:
+            torch.save({"flat_p": step.flat_p.cpu(), "flat_g": step.flat_g.cpu(), "first_g": first_g, "losses": torch.stack(losses)},
+                       os.path.join(out_dir, f"{mode}_{wire}.pt"))
+        del step, net
+        torch.cuda.empty_cache()
+        dist.barrier()
     dist.destroy_process_group()
 
 
@@ -142,16 +155,17 @@ def test_data_parallel_step_replays_the_chain_of_graphs_bit_identically(tmp_path
     ('auto') against six eager steps ('off'): losses, exchanged gradients and weights bit-identical.  And the bf16 gradient wire
     against the f32 wire: same schedule, exchanged gradient within bf16 rounding."""
     world = 2
-    for mode, wire in (("off", "f32"), ("auto", "f32"), ("auto", "bf16")):
-        mp.spawn(_worker_chain, args=(world, _free_port(), str(tmp_path), backbone, tag, B, H, W, dtype_name, mode, wire), nprocs=world, join=True)
+    mp.spawn(_worker_chain, args=(world, _free_port(), str(tmp_path), backbone, tag, B, H, W, dtype_name), nprocs=world, join=True)
     off, auto, wired = (torch.load(os.path.join(tmp_path, f"{m}_{w}.pt")) for m, w in (("off", "f32"), ("auto", "f32"), ("auto", "bf16")))
     assert torch.equal(off["losses"], auto["losses"])
     assert torch.equal(off["flat_g"], auto["flat_g"]) and torch.equal(off["flat_p"], auto["flat_p"])
-    # bf16 wire: the first step's loss is the same forward; the last exchanged gradient (already the mean over ranks) against the f32
-    # exchange's sum / world.  The two runs' weights have parted by then (five different updates), so the bar is loose on purpose --
-    # the exact bar of the exchange itself is tests/test_parallel_cpu.py's 6e-3
-    assert torch.equal(off["losses"][0], wired["losses"][0])
-    a, b = wired["flat_g"].double(), off["flat_g"].double() / world
+    # bf16 wire: the first step runs on the same weights in every variant -- same loss, and its exchanged gradient (already the mean over
+    # ranks) equals the f32 exchange's sum / world to bf16 rounding: relative L2 <= 6e-3 (the bar of tests/test_parallel_cpu.py).  Later
+    # steps are different trajectories (five different updates): finite, not compared
+    assert torch.equal(off["losses"][0], wired["losses"][0]) and torch.equal(off["first_g"], auto["first_g"])
+    a, b = wired["first_g"].double(), off["first_g"].double() / world
+    rel = float((a - b).norm() / b.norm())
     cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-    print(f"{backbone}: bf16-wire gradient after 6 steps vs f32 wire: cosine {cos:.5f}; loss {wired['losses'][-1][0].item():.5f} vs {off['losses'][-1][0].item():.5f}")
-    assert cos > 0.98 and abs(wired["losses"][-1][0].item() - off["losses"][-1][0].item()) < 2e-2
+    print(f"{backbone}: first-step gradient over the bf16 wire vs the f32 wire: relative L2 {rel:.2e}, cosine {cos:.7f}")
+    assert rel <= 6e-3 and cos > 0.9999
+    assert bool(torch.isfinite(wired["losses"]).all())

@@ -464,6 +464,12 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
     }
 #else
     issue_tile(0);
+#ifdef UMR_ATTN_BARE
+    // ceiling probe (tools/probe/attn_ceiling.py; never in the product build): both ring buffers are filled ONCE, the tile loop below
+    // then issues no global or LDS-DMA traffic at all -- what is left is the loop's own arithmetic on LDS-resident operands (QK^T MFMAs,
+    // the max3 chain and lane swaps, exp2, bf16 conversion, V^T transposing reads, PV and row-sum MFMAs, one barrier per tile)
+    if (ntiles > 1) issue_tile(1);
+#endif
 #ifdef UMR_ATTN_PEEL_LAST
     // experiment hook (profiles/r05_attention_experiments.txt): the tile body twice, the key mask only in the copy that runs the last tile
     auto tile_body = [&](int j, auto last_tag) {
@@ -474,7 +480,9 @@ __global__ __launch_bounds__(256, UMR_ATTN_FWD_MIN_WAVES) void attn_fwd_bf16_ker
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // tile j landed for everyone; everyone is done reading buffer (j+1)&1
+#ifndef UMR_ATTN_BARE
         if (!LAST) issue_tile(j + 1);
+#endif
         const int sb = (j & 1) * STB;
         // S^T tiles: 4 x (16 keys x 16 queries) per query block
         f32x4 s[QB][4];
@@ -1166,7 +1174,15 @@ extern "C" int umr_attention_fwd(const void* qkv, void* out, float* lse, int B, 
     if (dtype == UMR_BF16 && fast_fwd) {
         if (N >= 128 && fast_fwd != 2) {   // 32 queries per wave: half the LDS reads per MFMA
             dim3 g2((unsigned)(gx2 * B * heads));
+#ifdef UMR_ATTN_BARE
+            // probe build only: extra dynamic LDS per workgroup caps the resident workgroups per CU (32 KiB static: 0 -> 4 per CU by
+            // registers, 24576 -> 2, 98304 -> 1): the bare loop at 4, 2 and 1 waves per SIMD
+            static const int pad = umr_env_int("UMR_ATTN_BARE_LDS", 0);
+            if (pad > 0) (void)hipFuncSetAttribute((const void*)attn_fwd_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+            hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g2, b, pad, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a2);
+#else
             hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g2, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a2);
+#endif
         } else {
             hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, b, 0, s, (const bf16_t*)qkv, (bf16_t*)out, lse, N, heads, a1);
         }

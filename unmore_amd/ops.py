@@ -771,18 +771,22 @@ def adam_step_hyper(p, g, m, v, hyper):
 
 # ---------------------------------------------------------------- kernel timing hook (bench.py roofline leg)
 # HIP events recorded on the launch stream around selected umr_gemm_nt launches.
-_timer = {"select": None, "events": []}
+_timer = {"select": None, "events": [], "modes": []}
 
 
 def set_kernel_timer(select):
     """select(desc: GemmDesc) -> bool chooses which gemm_nt launches to time; None disables."""
     _timer["select"] = select
     _timer["events"] = []
+    _timer["modes"] = []
 
 
-def kernel_timer_results_ms():
+def kernel_timer_results_ms(with_modes=False):
+    """durations of the timed launches; with_modes: (ms, f32 product mode at launch) pairs -- a certificate-driven sweep mixes
+    three-term and six-term launches of the same kernel (reasoning.sweep_proposals)"""
     torch.cuda.synchronize()
-    return [a.elapsed_time(b) for a, b in _timer["events"]]
+    ms = [a.elapsed_time(b) for a, b in _timer["events"]]
+    return list(zip(ms, _timer["modes"])) if with_modes else ms
 
 
 _raw_gemm_nt_call = None
@@ -813,6 +817,7 @@ def _timed_call(d):
         st = _gemm_nt_call(d)
         b.record()
         _timer["events"].append((a, b))
+        _timer["modes"].append(get_f32_mode())
         return st
     return _gemm_nt_call(d)
 

@@ -314,6 +314,19 @@ int umr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * same arguments. */
 int umr_adam_set_hyper(float* hyper7_dev, float lr, float beta1, float beta2, float eps, int step, float grad_scale, umr_stream_t stream);
 int umr_adam_step_hyper(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper7_dev, umr_stream_t stream);
+/* The optimizer step of a whole STAGE of the flat parameter buffer in one launch, writing the kernel-layout bf16 copies of its Linear
+ * weights itself (no refresh pass that re-reads the f32 weights: -8 B per parameter and copy pair).  table_dev[i]:
+ *   N == 0  a plain range: p / g / m / v of n elements, updated exactly as umr_adam_step_hyper does (4096 elements per block);
+ *   N  > 0  a 2-D weight [N][K] (f32, contiguous; K % 4 == 0, N % 8 == 0, 16-byte aligned), walked in 64 x 64 tiles
+ *           (ceil(N/64) * ceil(K/64) blocks, k fastest); dst_lin (may be NULL) receives bf16(p) as [N][K], dst_t (may be NULL) as [K][N].
+ * blk_start = the first block of the entry, blk_entry_dev[b] = the entry of block b (int32[total_blocks]).  The update is the same
+ * expression as umr_adam_step_hyper's, the copies round as umr_cast does: weights and copies are bit-identical to
+ * umr_adam_step_hyper followed by umr_permute4_batched. */
+typedef struct umr_adam_pack_entry {
+    float* p; const float* g; float* m; float* v; void* dst_lin; void* dst_t; int64_t n; int32_t N, K; int64_t blk_start;
+} umr_adam_pack_entry;
+int umr_adam_pack_step(const umr_adam_pack_entry* table_dev, int n_entries, int64_t total_blocks, const int32_t* blk_entry_dev,
+                       const float* hyper7_dev, umr_stream_t stream);
 
 /* ---- object-reasoning glue around the net ("next" rows f1/f2) -----------------------
  * crop_resize: proposal crops [x1,y1,x2,y2) of a [3,H,W] f32 image -> [N,3,S,S], bilinear, no antialias

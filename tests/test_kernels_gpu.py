@@ -61,6 +61,65 @@ def test_layernorm(dtype, M, D):
     assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+def _attn_ref(x, N, HD=64):
+    """fp64 softmax attention of a [N, 3 * HD] single-head operand: (out [N, HD], lse [N])"""
+    q, k, v = (x[:, i * HD:(i + 1) * HD].double() for i in range(3))
+    s = (q @ k.t()) / math.sqrt(HD)
+    return torch.softmax(s, dim=1) @ v, torch.logsumexp(s, dim=1)
+
+
+def test_attention_forward_wide_score_range_regression(golden_dir):
+    """Round 6: the operand on which the bf16 attention forward returned lse = +inf and a NaN output row during a soak of the reference
+    recipe (tests/golden/attn_wide_score_range_n65.npz: one (image, head) of block 7, 65 tokens; the class token's scores span
+    -75.7 .. +62.2 in log2 units, and the 16 keys its lane group 0 holds all sit more than 128 below the row maximum).  Cause: the
+    compiler dropped the max after v_permlane{16,32}_swap, so the 'row maximum' was lane group 0's own maximum (csrc/attention.hip,
+    xor16_max).  Output and lse must be finite and match the fp64 softmax; the backward kernels must accept that lse."""
+    import numpy as np
+    import os
+    from unmore_amd import ops
+    g = np.load(os.path.join(golden_dir, "attn_wide_score_range_n65.npz"))
+    x = torch.from_numpy(g["qkv_bf16_bits"]).view(torch.bfloat16).reshape(65, 192).cuda()
+    for n in (65, 64):
+        xx = x[:n].contiguous()
+        out, lse = ops.attention_fwd(xx, 1, n, 1, need_lse=True)
+        ref, lref = _attn_ref(xx, n)
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all()), n
+        torch.testing.assert_close(out.double(), ref, atol=3e-2, rtol=3e-2)
+        torch.testing.assert_close(lse.double(), lref, atol=3e-2, rtol=2e-3)
+        dq = ops.attention_bwd(xx, out, torch.ones_like(out), lse, 1, n, 1)
+        assert bool(torch.isfinite(dq.float()).all()), n
+
+
+@pytest.mark.parametrize("N", [64, 65, 127, 200, 577, 1370])
+def test_attention_forward_row_maximum_outside_lane_group_zero(N):
+    """The same hazard built on purpose, for both forward kernels (16 and 32 queries per wave: N < 128 / >= 128) and every tile: the
+    keys lane group 0 holds (key % 16 < 4) score -70, one other key per 64-key tile scores +70 (log2 units: a range of 140 > 128), the
+    rest 0.  With the row maximum taken over lane group 0 only, exp2 overflows and the row is NaN; values within range were never
+    affected (softmax is invariant to the reference subtracted), which is why every earlier test passed."""
+    from unmore_amd import ops
+    dev = _dev()
+    HD, heads, B = 64, 2, 2
+    gen = torch.Generator().manual_seed(N)
+    x = torch.zeros(B, N, 3, heads, HD)
+    x[:, :, 2] = torch.randn(B, N, heads, HD, generator=gen)
+    x[:, :, 0, :, 1:] = 0.05 * torch.randn(B, N, heads, HD - 1, generator=gen)
+    x[:, :, 1, :, 1:] = 0.05 * torch.randn(B, N, heads, HD - 1, generator=gen)
+    c = 70.0 / (8.0 * 0.125 * 1.4426950408889634)
+    x[:, :, 0, :, 0] = 8.0                                        # every query: q[0] = 8
+    keys = torch.arange(N)
+    x[:, :, 1, :, 0] = torch.where(keys % 16 < 4, -c, torch.where(keys % 64 == 5 + 16 * ((keys // 64) % 3), c, 0.0))[None, :, None]
+    xx = x.reshape(B * N, 3 * heads * HD).to(dev).bfloat16()
+    out, lse = ops.attention_fwd(xx, B, N, heads, need_lse=True)
+    assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(lse).all())
+    xb = xx.view(B, N, 3, heads, HD)
+    for b in range(B):
+        for h in range(heads):
+            one = xb[b, :, :, h].reshape(N, 3 * HD)
+            ref, lref = _attn_ref(one, N)
+            torch.testing.assert_close(out.view(B, N, heads, HD)[b, :, h].double(), ref, atol=3e-2, rtol=3e-2)
+            torch.testing.assert_close(lse.view(B, heads, N)[b, h].double(), lref, atol=3e-2, rtol=2e-3)
+
+
 @pytest.mark.parametrize("B,N,heads", [(20, 65, 16), (3, 100, 2), (2, 17, 1), (1, 127, 3)])
 def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, umr_opts):
     """N < 128 in bf16: dQ and dK / dV workgroups in ONE launch, each taking its rows' -lse and rowsum(dO * O) itself

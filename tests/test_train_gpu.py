@@ -407,10 +407,101 @@ def test_batched_repack_equals_lazy_repack(dtype, monkeypatch):
         if mode:
             eng = net._engine()
             # (one launch for all copies, or -- small problems -- one per stage behind the weight-gradient stream)
-            assert eng.cache._replay and sum(len(keys) for _, keys in eng.cache._replay.values()) > 40 and not eng.cache._o
+            assert eng.cache._replay and sum(len(v[-1]) for v in eng.cache._replay.values() if v) > 40 and not eng.cache._o
         res[mode] = (torch.stack(losses).cpu(), step.flat_p.clone().cpu())
     assert torch.equal(res[True][0], res[False][0])
     assert torch.equal(res[True][1], res[False][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("graph", ["off", "auto"])
+def test_adam_pack_equals_adam_then_refresh(dtype, graph, monkeypatch):
+    """Round 6: per stage, ONE optimizer launch that writes the bf16 [N,K] / [K,N] copies of the stage's Linear weights itself
+    (trainer._ADAM_PACK, PackCache.adam_and_refresh, umr_adam_pack_step) against the Adam launch followed by the batched refresh: ten
+    steps end in bit-identical losses, weights, Adam moments AND packed copies -- eagerly on two streams and replayed as a chain of
+    graphs.  (fp32 mode has no bf16 copies: the fused form declines and both arms run the same launches.)"""
+    from unmore_amd import trainer
+    B, H, W = 2, 64, 64
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(trainer, "_ADAM_PACK", fused)
+        net, _ = _net("dpt_tiny", "tiny", dtype)
+        step = trainer.TrainStep(net, lr=1e-3).set_graph_mode(graph)
+        losses = []
+        for it in range(10):
+            img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=60 + it))
+            losses.append(step.step(img, cf, sdf, sal).clone())
+        torch.cuda.synchronize()
+        eng = net._engine()
+        packs = {k: e[1].clone() for k, e in eng.cache._c.items() if torch.is_tensor(e[1])}
+        n_fused = sum(1 for k, v in eng.cache._replay.items() if isinstance(k, tuple) and k[0] == "adam" and v)
+        assert (n_fused > 0) == (fused and dtype == torch.bfloat16), n_fused
+        res[fused] = (torch.stack(losses).cpu(), step.flat_p.clone(), step.m.clone(), step.v.clone(), packs)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert a[4].keys() == b[4].keys() and len(a[4]) > 20
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+    # and the copies ARE the weights: every bf16 [N,K] copy equals the cast of its parameter after the last update
+    P = dict(net.named_parameters())
+    n_chk = 0
+    for key, t in a[4].items():
+        if len(key) != 3 or key[0] not in P:      # (fp32 mode keys its plane packs differently)
+            continue
+        name, kind, dt_ = key
+        if kind == "lin" and dt_ == torch.bfloat16 and P[name].dim() == 2:
+            assert torch.equal(t, P[name].detach().to(torch.bfloat16)), name
+            n_chk += 1
+        if kind == "lin_t" and dt_ == torch.bfloat16 and P[name].dim() == 2:
+            assert torch.equal(t, P[name].detach().t().to(torch.bfloat16)), name
+            n_chk += 1
+    assert n_chk > 10 or dtype == torch.float32
+
+
+def test_adam_pack_kernel_against_adam_and_casts():
+    """umr_adam_pack_step alone: plain ranges (with a tail that is not a multiple of four) and weight entries with one, the other or both
+    copies, ragged 64 x 64 tiles -- against umr_adam_step_hyper on the same buffers and torch casts / transposes of the result"""
+    from unmore_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    shapes = [("plain", 1003), ("weight", (72, 100), True, True), ("plain", 4096 + 8), ("weight", (192, 64), True, False),
+              ("weight", (64, 256), False, True), ("plain", 3), ("weight", (136, 68), True, True)]
+    total = sum((sh[1] if sh[0] == "plain" else sh[1][0] * sh[1][1] + 0) for sh in shapes)
+    total = (total + 63) // 64 * 64 + 64 * len(shapes)
+    bufs = [torch.randn(total, generator=g).to(dev) for _ in range(3)] + [torch.rand(total, generator=g).to(dev)]
+    ref = [b.clone() for b in bufs]
+    hyper = torch.zeros(8, device=dev)
+    ops.adam_set_hyper(hyper, 3, 1e-3, 0.9, 0.999, 1e-8, 0.5)
+    entries, copies, off = [], [], 0
+    for sh in shapes:
+        if sh[0] == "plain":
+            n = sh[1]
+            entries.append(("plain",) + tuple(b[off:off + n] for b in bufs))
+            off += (n + 63) // 64 * 64
+        else:
+            N, K = sh[1]
+            dl = torch.zeros((N, K), dtype=torch.bfloat16, device=dev) if sh[2] else None
+            dt_ = torch.zeros((K, N), dtype=torch.bfloat16, device=dev) if sh[3] else None
+            entries.append(("weight",) + tuple(b[off:off + N * K].view(N, K) for b in bufs) + (dl, dt_))
+            copies.append((off, N, K, dl, dt_))
+            off += N * K
+    ops.adam_pack(entries, hyper)()
+    # reference: the plain Adam launch over exactly the ranges the entries cover
+    for ent in entries:
+        sl = [t.reshape(-1) for t in ent[1:5]]
+        o = sl[0].data_ptr() - bufs[0].data_ptr()
+        o //= 4
+        n = sl[0].numel()
+        ops.adam_step_hyper(ref[0][o:o + n], ref[1][o:o + n], ref[2][o:o + n], ref[3][o:o + n], hyper)
+    torch.cuda.synchronize()
+    for a, b in zip(bufs, ref):
+        assert torch.equal(a, b)
+    for off, N, K, dl, dt_ in copies:
+        w = bufs[0][off:off + N * K].view(N, K)
+        if dl is not None:
+            assert torch.equal(dl, w.to(torch.bfloat16))
+        if dt_ is not None:
+            assert torch.equal(dt_, w.t().to(torch.bfloat16))
 
 
 def test_permute4_batched_equals_single_launches():

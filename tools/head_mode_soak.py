@@ -68,8 +68,10 @@ if "--no-first-step" not in sys.argv:
 
 hist = {}
 rate = {}
+GRAPHS = os.environ.get("SOAK_GRAPHS", "auto")      # 'off': the eager two-stream schedule instead of the chain of per-stage graphs
 for mode in ("auto", "factored"):
     net, st = make(torch.bfloat16, mode)
+    st.set_graph_mode(GRAPHS)
     h = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -78,7 +80,10 @@ for mode in ("auto", "factored"):
     torch.cuda.synchronize()
     rate[mode] = steps * BATCH / (time.perf_counter() - t0)
     hist[mode] = torch.stack(h).cpu()
-    assert torch.isfinite(hist[mode]).all(), mode
+    bad = (~torch.isfinite(hist[mode][:, 0])).nonzero().flatten()
+    if bad.numel():
+        b0 = int(bad[0])
+        print(f"{mode}: NON-FINITE loss from step {b0 + 1} on; the ten steps before it: {[round(float(x), 4) for x in hist[mode][max(0, b0 - 10):b0 + 1, 0]]}", flush=True)
     print(f"{mode}: {rate[mode]:.1f} images/s sustained over {steps} steps incl. per-step host work; peak {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB", flush=True)
     del net, st
     torch.cuda.empty_cache()
@@ -94,4 +99,5 @@ print("50-step averages, factored: ", [round(v, 4) for v in af])
 print(f"first 8 steps |diff|: {[round(abs(float(a[i, 0] - f[i, 0])), 5) for i in range(min(8, steps))]}")
 print(f"largest |difference| of the 50-step averages: {max(abs(x - y) for x, y in zip(aa, af)):.4f}; final averages {aa[-1]:.4f} vs {af[-1]:.4f}; "
       f"loss falls in both: {aa[-1] < aa[0] and af[-1] < af[0]}")
+assert torch.isfinite(a).all() and torch.isfinite(f).all(), "non-finite loss"
 assert aa[-1] < aa[0] and af[-1] < af[0]

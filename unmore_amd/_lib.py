@@ -39,6 +39,11 @@ class GemmTnDesc(ctypes.Structure):
                 ("x_rows_in", _i32), ("x_rows_out", _i32), ("x_row_off", _i32)]
 
 
+class AdamPackEntry(ctypes.Structure):   # umr_adam_pack_entry
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("dst_lin", _vp), ("dst_t", _vp), ("n", _i64), ("N", _i32), ("K", _i32),
+                ("blk_start", _i64)]
+
+
 class PermEntry(ctypes.Structure):   # umr_perm_entry
     _fields_ = [("src", _vp), ("dst", _vp), ("d", _i32 * 4), ("sstride", _i64 * 4), ("soff", _i64), ("dtype_in", _i32), ("dtype_out", _i32),
                 ("blk_start", _i64), ("e", _i32 * 4), ("ord", _i32 * 4), ("rowlen", _i64)]
@@ -106,6 +111,7 @@ _SIGS = {
     "umr_adam_step": [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
     "umr_adam_set_hyper": [_vp, _f32, _f32, _f32, _f32, _i32, _f32, _vp],
     "umr_adam_step_hyper": [_vp, _vp, _vp, _vp, _i64, _vp, _vp],
+    "umr_adam_pack_step": [_vp, _i32, _i64, _vp, _vp, _vp],
     "umr_crop_resize_bilinear": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks_certified": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, ctypes.c_double, _vp],

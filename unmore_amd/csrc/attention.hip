@@ -242,16 +242,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
 // the compiler does not see an asm statement's reads when it pads the MFMA -> VALU read hazard.)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 __device__ __forceinline__ float max2f(float a, float b) { return fmaxf(a, b); }
-// max over lanes l, l^16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) and l, l^32
+// max over lanes l, l^16 (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of the second) and l, l^32.
+// ROUND 6: the second result of the swap goes through an empty asm before the max.  hipcc (ROCm 7.2, clang 22) folds
+// fmax(extract 0, extract 1) of llvm.amdgcn.permlane{16,32}.swap to extract 0 at -O3 (tools/probe: the max instruction is simply absent from
+// the ISA, with or without -fno-honor-nans), so the "maximum over the four lane groups of a query column" used to be lane group 0's own
+// maximum.  Softmax does not care which reference is subtracted -- every test passed -- until the true maximum sits more than 128 (log2
+// units) above that group's 16 scores: exp2 overflows, the row sum becomes +inf and the output row NaN.  Found in a 2000-step soak of the
+// reference recipe (step 921 / 1145 / 2913 by trajectory; tests/golden/attn_wide_score_range_n65.npz is that operand).
 __device__ __forceinline__ float xor16_max(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return max2f(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r1));
+    return max2f(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
 }
 __device__ __forceinline__ float xor32_max(float x) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return max2f(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    unsigned r0 = r[0], r1 = r[1];
+    asm volatile("" : "+v"(r1));
+    return max2f(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
 }
 
 template <int OFF>

@@ -1000,16 +1000,119 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------- Adam (torch.optim.Adam defaults; train_objectness_net.py:96)
+// ONE update expression for every Adam kernel of this file, written with the round-to-nearest intrinsics: the compiler neither contracts
+// them into other fused multiply-adds nor reassociates them, so the plain, the device-scalar and the copy-writing launches give the same
+// bits whatever code surrounds the call (the copy-writing kernel's unrolled form first came out one ulp away from the plain one's)
+__device__ __forceinline__ void adam_update1(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps, float bc1,
+                                             float bc2_sqrt, float gscale) {
+    const float gi = __fmul_rn(g, gscale);
+    const float mi = __fmaf_rn(m, b1, __fmul_rn(gi, __fsub_rn(1.f, b1)));
+    const float vi = __fmaf_rn(v, b2, __fmul_rn(__fmul_rn(gi, gi), __fsub_rn(1.f, b2)));
+    m = mi;
+    v = vi;
+    const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+    p = __fsub_rn(p, __fmul_rn(__fdiv_rn(lr, bc1), __fdiv_rn(mi, denom)));
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
                             float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = m[i] * b1 + gi * (1.f - b1);
-        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - (lr / bc1) * (mi / denom);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update1(pi, g[i], mi, vi, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+// ---------------------------------------------------------------- Adam that writes the kernel-layout bf16 weight copies itself
+// Round 6 (small-step regime: the reference recipe's 347.6 M parameters per 20-ms step): the optimizer pass already holds every updated
+// weight in registers; writing the bf16 copies the GEMMs read -- the [N][K] forward operand and the [K][N] data-gradient operand of a
+// Linear weight -- from there saves the refresh pass that re-read the f32 weights (umr_permute4_batched: 12 B per parameter and copy pair
+// on top of Adam's 28; now 4).  One launch covers a whole stage of the flat parameter buffer: `plain` entries are ranges updated as
+// umr_adam_step_hyper does, `weight` entries are 2-D [N][K] weights walked in 64 x 64 tiles (16-byte accesses on every stream; the
+// transposed copy goes through LDS).  Same update expression as adam_hyper_kernel, same rounding of the copies as the refresh pass's
+// casts: bit-identical weights and copies (tests/test_train_gpu.py::test_adam_pack_equals_adam_then_refresh).
+struct AdamPackEntry { float* p; const float* g; float* m; float* v; void* dst_lin; void* dst_t; int64_t n; int32_t N, K; int64_t blk_start; };
+static_assert(sizeof(AdamPackEntry) == sizeof(umr_adam_pack_entry), "umr_adam_pack_entry layout");
+
+__device__ __forceinline__ void adam_update4(f32x4& p, const f32x4& g, f32x4& m, f32x4& v, float lr, float b1, float b2, float eps, float bc1,
+                                             float bc2_sqrt, float gscale) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float pc = p[c], mc = m[c], vc = v[c];
+        adam_update1(pc, g[c], mc, vc, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+        p[c] = pc; m[c] = mc; v[c] = vc;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_pack_kernel(const AdamPackEntry* __restrict__ table, const int32_t* __restrict__ blk_entry,
+                                                        const float* __restrict__ hyper) {
+    __shared__ float tile[64 * 65];
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5], gscale = hyper[6];
+    const AdamPackEntry e = table[blk_entry[blockIdx.x]];
+    const int64_t lb = (int64_t)blockIdx.x - e.blk_start;
+    const int t = threadIdx.x;
+    if (e.N == 0) {
+        // plain range: 4096 elements per block, four 16-byte accesses per thread and stream; a tail shorter than four goes scalar
+        const int64_t base = lb * 4096;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = base + (int64_t)(j * 256 + t) * 4;
+            if (i + 4 <= e.n) {
+                f32x4 p = *(const f32x4*)(e.p + i), m = *(const f32x4*)(e.m + i), v = *(const f32x4*)(e.v + i);
+                const f32x4 g = *(const f32x4*)(e.g + i);
+                adam_update4(p, g, m, v, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+                *(f32x4*)(e.p + i) = p; *(f32x4*)(e.m + i) = m; *(f32x4*)(e.v + i) = v;
+            } else {
+                for (int64_t q = i; q < e.n; ++q) {
+                    float pq = e.p[q], mq = e.m[q], vq = e.v[q];
+                    adam_update1(pq, e.g[q], mq, vq, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+                    e.p[q] = pq; e.m[q] = mq; e.v[q] = vq;
+                }
+            }
+        }
+        return;
+    }
+    // weight [N][K]: tile rows n0.., columns k0.. (k fastest over the blocks: neighbouring blocks touch adjacent 256-byte pieces of the same rows)
+    const int ntk = (e.K + 63) >> 6;
+    const int k0 = (int)(lb % ntk) << 6, n0 = (int)(lb / ntk) << 6;
+    const int kc = k0 + (t & 15) * 4;
+    f32x4 pw[4];
+    bool live[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j * 16 + (t >> 4);
+        live[j] = n < e.N && kc < e.K;          // K % 4 == 0: a chunk is inside or outside as a whole
+        pw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live[j]) {
+            const int64_t i = (int64_t)n * e.K + kc;
+            f32x4 m = *(const f32x4*)(e.m + i), v = *(const f32x4*)(e.v + i);
+            const f32x4 g = *(const f32x4*)(e.g + i);
+            pw[j] = *(const f32x4*)(e.p + i);
+            adam_update4(pw[j], g, m, v, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+            *(f32x4*)(e.p + i) = pw[j]; *(f32x4*)(e.m + i) = m; *(f32x4*)(e.v + i) = v;
+            if (e.dst_lin) {
+                const bf16x4 o = {(bf16_t)pw[j][0], (bf16_t)pw[j][1], (bf16_t)pw[j][2], (bf16_t)pw[j][3]};
+                *(bf16x4*)((bf16_t*)e.dst_lin + i) = o;
+            }
+        }
+    }
+    if (!e.dst_t) return;
+    // transposed copy dst_t[k][n]: tile[n local][k local] through LDS, then 16-byte stores along n
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tile[(j * 16 + (t >> 4)) * 65 + (t & 15) * 4 + c] = pw[j][c];
+    __syncthreads();
+    const int kl = t >> 2;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int nl = (t & 3) * 8 + h * 32;
+        if (k0 + kl < e.K && n0 + nl < e.N) {      // N % 8 == 0: eight rows are inside or outside as a whole
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)tile[(nl + j) * 65 + kl];
+            *(bf16x8*)((bf16_t*)e.dst_t + (int64_t)(k0 + kl) * e.N + n0 + nl) = o;
+        }
     }
 }
 
@@ -1018,13 +1121,9 @@ __global__ void adam_hyper_kernel(float* __restrict__ p, const float* __restrict
                                   const float* __restrict__ hyper) {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5], gscale = hyper[6];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = m[i] * b1 + gi * (1.f - b1);
-        const float vi = v[i] * b2 + gi * gi * (1.f - b2);
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - (lr / bc1) * (mi / denom);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update1(pi, g[i], mi, vi, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -1349,6 +1448,15 @@ extern "C" int umr_adam_step(float* p, const float* g, float* m, float* v, int64
     adam_hyper(lr, beta1, beta2, eps, step, grad_scale, h);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, p, g, m, v, n, h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_adam_pack_step(const umr_adam_pack_entry* table_dev, int n_entries, int64_t total_blocks, const int32_t* blk_entry_dev,
+                                  const float* hyper7_dev, umr_stream_t stream) {
+    UMR_CHECK_ARG(table_dev && blk_entry_dev && hyper7_dev && n_entries > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "adam_pack_step: bad arguments");
+    hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPackEntry*)table_dev, blk_entry_dev,
+                       hyper7_dev);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

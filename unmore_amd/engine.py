@@ -184,6 +184,66 @@ class PackCache:
             e[0] = (e[5]._version, e[5].data_ptr())
             e[2], e[3] = ev, {st.cuda_stream}
 
+    def adam_and_refresh(self, tag, select, stage_params, lo, hi, bufs, hyper):
+        """Optimizer step of the flat-buffer slice [lo, hi) AND the refresh of its packed copies, with the copies of its Linear
+        weights written by the optimizer launch itself (ops.adam_pack / umr_adam_pack_step: the refresh pass that re-read those f32
+        weights is gone; the other packs of the stage -- conv layouts, plane forms -- keep the batched permute).
+        stage_params: [(name, element offset, numel, shape)] of the slice in buffer order; bufs = (flat p, g, m, v); hyper: device
+        scalars of umr_adam_set_hyper.  Returns False (nothing launched) when no weight of the stage has a bf16 [N,K] / [K,N] copy
+        -- the caller then runs the two-launch form.  Bit-identical to it (tests/test_train_gpu.py)."""
+        rk = ("adam", tag)
+        if rk not in self._replay:
+            assert not graphs.capturing(), "PackCache.adam_and_refresh: the tables must be built before a capture (warm-up steps)"
+            keys = [k for k in self._c if select is None or select(k)]
+            by_name = {}
+            for k in keys:
+                by_name.setdefault(k[0], {})[k[1]] = k
+            flat_p, flat_g, flat_m, flat_v = bufs
+            entries, fused, cur = [], set(), lo
+            for name, off, numel, shape in stage_params:
+                kinds = by_name.get(name, {})
+                ok = (len(shape) == 2 and shape[0] % 8 == 0 and shape[1] % 4 == 0 and off % 4 == 0 and kinds and set(kinds) <= {"lin", "lin_t"}
+                      and all(torch.is_tensor(self._c[k][1]) and self._c[k][1].dtype == torch.bfloat16 and self._c[k][1].is_contiguous()
+                              for k in kinds.values()))
+                if ok:
+                    dl = self._c[kinds["lin"]][1] if "lin" in kinds else None
+                    dt_ = self._c[kinds["lin_t"]][1] if "lin_t" in kinds else None
+                    ok = (dl is None or tuple(dl.shape) == tuple(shape)) and (dt_ is None or tuple(dt_.shape) == (shape[1], shape[0]))
+                if not ok:
+                    continue
+                if cur < off:
+                    entries.append(("plain",) + tuple(b[cur:off] for b in bufs))
+                entries.append(("weight",) + tuple(b[off:off + numel].view(shape) for b in bufs) + (dl, dt_))
+                fused.update(kinds.values())
+                cur = off + numel
+            if not fused:
+                self._replay[rk] = None
+            else:
+                if cur < hi:
+                    entries.append(("plain",) + tuple(b[cur:hi] for b in bufs))
+                rest = [k for k in keys if k not in fused]
+                self._replay[rk] = (ops.adam_pack(entries, hyper), ops.permute4_batched([self._c[k][4] for k in rest]) if rest else None, keys)
+        rec = self._replay[rk]
+        if rec is None:
+            return False
+        launch_adam, launch_rest, keys = rec
+        if any(self._c[k][5].data_ptr() != self._c[k][0][1] for k in keys):   # a parameter's storage moved: the tables are stale
+            self.clear()
+            return False
+        launch_adam()
+        if launch_rest is not None:
+            launch_rest()
+        if graphs.capturing():
+            return True                # the replaying caller publishes the refresh with refreshed_by_replay()
+        st = torch.cuda.current_stream(self._c[keys[0]][5].device)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        for k in keys:
+            e = self._c[k]
+            e[0] = (e[5]._version, e[5].data_ptr())
+            e[2], e[3] = ev, {st.cuda_stream}
+        return True
+
     def refresh_done(self):
         """after the last (partial) refresh of a round: the copies that cannot be replayed are dropped (rebuilt on next use).
         Inside a capture, entries the capture built itself go silently (each of its replays rebuilds them); every OTHER dropped entry

@@ -651,6 +651,48 @@ def permute4_batched(recipes):
     return launch
 
 
+def adam_pack(entries, hyper):
+    """One optimizer launch for a stage of the flat parameter buffer that also writes the bf16 kernel-layout copies of its Linear
+    weights (include/umr.h, umr_adam_pack_step).  entries: list of
+        ("plain", p, g, m, v)                   1-D f32 views of equal length
+        ("weight", p, g, m, v, dst_lin, dst_t)  p .. v: [N, K] f32 contiguous views; dst_lin [N, K] / dst_t [K, N] bf16 or None
+    hyper: the device-side scalars of umr_adam_set_hyper.  Returns a callable that launches it on the current stream."""
+    import numpy as np
+    n = len(entries)
+    arr = (L.AdamPackEntry * n)()
+    blk, counts, keep = 0, [], [hyper]
+    for i, ent in enumerate(entries):
+        e = arr[i]
+        p, g, m, v = ent[1:5]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (p, g, m, v)) and p.shape == g.shape == m.shape == v.shape
+        e.p, e.g, e.m, e.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        e.blk_start = blk
+        if ent[0] == "plain":
+            e.n, e.N, e.K, e.dst_lin, e.dst_t = p.numel(), 0, 0, None, None
+            nb = (p.numel() + 4095) // 4096
+        else:
+            dl, dt_ = ent[5], ent[6]
+            N, K = p.shape
+            assert K % 4 == 0 and N % 8 == 0 and all(t.data_ptr() % 16 == 0 for t in (p, g, m, v))
+            for d, shp in ((dl, (N, K)), (dt_, (K, N))):
+                assert d is None or (d.dtype == torch.bfloat16 and d.is_contiguous() and tuple(d.shape) == shp and d.data_ptr() % 16 == 0)
+            e.n, e.N, e.K = p.numel(), N, K
+            e.dst_lin, e.dst_t = (dl.data_ptr() if dl is not None else None), (dt_.data_ptr() if dt_ is not None else None)
+            nb = ((N + 63) // 64) * ((K + 63) // 64)
+            keep += [t for t in (dl, dt_) if t is not None]
+        keep += [p, g, m, v]
+        blk += nb
+        counts.append(nb)
+    dev = entries[0][1].device
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+    blk_entry = torch.from_numpy(np.repeat(np.arange(n, dtype=np.int32), counts)).to(dev)
+
+    def launch():
+        L.check(L.lib().umr_adam_pack_step(_p(table), n, blk, _p(blk_entry), _p(hyper), _stream()), "umr_adam_pack_step")
+    launch.keep = keep
+    return launch
+
+
 def permute4(src, dst, dst_dims, src_strides, src_offset=0, accumulate=False):
     """dst[i0,i1,i2,i3] = src.flat[src_offset + sum i_k*src_strides[k]] (cast to dst dtype)."""
     _need_gpu(src, dst)

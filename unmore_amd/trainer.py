@@ -17,6 +17,9 @@ from . import graphs, ops
 from .parallel import BucketedAllReduce
 
 _BATCHED_REPACK = os.environ.get("UMR_BATCHED_REPACK", "1") != "0"   # A/B switch: 0 = drop the packed copies, re-pack lazily (round 2)
+# A/B switch: 0 = per stage, the Adam launch and then the batched refresh of its packed copies (round 5); 1 = the Adam launch writes the
+# bf16 copies of the stage's Linear weights itself (round 6: ops.adam_pack; bit-identical)
+_ADAM_PACK = os.environ.get("UMR_ADAM_PACK", "1") != "0"
 
 
 def _stage_of(name, cfg):
@@ -94,6 +97,9 @@ class TrainStep:
                 self.G[n] = self.flat_g[o:o + p.numel()].view(p.shape)
         self.P = {n: p for n, p in net.named_parameters()}
         self._offs = offs
+        self._stage_params = {}     # stage -> [(name, offset, numel, shape)] in buffer order (PackCache.adam_and_refresh)
+        for n, o in sorted(offs.items(), key=lambda t: t[1]):
+            self._stage_params.setdefault(_stage_of(n, net.cfg), []).append((n, o, named[n].numel(), tuple(named[n].shape)))
         if grad_wire_dtype is None and os.environ.get("UMR_DP_WIRE", "") == "bf16":
             grad_wire_dtype = torch.bfloat16
         self.comm = BucketedAllReduce(self.flat_g, bounds, group, wire_dtype=grad_wire_dtype)
@@ -125,6 +131,17 @@ class TrainStep:
             if hi > lo:
                 ops.adam_step_hyper(self.flat_p[lo:hi], self.flat_g[lo:hi], self.m[lo:hi], self.v[lo:hi], self._hyper)
 
+        def update_and_refresh(stage, k):
+            """stage k's optimizer step and the refresh of its packed weight copies: one launch that writes the Linear weights' bf16
+            copies itself where the stage has such copies (bf16 mode), the two-launch form otherwise"""
+            lo, hi = bounds[k], bounds[k + 1]
+            sel = lambda key, stage=stage: _stage_of(key[0], self.net.cfg) == stage
+            if _ADAM_PACK and hi > lo and eng.cache.adam_and_refresh(stage, sel, self._stage_params.get(stage, []), lo, hi,
+                                                                     (self.flat_p, self.flat_g, self.m, self.v), self._hyper):
+                return
+            update(k)
+            eng.cache.refresh(tag=stage, select=sel)
+
         # a staged capture in progress (graphs.StagedCaptured): collectives are not captured -- the chain is cut at the bucket
         # boundaries it already has, and a replay issues each bucket's all-reduce between two graph launches (on the side lane,
         # behind the stage's weight gradients; the main lane waits for the exchange only in finish(), before the optimizer update)
@@ -143,8 +160,7 @@ class TrainStep:
                 # gradients on the second stream -- HBM-bound work beside the (latency-bound) rest of backward.  Nothing later in
                 # this step reads the stage's weights again; the final join of backward orders the next step after them.
                 def launch():
-                    update(k)
-                    eng.cache.refresh(tag=stage, select=lambda key, stage=stage: _stage_of(key[0], self.net.cfg) == stage)
+                    update_and_refresh(stage, k)
                 wg.run(launch)
                 updated.add(k)
 
@@ -163,8 +179,7 @@ class TrainStep:
         else:
             for stage, k in self.stage_bucket.items():
                 if k not in updated:
-                    update(k)
-                    eng.cache.refresh(tag=stage, select=lambda key, stage=stage: _stage_of(key[0], self.net.cfg) == stage)
+                    update_and_refresh(stage, k)
             eng.cache.refresh_done()
             if not graphs.capturing():
                 eng.cache.synced_with(torch.cuda.current_stream(images.device))

@@ -40,6 +40,7 @@ def stats(name, t):
 
 
 it = 0
+hist = []
 while it < max_steps:
     snap = None
     if it % 50 == 0:
@@ -47,6 +48,58 @@ while it < max_steps:
     # keep a copy of the optimizer state every step is too slow: check the loss every step (one sync), snapshot lazily
     p0, m0, v0 = st.flat_p.clone(), st.m.clone(), st.v.clone()
     out5 = st.step(*pool[it % 4])
+    hist.append(out5)
+    if (it + 1) % 250 == 0:
+        print(f"step {it + 1}: loss {[round(v, 4) for v in out5.tolist()]}", flush=True)
+    if fin(out5) and not fin(st.flat_g):
+        # the loss (taken in the forward pass) is finite but the step's BACKWARD produced non-finite gradients
+        print(f"step {it + 1}: finite loss {out5.tolist()} but non-finite gradients; the 12 losses before: {[round(float(h[0]), 4) for h in hist[-13:-1]]}", flush=True)
+        st.flat_p.copy_(p0); st.m.copy_(m0); st.v.copy_(v0)
+        eng = net._engine()
+        eng.cache.clear()
+        P = {n: p.detach() for n, p in net.named_parameters()}
+        img, cf, sdf, sal = pool[it % 4]
+        c, s, S = eng.forward(P, img, save=True)
+        stats("center_fields", c)
+        stats("sdf_maps", s)
+        print(f"    sdf_maps: share of |out| == 1 exactly: {float((s.abs() == 1).float().mean()):.4f}; max |out| {float(s.abs().max()):.8f}")
+        for k, v in S["heads"][1].items():
+            if torch.is_tensor(v):
+                stats("sdf head saved: " + k, v)
+        l5, dpc, dps = ops.objectness_loss(c, s, cf, sdf, sal)
+        stats("d loss / d center", dpc)
+        stats("d loss / d sdf", dps)
+        G = {n: torch.zeros_like(P[n]) for n in P if n not in net.nograd_names()}
+        seen = set()
+
+        def cb(stage, wg):
+            torch.cuda.synchronize()
+            bad = [n for n, g in G.items() if n not in seen and not fin(g)]
+            seen.update(bad)
+            if bad:
+                print(f"  after backward stage '{stage}': {len(bad)} newly non-finite gradient tensors {bad[:6]}", flush=True)
+            for n in bad[:4]:
+                stats(n, G[n])
+        real_bwd = ops.attention_bwd
+        state = {"saved": False, "call": 0}
+
+        def spy(qkv, out, dout, lse, B_, N_, heads_):
+            dq = real_bwd(qkv, out, dout, lse, B_, N_, heads_)
+            state["call"] += 1
+            if not state["saved"] and not fin(dq):
+                state["saved"] = True
+                bad = ~torch.isfinite(dq.float())
+                rows = bad.any(1).nonzero().flatten()
+                cols = bad.any(0).nonzero().flatten()
+                print(f"  attention_bwd call {state['call']} (block {max(net.cfg['hooks']) + 1 - state['call']}): inputs finite qkv {fin(qkv)} out {fin(out)} dout {fin(dout)} lse {fin(lse)}; "
+                      f"dqkv non-finite {int(bad.sum())} in rows {rows[:6].tolist()}..({rows.numel()}) cols {cols[:4].tolist()}..{cols[-2:].tolist()} ({cols.numel()})", flush=True)
+                out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "gpurun_out")
+                torch.save({"qkv": qkv.cpu(), "out": out.cpu(), "dout": dout.cpu(), "lse": lse.cpu(), "dqkv": dq.cpu()}, os.path.join(out_dir, f"nan_hunt_attn_bwd_{mode}.pt"))
+            return dq
+        ops.attention_bwd = spy
+        eng.backward(P, S, dpc, dps, G, stage_cb=cb)
+        ops.attention_bwd = real_bwd
+        break
     if not fin(out5):
         print(f"step {it + 1}: loss {out5.tolist()} -- repeating it by hand from the state before it", flush=True)
         st.flat_p.copy_(p0); st.m.copy_(m0); st.v.copy_(v0)

@@ -776,6 +776,20 @@ __device__ __forceinline__ void attn_bwd_dq_bf16_body(char* smem, const bf16_t* 
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) { t0[dt] = ds_tr_b64<4096>(tad[dt] + tb); t1[dt] = ds_tr_b64<4096 + 2048>(tad[dt] + tb); }
             }
+            // Keys past N (zero-filled rows of the last tile) are NOT harmless when a query's scores all lie far below zero: their
+            // "probability" is exp2(0 - lse * log2 e), +inf once lse < -128 log2 units, and inf * (0 - D) * 0 is NaN in dQ.  Found in a
+            // 6000-step soak of the reference recipe (round 6: block 1, a head whose scores had drifted to -130 .. -170).  Masked as in
+            // the forward kernel, in the last tile only (wave-uniform branch).
+            if (j == ntiles - 1 && (N & (TK - 1)) != 0) {
+#pragma unroll
+                for (int su = 0; su < 2; ++su)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (j * TK + (2 * half + su) * 16 + 4 * g + e >= N) {
+#pragma unroll
+                            for (int qi = 0; qi < QB; ++qi) s[qi][su][e] = -INFINITY;
+                        }
+            }
             bf16x8 dsb[QB];
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi)

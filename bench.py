@@ -235,6 +235,8 @@ def measured_traffic(a, M_head):
     # algorithmic bytes: one read of the input map + one write of the output map, 512 channels each; bf16 = 2 B per value, planes = 6 B
     per_value = 6.0 if a.dtype == "fp32" else 2.0
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")), reverse=True):
+        if a.workload == "cfg5" and getattr(a, "sweep_precision", "full") == "certified" and os.path.basename(f) < "r06":
+            continue      # (rounds 2-5 profiled the six-term sweep: another kernel mix)
         try:
             for k in json.load(open(f))["kernels"]:
                 if k["kernel"].startswith(prefix) and k.get("class") == "large" and "hbm_bytes_per_launch" in k:

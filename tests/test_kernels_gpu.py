@@ -153,9 +153,12 @@ def test_attention_backward_when_every_score_is_far_below_zero(N):
     # other 63 features of dQ / dK and all of dV are held to the suite's bf16 bar
     keep = torch.ones(3 * heads * HD, dtype=torch.bool, device=dev)
     keep[torch.arange(0, 2 * heads * HD, HD, device=dev)] = False
-    diff = (dqkv.double() - ref)[:, keep].abs().max()
-    scale = float(ref[:, keep].abs().max())
-    assert float(diff) <= 3e-2 * scale + 1e-6, (float(diff), scale)
+    a, r = dqkv.double()[:, keep], ref[:, keep]
+    rel = float((a - r).norm() / r.norm())
+    print(f"N = {N}: lse max {float(lse.max()):.1f}; dQ/dK/dV (63 features + dV) relative L2 vs fp64 {rel:.3e}, max error {float((a - r).abs().max()):.3e} of max {float(r.abs().max()):.3e}")
+    # accuracy too: the forward, dQ and dK / dV kernels all form a score from the SAME two bf16 operands (bf16(q c) and k) since round 6 --
+    # with the scale on K in the dK / dV kernel its probabilities were 14 % off here (two roundings of a score of -140, 0.19 apart)
+    assert rel <= 0.02, rel
 
 
 @pytest.mark.parametrize("B,N,heads", [(20, 65, 16), (3, 100, 2), (2, 17, 1), (1, 127, 3)])

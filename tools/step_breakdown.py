@@ -11,12 +11,12 @@ rows = d["kernels"]
 def grp(k):
     n, big = k["kernel"], k.get("class") == "large"
     if n.startswith("gemm_nt256p_kernel<1, 3") and big and k["avg_ms"] > 5:
-        return "head 3x3 conv NT (forward x2, masked data gradient)"
+        return "head 3x3 conv NT (centre head: forward, masked data gradient; + the boundary-distance head's forward in factored mode)"
     if n.startswith("gemm_tn256_kernel<1") and k["avg_ms"] > 5:
         return "head 3x3 conv TN (weight gradient)"
     if n.startswith("gemm_nt256p_kernel<0, 3, 0, true") or (n.startswith("gemm_nt256p_kernel<0, 3, 2") and k["avg_ms"] > 5) or \
             (n.startswith("gemm_tn256_kernel<0") and k["avg_ms"] > 5) or n.startswith("head_out"):
-        return "centre-head 1x1 group (512->1024 + fused output x2, masked dgrad, W3 wgrad, head_out_bwd)"
+        return "centre-head 1x1 group (512->1024 + fused output, masked dgrad, W3 wgrad, head_out_bwd)"
     if n.startswith("attn"):
         return "attention"
     if n.startswith("bilinear"):

@@ -856,7 +856,11 @@ __device__ __forceinline__ void attn_bwd_dkv_bf16_body(char* smem, const bf16_t*
 #pragma unroll
     for (int ki = 0; ki < KB; ++ki) {
         const int key = key0 + 16 * ki;
-        kf[ki] = rowfrag_global<bf16_t>(key < N ? kb + (int64_t)key * ld : nullptr, g, 0.125f * 1.4426950408889634f);   // hd^-0.5 and log2 e on K here
+        // K as it is: hd^-0.5 and log2 e are on Q, as in the forward and dQ kernels (round 6).  This kernel used to put the scale on K
+        // instead -- bf16(k c) . q against the forward's bf16(q c) . k: two different roundings of the same score, 2^-9 RELATIVE apart.
+        // At |score| ~ 10 log2 units that is 1 % in every probability; at the -140 a soak of the reference recipe reached, 0.19 log2
+        // units = 14 % in dK and dV against an lse that came from the other rounding (tools/probe/attn_extreme.py)
+        kf[ki] = rowfrag_global<bf16_t>(key < N ? kb + (int64_t)key * ld : nullptr, g, 1.0f);
         vf[ki] = rowfrag_global<bf16_t>(key < N ? vb + (int64_t)key * ld : nullptr, g, 1.0f);
     }
     const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (unsigned)(((int64_t)(N - 1) * ld + HD) * 2), 0x00020000);
@@ -940,6 +944,19 @@ __device__ __forceinline__ void attn_bwd_dkv_bf16_body(char* smem, const bf16_t*
     for (int j = 0; j < ntiles; ++j) {
         if (OWN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the statistics block was written with ds_write)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            // Q' = bf16(q * hd^-0.5 * log2 e), the forward kernel's own rounding, applied in place to the two 1-KiB pieces of the Q tile
+            // THIS wave's DMA wrote (lane-linear: piece base + 16 lane), before the barrier that publishes the tile
+            char* qt = smem + (j & 1) * STB + w * 2048 + lane * 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bf16x8 t = *(const bf16x8*)(qt + i * 1024);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (bf16_t)((float)t[e] * (0.125f * 1.4426950408889634f));
+                *(bf16x8*)(qt + i * 1024) = t;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (OWN && j + 1 < ntiles) stats_load(j + 1);
         if (j + 1 < ntiles) issue_tile(j + 1);
@@ -1026,7 +1043,7 @@ __device__ __forceinline__ void attn_bwd_dkv_bf16_body(char* smem, const bf16_t*
             bf16_t* vrow = krow + D;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                Vec4<bf16_t>::store(krow + dt * 16 + 4 * g, accK[ki][dt] * 0.125f);
+                Vec4<bf16_t>::store(krow + dt * 16 + 4 * g, accK[ki][dt] * 0.69314718055994531f);   // dK = hd^-0.5 dS^T q = dS^T Q' / log2 e
                 Vec4<bf16_t>::store(vrow + dt * 16 + 4 * g, accV[ki][dt]);
             }
         }

@@ -68,6 +68,8 @@ if "--no-first-step" not in sys.argv:
 
 hist = {}
 rate = {}
+torch.cuda.empty_cache()
+torch.cuda.reset_peak_memory_stats()       # (the first-step leg above ran an fp32 step: not the soak's peak)
 GRAPHS = os.environ.get("SOAK_GRAPHS", "auto")      # 'off': the eager two-stream schedule instead of the chain of per-stage graphs
 for mode in ("auto", "factored"):
     net, st = make(torch.bfloat16, mode)

@@ -15,16 +15,20 @@ from unmore_amd.trainer import TrainStep
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "auto"
 max_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+# NAN_HUNT_CFG = ref (default: dpt_large 128x128 batch 20) | cfg2 (dpt_base 384x384 batch 64) | cfg4 (dpt_large14 518x518 batch 16);
+# NAN_HUNT_DTYPE = bf16 (default) | fp32
+BACKBONE, SIZE, BATCH = {"ref": ("dpt_large", 128, 20), "cfg2": ("dpt_base", 384, 64), "cfg4": ("dpt_large14", 518, 16)}[os.environ.get("NAN_HUNT_CFG", "ref")]
+DT = torch.float32 if os.environ.get("NAN_HUNT_DTYPE") == "fp32" else torch.bfloat16
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-net = ObjectnessNet(dev, 128, "dpt_large", Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
-net.set_compute_dtype(torch.bfloat16)
+net = ObjectnessNet(dev, SIZE, BACKBONE, Namespace(use_bg_sdf=True, sdf_activation="tanh")).to(dev)
+net.set_compute_dtype(DT)
 net.set_sdf_head_mode(mode)
 net.train()
 pool = []
 for b in range(4):
-    _, cf, sdf, sal = synth.make_batch(20, 128, 128, seed=100 + b)
-    img = synth.blob_images(20, 128, 128, seed=100 + b)
+    _, cf, sdf, sal = synth.make_batch(BATCH, SIZE, SIZE, seed=100 + b)
+    img = synth.blob_images(BATCH, SIZE, SIZE, seed=100 + b)
     pool.append(tuple(torch.from_numpy(a).to(dev) for a in (img, cf, sdf, sal)))
 st = TrainStep(net, lr=1e-4, lr_milestones=(10000, 20000), lr_gamma=0.1).set_graph_mode("off")
 
@@ -174,4 +178,4 @@ while it < max_steps:
         break
     it += 1
 else:
-    print(f"no non-finite loss in {max_steps} steps ({mode})")
+    print(f"no non-finite loss or gradient in {max_steps} steps ({mode}, {os.environ.get('NAN_HUNT_CFG', 'ref')}, {'fp32' if DT == torch.float32 else 'bf16'})")

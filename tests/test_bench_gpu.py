@@ -29,6 +29,16 @@ def test_two_ranks_spawned_by_bench_itself():
     assert res["value"] > 0 and res["scaling"] == "weak" and "cpu_baseline" not in res
 
 
+def test_two_ranks_with_the_bf16_gradient_wire():
+    """`--dp-wire bf16` end to end (2 gloo ranks on the one GPU, miniature workload): the line says which wire was used, the step runs and
+    trains (finite loss); the exchange's accuracy is tests/test_parallel_cpu.py's and tests/test_dp_gpu.py's business"""
+    res = _run("--gpus", "2", "--workload", "tiny", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--dp-wire", "bf16")
+    assert res["n_gpus"] == 2 and res["collective"]["gradient_wire"] == "bf16" and res["value"] > 0
+    assert res["final_loss"] == res["final_loss"] and 0 < res["final_loss"] < 100
+    tr = res.get("allreduce_trace_rank0")
+    assert tr and "buckets" in tr and tr["buckets"][0]["mbytes"] > 0
+
+
 @pytest.mark.parametrize("workload,extra", [("tiny", []), ("cfg1", []), ("cfg5", ["--steps", "1", "--warmup", "1"]),
                                             ("cfg4", ["--steps", "1", "--warmup", "1", "--no-alt"])])
 def test_single_gpu_lines_carry_the_contract(workload, extra):

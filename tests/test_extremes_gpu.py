@@ -1,0 +1,163 @@
+"""Operands at the edges of their ranges (round 6).
+
+Both numerical bugs of round 6 lived in regimes no fixture and no random operand reaches: softmax is invariant to the reference that
+is subtracted, a probability of a padded key multiplies a zero row, ... until a long training run drives a head's scores to +-100.  The
+tests here build such regimes on purpose for the other kernels of the path: every output must be finite and must match a float64
+PyTorch evaluation of the same op (the reference's ops: timm LayerNorm / GELU / SDPA, train_objectness_net.py:215-261) at the suite's
+bars.  The attention cases proper are in tests/test_kernels_gpu.py (the captured operand, the constructed hazards)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _fin(*ts):
+    return all(bool(torch.isfinite(t.float()).all()) for t in ts)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_rows_with_a_huge_mean_constant_rows_and_huge_rows(dtype):
+    """rows = mean 3e3 + unit noise (E[x^2] - E[x]^2 would cancel to rubbish: the kernel's variance is two-pass), exactly constant rows
+    (variance 0: rstd = eps^-1/2), rows of magnitude 1e4 and 1e-4"""
+    from unmore_amd import ops
+    torch.manual_seed(0)
+    D = 768
+    rows = [3e3 + torch.randn(8, D), torch.full((4, D), 7.25), 1e4 * torch.randn(8, D), 1e-4 * torch.randn(8, D), torch.zeros(2, D)]
+    x = torch.cat(rows).to(DEV).to(dtype)
+    g = (1 + 0.1 * torch.randn(D)).to(DEV)
+    b = (0.1 * torch.randn(D)).to(DEV)
+    dy = torch.randn(x.shape).to(DEV).to(dtype)
+    y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-6)
+    dg, db = torch.empty(D, device=DEV), torch.empty(D, device=DEV)
+    dx = ops.layernorm_bwd(dy, x, g, mean, rstd, dg, db)
+    assert _fin(y, mean, rstd, dx, dg, db)
+    xr = x.double().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), g.double(), b.double(), eps=1e-6)
+    yr.backward(dy.double())
+    tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=6e-2)
+    # (the rows whose variance is ~0 amplify any input rounding by eps^-1/2 = 1000: compared on the rows with a real spread)
+    keep = torch.ones(x.shape[0], dtype=torch.bool, device=DEV)
+    keep[8:12] = False
+    keep[-2:] = False
+    if dtype == torch.bfloat16:
+        keep[:8] = False          # bf16 cannot hold 3e3 + unit noise: the noise IS the rounding
+    torch.testing.assert_close(y.double()[keep], yr.detach()[keep], **tol)
+    scale = float(xr.grad[keep].abs().max())
+    assert float((dx.double() - xr.grad)[keep].abs().max()) <= (2e-3 if dtype == torch.float32 else 6e-2) * scale
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu_epilogue_and_its_derivative_far_from_zero(dtype):
+    """fc1's epilogue (GELU + saved pre-activation) and the GELU'-masked data gradient with pre-activations of +-30 ... +-3e4: the fast erf
+    (Abramowitz-Stegun on exp2(-x^2 log2 e / 2)) must saturate, not overflow"""
+    from unmore_amd import _lib as L, ops
+    torch.manual_seed(1)
+    M, K, N = 256, 64, 128
+    A = torch.zeros(M, K)
+    A[:, 0] = torch.cat([torch.linspace(-3e4, 3e4, M // 2), torch.linspace(-40, 40, M // 2)])
+    B = torch.zeros(N, K)
+    B[:, 0] = 1.0
+    B[:, 1:] = 0.01 * torch.randn(N, K - 1)
+    A[:, 1:] = torch.randn(M, K - 1)
+    Ad, Bd = A.to(DEV).to(dtype), B.to(DEV).to(dtype)
+    h, hpre = ops.gemm_nt(Ad, Bd, None, act=L.ACT_GELU, c2_mode=2)
+    assert _fin(h, hpre)
+    pre = Ad.double() @ Bd.double().t()
+    ref = F.gelu(pre)
+    tol = dict(atol=1e-3, rtol=2e-5) if dtype == torch.float32 else dict(atol=5e-2, rtol=2e-2)
+    torch.testing.assert_close(h.double(), ref, **tol)
+    dyv = torch.randn(M, N).to(DEV).to(dtype)
+    Wt = torch.eye(N).to(DEV).to(dtype)
+    dpre = ops.gemm_nt(dyv, Wt, None, aux=hpre, mask_dgelu=True)
+    assert _fin(dpre)
+    pr = hpre.double().requires_grad_(True)
+    F.gelu(pr).backward(dyv.double())
+    torch.testing.assert_close(dpre.double(), pr.grad, atol=(1e-3 if dtype == torch.float32 else 6e-2), rtol=(1e-4 if dtype == torch.float32 else 3e-2))
+
+
+def test_loss_kernel_at_saturated_and_degenerate_maps():
+    """the four loss terms (train_objectness_net.py:215-254) where the boundary-distance map is saturated at +-1 exactly, equals its
+    target exactly (L1 kink), and the saliency is all 0 / all 1 for some images: finite values and gradients, equal to the oracle's"""
+    from oracle import objectness_oracle as orc
+    from unmore_amd import ops
+    torch.manual_seed(2)
+    B, H, W = 4, 32, 48
+    pc = torch.randn(B, 2, H, W)
+    gc = torch.randn(B, 2, H, W)
+    ps = torch.tanh(3 * torch.randn(B, 1, H, W))
+    ps[0] = 1.0
+    ps[1] = -1.0
+    gs = torch.tanh(torch.randn(B, 1, H, W))
+    gs[2] = ps[2]                      # exact equality: |pred - gt| == 0 everywhere in image 2
+    sal = (torch.rand(B, 1, H, W) > 0.5).float()
+    sal[0] = 0.0
+    sal[1] = 1.0
+    out5, dpc, dps = ops.objectness_loss(pc.to(DEV), ps.to(DEV), gc.to(DEV), gs.to(DEV), sal.to(DEV))
+    assert _fin(out5, dpc, dps)
+    loss_o, terms = orc.loss_terms({"center_fields": pc.double(), "sdf_maps": ps.double()}, gc.double(), gs.double(), sal.double())
+    assert abs(out5[0].item() - loss_o.item()) < 1e-5
+    for i, t in enumerate(terms):
+        assert abs(out5[1 + i].item() - t.item()) < 1e-5, i
+
+
+def test_adam_at_zero_gradients_zero_moments_and_huge_gradients():
+    """the optimizer launches (plain, device-scalar, copy-writing: one update expression since round 6) on g = 0 with v = 0 (0 / (0 + eps)),
+    on g = 1e18 (g^2 = 1e36 stays finite in f32; 1e20 would not and does not in torch either) and on ordinary values, against torch.optim.Adam"""
+    from unmore_amd import ops
+    n = 4096
+    torch.manual_seed(3)
+    g = torch.randn(n)
+    g[:64] = 0.0
+    g[64:128] = 1e18
+    g[128:192] = -1e-30
+    p0 = torch.randn(n)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-3)
+    bufs = [t.to(DEV) for t in (p0.clone(), g.clone(), torch.zeros(n), torch.zeros(n))]
+    hyper = torch.zeros(8, device=DEV)
+    for it in range(1, 4):
+        p.grad = g.clone()
+        opt.step()
+        ops.adam_set_hyper(hyper, it, 1e-3, 0.9, 0.999, 1e-8, 1.0)
+        ops.adam_step_hyper(bufs[0], bufs[1], bufs[2], bufs[3], hyper)
+    assert _fin(*bufs)
+    torch.testing.assert_close(bufs[0].cpu(), p.detach(), atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("N", [65, 577])
+def test_attention_with_identical_keys_one_dominant_key_and_tiny_values(N):
+    """uniform attention (every key identical: all scores equal), one key that dominates by 60 log2 units, and values of magnitude 1e-20
+    / 1e20 (bf16 has the f32 exponent range): forward and backward finite, equal to float64 softmax attention"""
+    from unmore_amd import ops
+    HD, heads, B = 64, 2, 3
+    gen = torch.Generator().manual_seed(N)
+    x = torch.zeros(B, N, 3, heads, HD)
+    x[:, :, 0] = torch.randn(B, N, heads, HD, generator=gen)
+    x[0, :, 1] = torch.randn(1, heads, HD, generator=gen)                       # image 0: identical keys
+    x[1, :, 1] = 0.1 * torch.randn(N, heads, HD, generator=gen)
+    x[1, 7, 1] = 6.0 * x[1, :, 0].mean(0) / x[1, :, 0].mean(0).norm(dim=-1, keepdim=True) * 8      # image 1: key 7 dominates for most queries
+    x[2, :, 1] = torch.randn(N, heads, HD, generator=gen)
+    x[:, :, 2] = torch.randn(B, N, heads, HD, generator=gen)
+    x[2, :, 2] *= 1e-20
+    x[0, :, 2] *= 1e20
+    xx = x.reshape(B * N, 3 * heads * HD).to(DEV).bfloat16()
+    dout = torch.randn(B * N, heads * HD, generator=gen).to(DEV).bfloat16()
+    out, lse = ops.attention_fwd(xx, B, N, heads, need_lse=True)
+    dqkv = ops.attention_bwd(xx, out, dout, lse, B, N, heads)
+    assert _fin(out, lse, dqkv)
+    xr = xx.double().view(B, N, 3, heads, HD).requires_grad_(True)
+    q, k, v = xr[:, :, 0].transpose(1, 2), xr[:, :, 1].transpose(1, 2), xr[:, :, 2].transpose(1, 2)
+    o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(HD), dim=-1) @ v
+    o.transpose(1, 2).reshape(B * N, heads * HD).backward(dout.double())
+    oref = o.detach().transpose(1, 2).reshape(B, N, heads * HD)
+    og = out.double().view(B, N, heads * HD)
+    gref = xr.grad.reshape(B, N, 3 * heads * HD)
+    gg = dqkv.double().view(B, N, 3 * heads * HD)
+    for b in range(B):                       # per image: their scales differ by 40 orders of magnitude
+        so, sg = float(oref[b].abs().max()), float(gref[b].abs().max())
+        assert float((og[b] - oref[b]).abs().max()) <= 3e-2 * so, b
+        assert float((gg[b] - gref[b]).abs().max()) <= 4e-2 * sg, b

@@ -38,7 +38,8 @@ def test_layernorm_rows_with_a_huge_mean_constant_rows_and_huge_rows(dtype):
     xr = x.double().requires_grad_(True)
     yr = F.layer_norm(xr, (D,), g.double(), b.double(), eps=1e-6)
     yr.backward(dy.double())
-    tol = dict(atol=2e-4, rtol=2e-4) if dtype == torch.float32 else dict(atol=6e-2, rtol=6e-2)
+    # (f32: a row at 3e3 has an ulp of 2.4e-4 -- the mean's own rounding is that large against a unit spread)
+    tol = dict(atol=1e-3, rtol=1e-3) if dtype == torch.float32 else dict(atol=6e-2, rtol=6e-2)
     # (the rows whose variance is ~0 amplify any input rounding by eps^-1/2 = 1000: compared on the rows with a real spread)
     keep = torch.ones(x.shape[0], dtype=torch.bool, device=DEV)
     keep[8:12] = False
@@ -47,7 +48,7 @@ def test_layernorm_rows_with_a_huge_mean_constant_rows_and_huge_rows(dtype):
         keep[:8] = False          # bf16 cannot hold 3e3 + unit noise: the noise IS the rounding
     torch.testing.assert_close(y.double()[keep], yr.detach()[keep], **tol)
     scale = float(xr.grad[keep].abs().max())
-    assert float((dx.double() - xr.grad)[keep].abs().max()) <= (2e-3 if dtype == torch.float32 else 6e-2) * scale
+    assert float((dx.double() - xr.grad)[keep].abs().max()) <= (5e-3 if dtype == torch.float32 else 6e-2) * scale
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -833,7 +833,7 @@ def test_cu_budget_does_not_change_results(umr_opts):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_xcd_tile_order_does_not_change_results(dtype, umr_opts):
     """The 128x128 NT kernel walks an XCD's run of tiles n-fastest or m-fastest (csrc/gemm_nt.hip: the operand every XCD has to fetch
-    whole should be the smaller one; UMR_NT_ORDER forces an order per launch).  Which workgroup computes a tile never changes the
+    whole should be the smaller one; UMR_NT_ORDER forces an order: umr_set_debug_option).  Which workgroup computes a tile never changes the
     tile's arithmetic: both orders and the library's own choice are bit-identical, with and without split-K, ragged edges included."""
     from unmore_amd import ops, _lib as L
     dev = _dev()

@@ -164,7 +164,7 @@ def test_attention_backward_when_every_score_is_far_below_zero(N):
 @pytest.mark.parametrize("B,N,heads", [(20, 65, 16), (3, 100, 2), (2, 17, 1), (1, 127, 3)])
 def test_attention_backward_of_short_sequences_in_one_launch(B, N, heads, umr_opts):
     """N < 128 in bf16: dQ and dK / dV workgroups in ONE launch, each taking its rows' -lse and rowsum(dO * O) itself
-    (attn_bwd_small_bf16_kernel) -- against the three launches (prep, dQ, dK / dV; UMR_ATTN_BWD_FUSED=0, read per launch).  The same
+    (attn_bwd_small_bf16_kernel) -- against the three launches (prep, dQ, dK / dV; UMR_ATTN_BWD_FUSED=0 through umr_set_debug_option).  The same
     arithmetic per output except the order of the 64 products in rowsum(dO * O): a last-bit difference there flips the bf16 rounding of
     a few dS entries, so the outputs agree to a few bf16 roundings, and most of them exactly."""
     from unmore_amd import ops

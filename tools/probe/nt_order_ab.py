@@ -1,4 +1,4 @@
-"""Tile order of the 128x128 NT kernel inside an XCD's run (UMR_NT_ORDER=n|m, read per launch): the reference recipe's GEMM shapes (1300 tokens, ViT-L),
+"""Tile order of the 128x128 NT kernel inside an XCD's run (UMR_NT_ORDER=n|m: ops.set_debug_option): the reference recipe's GEMM shapes (1300 tokens, ViT-L),
 weights rotated through a pool larger than the infinity cache (as in the step, where every layer's weights arrive cold), alternating orders.
 python tools/probe/nt_order_ab.py"""
 import os, sys

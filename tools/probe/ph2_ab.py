@@ -1,4 +1,4 @@
-"""Two-phase against four-phase K-tile of the persistent 256x256 kernel on plain GEMMs (UMR_NT256_PH2=1 / 0, read per launch; unset =
+"""Two-phase against four-phase K-tile of the persistent 256x256 kernel on plain GEMMs (UMR_NT256_PH2=1 / 0: ops.set_debug_option; unset =
 the host's choice: two-phase from 12 K-tile steps on), one process, same box.   python tools/probe/ph2_ab.py   (MI355X)"""
 import os
 import sys

@@ -71,7 +71,7 @@ template <typename T, int CONV, int EPI, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const umr_gemm_desc p, int tiles_n, int splits_arg, float* __restrict__ skws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // splits_arg < 0: the split-K hand-over in its textbook form (agent-scope release / acquire fences) -- chosen at run time
-    // (env UMR_SPLITK_FENCE=1, read per launch) or at build time (-DUMR_SPLITK_FENCE: libumr_fence.so)
+    // (umr_set_debug_option("UMR_SPLITK_FENCE", "1"); the environment variable is read once, at load) or at build time (-DUMR_SPLITK_FENCE: libumr_fence.so)
 #ifdef UMR_SPLITK_FENCE
     const bool fenced = true;
 #else

@@ -371,8 +371,14 @@ def run_rank(a):
         torch.cuda.set_device(local % ndev)   # gloo rehearsal on a 1-GPU box: ranks share the device
         dev = torch.device("cuda", local % ndev)
     coll = {"backend": "none", "world": world}
-    if world > 1:
+    # UMR_DP_FORCE=1: the data-parallel path in a process group of ONE rank (a builder's box has one GPU and RCCL refuses two ranks on
+    # a device): every bucket goes through ProcessGroupNCCL (parallel.BucketedAllReduce(force=...)), the line says so in `collective`
+    dist_on = world > 1 or os.environ.get("UMR_DP_FORCE", "0") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if a.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
             try:
@@ -384,11 +390,13 @@ def run_rank(a):
             dist.init_process_group("gloo")
             coll = {"backend": "gloo", "world": dist.get_world_size()}
 
-    if world > 1:
+    if dist_on:
         coll["gradient_wire"] = a.dp_wire
+        if world == 1:
+            coll["forced_single_rank"] = True
 
     def barrier():
-        if world > 1:
+        if dist_on:
             if a.backend == "nccl" and dev.type == "cuda":
                 dist.barrier(device_ids=[dev.index])
             else:
@@ -397,7 +405,7 @@ def run_rank(a):
             torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world > 1:
+        if dist_on:
             t = torch.tensor([x], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
@@ -405,7 +413,7 @@ def run_rank(a):
 
     def gather_over_ranks(x):
         """every rank's own figure, in rank order (for the per-rank rates in the line)"""
-        if world > 1:
+        if dist_on:
             t = torch.zeros(world, dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             t[rank] = x
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -500,7 +508,7 @@ def run_rank(a):
     from unmore_amd.engine import WgradStream
     # (data-parallel train steps replay too where the chain-of-graphs form applies -- trainer.TrainStep: the collectives are issued between
     # the chain's graph launches; inference sweeps with world > 1 are replicas and replay as at world 1)
-    graphed = ((world == 1 or kind != "train" or (graphs.STAGED and WgradStream.wanted(pixels)))
+    graphed = ((not dist_on or kind != "train" or (graphs.STAGED and WgradStream.wanted(pixels)))
                and graphs.wanted(a.graphs, pixels, train=(kind == "train"), two_streams=WgradStream.wanted(pixels)))
     warm = a.warmup + (graphs.WARMUP_CALLS + 1 if graphed and kind != "sweep" else 0)   # two eager calls + the capturing call, untimed
     for _ in range(warm):
@@ -535,7 +543,7 @@ def run_rank(a):
         drained.append(time.perf_counter() - th)
     torch.cuda.synchronize()
     ar_trace = None
-    if world > 1 and kind == "train":
+    if dist_on and kind == "train":
         # one more, untimed step with the exchange traced: per bucket, when its all-reduce was issued and when it completed, against
         # the end of backward (parallel.BucketedAllReduce.trace_report) -- how much of the exchange hides behind backward
         # (never at the price of the line: whatever goes wrong here is reported in place of the trace)
@@ -674,7 +682,7 @@ def run_rank(a):
         hip_peaks = None
         if kind == "sweep":
             res["maps_with_peak_share"] = res["maps_with_peak"] / wl["proposals"]
-        if world == 1 and kind == "sweep" and not a.no_alt:
+        if not dist_on and kind == "sweep" and not a.no_alt:
             def timed_sweeps(n):
                 one()
                 torch.cuda.synchronize()
@@ -759,7 +767,7 @@ def run_rank(a):
         if kind != "train":
             res["sdf_head"] = ("inference default 'auto': the boundary-distance head (no non-linearity before its tanh, objectness_net.py:128-135) "
                                "evaluated as one 3x3 conv 256 -> 1 on the map before the final resize; 'factored' leg beside it")
-        if world == 1 and kind == "forward" and not a.no_alt:
+        if not dist_on and kind == "forward" and not a.no_alt:
             # the same call with the boundary-distance head as the reference's four convolutions (A/B of the inference default)
             net.set_sdf_head_mode("factored")
             for _ in range(graphs.WARMUP_CALLS + 2):
@@ -773,7 +781,7 @@ def run_rank(a):
             net.set_sdf_head_mode("auto")
             res["alt_factored_sdf_head"] = {"value": B / dtf, "unit": "images/sec", "ms_per_step": 1e3 * dtf,
                                             "note": "set_sdf_head_mode('factored'): the head's four convolutions as the reference runs them"}
-        if world == 1 and kind == "train" and a.workload == "cfg2" and not a.no_alt:
+        if not dist_on and kind == "train" and a.workload == "cfg2" and not a.no_alt:
             # outside the timed region, reported BESIDE the headline: the same step with the boundary-distance head in its other forms
             # (identical function and gradients up to rounding, tests/test_train_gpu.py::
             # test_collapsed_sdf_head_equals_factored, tests/test_collapsed_train_gpu.py)
@@ -799,10 +807,10 @@ def run_rank(a):
             res["alt_gemm_backward_sdf_head"] = alt_leg("factored forward + boundary-distance head backward as layer-by-layer GEMMs (the reference's own schedule of operations)")
             net.set_linear_head_backward("algebraic")
             net.set_sdf_head_mode("auto")
-        if world == 1 and not a.no_cpu_baseline:
+        if not dist_on and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl, hip_peaks)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         barrier()
         dist.destroy_process_group()
     return 0

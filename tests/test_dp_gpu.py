@@ -169,3 +169,75 @@ def test_data_parallel_step_replays_the_chain_of_graphs_bit_identically(tmp_path
     print(f"{backbone}: first-step gradient over the bf16 wire vs the f32 wire: relative L2 {rel:.2e}, cosine {cos:.7f}")
     assert rel <= 6e-3 and cos > 0.9999
     assert bool(torch.isfinite(wired["losses"]).all())
+
+
+def _worker_rccl_one_rank(rank, world, port, out_dir, backbone, B, H, W, dtype_name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from argparse import Namespace
+    from unmore_amd import graphs, synth
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd.trainer import TrainStep
+    torch.manual_seed(0)
+    init = {k: v.clone() for k, v in ObjectnessNet("cpu", H, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh")).state_dict().items()}
+    warm = torch.ones(1 << 20, device="cuda:0")
+    dist.all_reduce(warm)                        # the communicator is created by its first collective: outside every timed / compared region
+    torch.cuda.synchronize()
+    assert float(warm.sum()) == float(1 << 20)
+    for name, force, mode, wire in (("plain", "0", "off", None), ("rccl_eager", "1", "off", None), ("rccl_chain", "1", "auto", None),
+                                    ("rccl_chain_traced", "1", "auto", None), ("rccl_chain_bf16", "1", "auto", torch.bfloat16)):
+        os.environ["UMR_DP_FORCE"] = force
+        net = ObjectnessNet("cuda:0", H, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+        net.load_state_dict(init, strict=True)
+        net = net.to("cuda:0")
+        net.set_compute_dtype(getattr(torch, dtype_name))
+        step = TrainStep(net, lr=1e-4, grad_wire_dtype=wire).set_graph_mode(mode)
+        assert step.comm.enabled == (force == "1") and step.comm.world == 1
+        losses, first_g, trace = [], None, None
+        for it in range(6):
+            img, cf, sdf, sal = (torch.from_numpy(a).cuda() for a in synth.make_batch(B, H, W, seed=40 + it))
+            if name == "rccl_chain_traced" and it == 4:
+                step.comm.trace = True           # what bench.py does for one untimed step at world > 1: per-bucket issue / completion events
+            losses.append(step.step(img, cf, sdf, sal).cpu())
+            if step.comm.trace:
+                trace = step.comm.trace_report()
+                step.comm.trace = False
+            if it == 0:
+                first_g = step.flat_g.cpu()
+        torch.cuda.synchronize()
+        if mode != "off":
+            assert step.graph_replays == 4, step.graph_replays
+            caps = [c for c in step._graphs.values() if isinstance(c, graphs.StagedCaptured)]
+            assert len(caps) == 1 and any(l == "scall" for l, _ in caps[0].segments) and any(l == "call" for l, _ in caps[0].segments)
+        if trace is not None:
+            assert len(trace["buckets"]) == step.comm.num_buckets and all(r["done_ms"] >= r["issue_ms"] for r in trace["buckets"]), trace
+        torch.save({"flat_p": step.flat_p.cpu(), "flat_g": step.flat_g.cpu(), "first_g": first_g, "losses": torch.stack(losses), "trace": trace},
+                   os.path.join(out_dir, f"{name}.pt"))
+        del step, net
+        torch.cuda.empty_cache()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backbone,B,H,W,dtype_name", [("dpt_tiny", 2, 64, 64, "float32"), ("dpt_large", 20, 128, 128, "bfloat16")])
+def test_gradient_exchange_through_rccl_in_a_group_of_one_rank(tmp_path, backbone, B, H, W, dtype_name):
+    """The exchange through the REAL backend.  RCCL refuses two ranks on one device, so the two-rank tests above use gloo, whose
+    transport synchronises on the host: it cannot show a missing stream dependency around a collective.  A process group of one rank on
+    the "nccl" backend (UMR_DP_FORCE=1: parallel.BucketedAllReduce exchanges even at world 1) takes every bucket through
+    ProcessGroupNCCL: the collective's own stream ordered behind the issuing lane, work handles waited for on the main lane before the
+    optimizer, the watchdog thread polling events while the chain of graphs is recorded, the per-bucket trace events of bench.py, the bf16
+    wire's dtype.  A sum over one rank is the identity: six steps, eager and replayed from the chain of per-stage graphs, must equal the
+    step without any exchange bit for bit; the bf16 wire differs by one rounding of the gradient."""
+    mp.spawn(_worker_rccl_one_rank, args=(1, _free_port(), str(tmp_path), backbone, B, H, W, dtype_name), nprocs=1, join=True)
+    r = {n: torch.load(os.path.join(tmp_path, f"{n}.pt")) for n in ("plain", "rccl_eager", "rccl_chain", "rccl_chain_traced", "rccl_chain_bf16")}
+    for n in ("rccl_eager", "rccl_chain", "rccl_chain_traced"):
+        assert torch.equal(r["plain"]["losses"], r[n]["losses"]), n
+        assert torch.equal(r["plain"]["flat_g"], r[n]["flat_g"]) and torch.equal(r["plain"]["flat_p"], r[n]["flat_p"]), n
+    print(backbone, "per-bucket trace of one replayed step through RCCL (world 1):", r["rccl_chain_traced"]["trace"])
+    a, b = r["rccl_chain_bf16"]["first_g"].double(), r["plain"]["first_g"].double()
+    rel = float((a - b).norm() / b.norm())
+    assert torch.equal(r["plain"]["losses"][0], r["rccl_chain_bf16"]["losses"][0])
+    assert rel <= 3e-3, rel                      # one rounding to bf16 (uniform relative error <= 2^-9: rms 2^-9 / sqrt 3 = 1.1e-3)
+    assert bool(torch.isfinite(r["rccl_chain_bf16"]["losses"]).all())

@@ -106,7 +106,7 @@ class Captured:
         self.store = {}
         _state["capturing"], _state["store"], _state["forks"] = True, self.store, []
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (see StagedCaptured._begin)
                 try:
                     outs = fn(*self.static_in)
                 except BaseException:
@@ -217,7 +217,9 @@ class StagedCaptured:
     # ---- capture side (called through engine.WgradStream while fn runs)
     def _begin(self, lane_):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._pools[lane_])
+        # (thread_local: only THIS thread's calls are policed while the stream records -- a data-parallel process has RCCL's watchdog
+        # thread polling its work events beside the capture)
+        g.capture_begin(pool=self._pools[lane_], capture_error_mode="thread_local")
         self._cur = (lane_, g, _launches[0])
         _state["lane"] = lane_
 

@@ -6,6 +6,7 @@ buckets laid out in backward-completion order so the exchange overlaps the rest 
 backward, then scale by 1/world inside the Adam kernel.
 
 Device-agnostic on purpose (tested with gloo on CPU, world_size 2)."""
+import os
 import time
 
 import torch
@@ -13,7 +14,7 @@ import torch.distributed as dist
 
 
 class BucketedAllReduce:
-    def __init__(self, flat, boundaries, group=None, wire_dtype=None):
+    def __init__(self, flat, boundaries, group=None, wire_dtype=None, force=None):
         """flat: 1-D gradient buffer; boundaries: ascending element offsets [0, ..., flat.numel()];
         bucket k = flat[boundaries[k]:boundaries[k+1]] becomes ready when `ready(k)` is called.
         wire_dtype: None = exchange the f32 gradients as they are (default).  torch.bfloat16 = exchange bf16 copies (half the bytes
@@ -22,11 +23,17 @@ class BucketedAllReduce:
         collective (bf16 arithmetic: one more rounding per addition); finish() widens the result back into `flat` and returns
         scale 1.0.  Error of the exchanged gradient against the f32 exchange: ~2^-9 relative per element from the rounding of the
         inputs plus <= 2^-9 per addition (tests/test_parallel_cpu.py asserts relative L2 <= 6e-3 at world 2); it is the same order
-        as the bf16 step's own gradient error against fp32 (relative L2 0.02-0.03)."""
+        as the bf16 step's own gradient error against fp32 (relative L2 0.02-0.03).
+        force (default: env UMR_DP_FORCE=1): exchange even in a process group of ONE rank.  A builder with one GPU cannot run RCCL at
+        world > 1 (it refuses two ranks on one device); at world 1 the "nccl" backend still takes every bucket through
+        ProcessGroupNCCL -- its own stream ordered behind the issuing lane, asynchronous work handles, the watchdog thread beside a
+        graph capture -- which is the part of the path gloo's host-side transport does not exercise (tests/test_dp_gpu.py)."""
+        if force is None:
+            force = os.environ.get("UMR_DP_FORCE", "0") == "1"
         assert flat.dim() == 1 and boundaries[0] == 0 and boundaries[-1] == flat.numel()
         assert wire_dtype in (None, torch.float32, torch.bfloat16)
         self.flat, self.bounds, self.group = flat, list(boundaries), group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or bool(force))
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.wire = None
         if self.enabled and wire_dtype == torch.bfloat16:

@@ -38,7 +38,7 @@ class BucketedAllReduce:
         self.wire = None
         if self.enabled and wire_dtype == torch.bfloat16:
             self.wire = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
-        self._pending = []
+        self._pending = {}          # bucket -> work handle of its all-reduce, in issue order
         self._sent = []
         # trace (bench.py switches it on for ONE untimed step when world > 1): per bucket, when its all-reduce was issued behind the
         # backward kernels that produce it and when it completed, on the device's timeline (events) for GPU buffers, on the host
@@ -77,7 +77,7 @@ class BucketedAllReduce:
         else:
             buf = self.flat[lo:hi]
         if not self.trace:
-            self._pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._pending[k] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             return
         gpu = self.flat.is_cuda
         if self._t0 is None:       # time zero: the first bucket's issue point
@@ -100,7 +100,21 @@ class BucketedAllReduce:
             t_issue = time.perf_counter()
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._trace.append([k, (hi - lo) * buf.element_size(), t_issue, None, work])
-        self._pending.append(work)
+        self._pending[k] = work
+
+    def wait(self, k):
+        """Make the CURRENT stream wait for bucket k's exchange (bf16 wire: and widen the sums back into `flat` there): what follows on
+        this stream may read the bucket's exchanged gradient -- the optimizer update of its stage, a few stages of backward later
+        (trainer.TrainStep: small problems update stage by stage on the weight-gradient lane instead of after finish()).  A bucket
+        that was not sent, or was waited for already, is a no-op; finish() covers whatever is left."""
+        w = self._pending.pop(k, None)
+        if w is None:
+            return
+        w.wait()
+        if self.wire is not None and k in self._sent:
+            lo, hi = self.bounds[k], self.bounds[k + 1]
+            self.flat[lo:hi].copy_(self.wire[lo:hi])
+            self._sent.remove(k)
 
     def finish(self):
         """Wait for every launched bucket; returns the scale (1/world) the optimizer must apply."""
@@ -110,14 +124,14 @@ class BucketedAllReduce:
                 self._end.record()                 # the compute stream has enqueued all of backward
             else:
                 self._end = time.perf_counter()
-        for w in self._pending:
+        for w in self._pending.values():
             w.wait()
         if self.trace and not self.flat.is_cuda:
             for e in self._trace:
                 if e[3] is None:
                     e[4].wait()
                     e[3] = time.perf_counter()
-        self._pending = []
+        self._pending = {}
         if self.wire is not None:
             for k in self._sent:       # widen the exchanged bf16 sums back into the f32 gradient buffer the optimizer reads
                 lo, hi = self.bounds[k], self.bounds[k + 1]

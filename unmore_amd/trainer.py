@@ -19,6 +19,7 @@ from .parallel import BucketedAllReduce
 _BATCHED_REPACK = os.environ.get("UMR_BATCHED_REPACK", "1") != "0"   # A/B switch: 0 = drop the packed copies, re-pack lazily (round 2)
 # A/B switch: 0 = per stage, the Adam launch and then the batched refresh of its packed copies (round 5); 1 = the Adam launch writes the
 # bf16 copies of the stage's Linear weights itself (round 6: ops.adam_pack; bit-identical)
+_DP_ADAM_LAG = max(1, int(os.environ.get("UMR_DP_ADAM_LAG", "2")))   # stages between a bucket's all-reduce and its optimizer update
 _ADAM_PACK = os.environ.get("UMR_ADAM_PACK", "1") != "0"
 
 
@@ -147,22 +148,44 @@ class TrainStep:
         # behind the stage's weight gradients; the main lane waits for the exchange only in finish(), before the optimizer update)
         staged = graphs.staged() if self.comm.enabled else None
 
+        lagq = []      # data-parallel small problems: stages whose all-reduce is in flight; updated _DP_ADAM_LAG stages later
+
         def stage_done(stage, wg):
             k = self.stage_bucket[stage]
             if staged is not None:
                 staged.defer_host(lambda k=k: self.comm.ready(k))
             else:
                 self.comm.ready(k)
+            if not (wg.on and _BATCHED_REPACK):
+                return
             # (not the reassemble stage: the readout projections are read again when the transformer's backward reaches a hooked
             # block -- the token gradient goes through them, models/dpt/vit.py:86-90 -- so they are updated after backward)
-            if wg.on and not self.comm.enabled and _BATCHED_REPACK and stage != "reassemble":
-                # small problems: this stage's Adam update and the refresh of its packed weight copies go behind its weight
-                # gradients on the second stream -- HBM-bound work beside the (latency-bound) rest of backward.  Nothing later in
-                # this step reads the stage's weights again; the final join of backward orders the next step after them.
-                def launch():
-                    update_and_refresh(stage, k)
-                wg.run(launch)
-                updated.add(k)
+            if not self.comm.enabled:
+                if stage != "reassemble":
+                    # small problems: this stage's Adam update and the refresh of its packed weight copies go behind its weight
+                    # gradients on the second stream -- HBM-bound work beside the (latency-bound) rest of backward.  Nothing later in
+                    # this step reads the stage's weights again; the final join of backward orders the next step after them.
+                    def launch():
+                        update_and_refresh(stage, k)
+                    wg.run(launch)
+                    updated.add(k)
+                return
+            # data-parallel: the same, _DP_ADAM_LAG stages LATER -- once the bucket's all-reduce, issued above, has had that many
+            # stages of backward to complete, the weight-gradient lane waits for it (BucketedAllReduce.wait: a stream dependency, the
+            # host does not block) and updates the stage.  Without this the whole optimizer pass (9.7 GB of traffic for ViT-L) sits
+            # exposed behind finish(): +2.1 ms on the reference recipe's 18.5-ms step (profiles/r06_rccl_one_rank.jsonl).  The last
+            # _DP_ADAM_LAG stages and the reassemble stage are updated after finish(), on the main lane.
+            if stage != "reassemble":
+                lagq.append((stage, k))
+            if len(lagq) > _DP_ADAM_LAG:
+                ps, pk = lagq.pop(0)
+                if staged is not None:
+                    staged.defer_host(lambda pk=pk: self.comm.wait(pk))
+                    wg.run(lambda ps=ps, pk=pk: update_and_refresh(ps, pk))
+                else:                              # eager (the warm-up steps before the capture, --graphs off): on the main stream,
+                    self.comm.wait(pk)             # which joins the weight-gradient stream at every stage in this form
+                    update_and_refresh(ps, pk)
+                updated.add(pk)
 
         eng.backward(self.P, S, dpc, dps, self.G, stage_cb=stage_done, join_at_stages=self.comm.enabled and staged is None)
         if staged is not None:

@@ -106,6 +106,28 @@ def attention():
     print()
 
 
+def valu_rates():
+    f = P("r06_valu_rates.jsonl")
+    if not os.path.exists(f):
+        return
+    rows = [json.loads(l) for l in open(f) if l.startswith("{")]
+    dev = rows[0]
+    by = {}
+    for d in rows[1:]:
+        by.setdefault(d["case"], {})[d["waves_per_simd"]] = d
+    ghz = dev["clock_mhz"] / 1000.0
+    print("### What one SIMD needs for the instructions of an attention tile (`profiles/r06_valu_rates.jsonl`, `tools/probe/valu_rates.hip`; "
+          f"{dev['cus']} CUs, cycles at the nominal {ghz:.1f} GHz)\n")
+    print("One 16x16x32 bf16 MFMA = 16,384 FLOP = 64 scores of a head-dim-64 forward (4 x 64 FLOP per score), i.e. ONE wave-wide instruction of every per-score step.\n")
+    print("| instruction stream (16 independent chains per wave) | ns per instruction group per SIMD: 1 / 2 / 4 waves per SIMD | cycles at 4 waves | matrix pipe's share of the 2.5-PFLOP/s peak if this were the whole tile loop (4 waves) |")
+    print("|---|---|---|---|")
+    for case, w in by.items():
+        ns = [w[k]["ns_per_wave_instruction_group_per_simd"] for k in (1, 2, 4)]
+        share = w[4]["mfma_share_of_peak_if_this_were_the_tile_loop"]
+        print(f"| `{case}` | {ns[0]:.2f} / {ns[1]:.2f} / {ns[2]:.2f} | {ns[2] * ghz:.1f} | {'%.3f' % share if share > 0 else '-'} |")
+    print()
+
+
 def adam_ab():
     f = P("r06_adam_pack_ab.txt")
     if not os.path.exists(f):
@@ -129,4 +151,5 @@ lines()
 breakdown("r06_pmc_traffic.json", 8, "cfg2 train step by kernel group")
 roofline()
 attention()
+valu_rates()
 adam_ab()

@@ -351,6 +351,13 @@ int umr_center_peaks_certified(const float* sdf_maps, const float* center_fields
                                int64_t* argmax, int32_t* certified, int B, int H, int W, int border, int erode_kernel, int erode_rounds,
                                float eps, double singular_threshold, umr_stream_t stream);
 int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream);
+/* nms: torchvision.ops.nms as object_reasoning.py:661 calls it -- `order` = the boxes' indices by descending score (the caller sorts;
+ * equal scores -- the reference passes its labels, all ones -- keep their input order), greedy: a box is kept unless an earlier kept one
+ * overlaps it with IoU > iou_threshold (f32: inter / (area_a + area_b - inter)).  keep[0 .. *n_keep) = the kept boxes' indices in rank
+ * order; keep has room for n, n_keep is one int32 on the device.  n <= 4096; workspace: umr_nms_workspace(n) bytes, 8-byte aligned. */
+int64_t umr_nms_workspace(int n);
+int umr_nms(const float* boxes, const int64_t* order, int n, float iou_threshold, void* workspace, int64_t workspace_bytes,
+            int64_t* keep, int32_t* n_keep, umr_stream_t stream);
 
 /* ---- collapsed linear head (opt-in; SURVEY.md section 7 "the sdf head has no nonlinearity before tanh") ------
  * A head whose four convolutions have no activation between them (objectness_net.py:119-142) equals ONE 3x3 conv

@@ -525,3 +525,28 @@ def update_bbox_with_boundary_fields(sdf_maps):
     mv = step * s
     return (-torch.amax(mv[:, :, 0], dim=1), -torch.amax(mv[:, 0, :], dim=1), torch.amax(mv[:, :, -1], dim=1),
             torch.amax(mv[:, -1, :], dim=1))
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms (object_reasoning.py:661; torchvision is absent from this image: restated from its documented algorithm and
+    its CPU kernel's arithmetic -- UNPINNED boundary): boxes by descending score (stable: equal scores keep their input order), greedily
+    keep a box unless a kept one overlaps it with IoU > threshold; IoU in float32 as inter / (area_a + area_b - inter).
+    numpy in, kept indices (int64, rank order) out."""
+    b = np.asarray(boxes, dtype=np.float32)
+    order = np.argsort(-np.asarray(scores, dtype=np.float64), kind="stable")
+    keep, removed = [], np.zeros(len(b), dtype=bool)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    for r, i in enumerate(order):
+        if removed[r]:
+            continue
+        keep.append(int(i))
+        for r2 in range(r + 1, len(order)):
+            j = order[r2]
+            w = np.float32(max(np.float32(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0])), np.float32(0)))
+            h = np.float32(max(np.float32(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1])), np.float32(0)))
+            inter = np.float32(w * h)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                iou = np.float32(inter / np.float32(np.float32(area[i] + area[j]) - inter))
+            if iou > np.float32(iou_threshold):
+                removed[r2] = True
+    return np.asarray(keep, dtype=np.int64)

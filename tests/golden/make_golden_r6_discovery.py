@@ -1,0 +1,119 @@
+"""Round-6 golden fixtures for the CALLER of the hot path at inference: the reference's `Object_Discovery`
+(object_reasoning.py:43-665), made by running the REFERENCE's own methods on the CPU.
+
+Run in the build container only (needs /root/reference; never shipped):
+    python tests/golden/make_golden_r6_discovery.py
+
+What executes verbatim from the reference (bound to an instance made with `__new__`: its `__init__` builds the COCO dataset, loads two
+checkpoints and writes a results folder, none of which exist here):
+    generate_random_proposal :109-137, post_process_bbox_update :176-197, enlarge_proposals :259-291, filter_small_proposal :293-299,
+    get_prediction_with_proposals :301-337, existence_checking :491-523, center_reasoning :525-580 (with batch_erode, utils/misc.py:10-20,
+    and center_field_to_anti_center_map :360-377), optimize_one_image_single_round :379-487 (with update_bbox_with_boundary_fields
+    :139-174), boundary_reasoning :582-612, and the statement sequence of main_object_discovery :626-657 for one image (replayed here
+    step by step: the method itself reads a dataset and writes JSON).
+The two networks are the stand-ins of tests/discovery_stubs.py on both sides: they read object-like fields back out of the crop
+(unmore_amd.synth.reasoning_scene), so everything AROUND the networks -- crops, thresholds, masks, erosion, peaks, box splits, the fifty
+boundary rounds, label rules, filters -- is the reference's own arithmetic on the reference's own crops.
+What cannot execute: torchvision (absent).  `transforms.Resize((128, 128), BILINEAR)` on a tensor is torchvision 0.14's
+F.interpolate(mode="bilinear", align_corners=False) without antialias (README.md:25 pins 0.14.1; UNPINNED boundary, as in
+tests/test_reasoning_gpu.py); `torchvision.ops.nms` (:661) is not run -- the fixture ends with the boxes that go INTO it.
+torchmetrics.image_gradients: restated in make_golden_r2.py (UNPINNED).  Only DATA is written."""
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import make_golden_r2 as g2          # noqa: E402  (placeholders for the import-only modules of object_reasoning.py)
+from unmore_amd import synth          # noqa: E402
+from discovery_stubs import FieldsFromCrop, ObjectFraction   # noqa: E402
+
+
+class ResizeTensor:
+    """torchvision.transforms.Resize for a [C,h,w] tensor (0.14: bilinear, align_corners=False, no antialias)"""
+    def __init__(self, size, interpolation=None):
+        self.size = size
+
+    def __call__(self, img):
+        return F.interpolate(img.unsqueeze(0), size=self.size, mode="bilinear", align_corners=False).squeeze(0)
+
+
+def reference_instance(args):
+    g2.install_placeholders()
+    tv = sys.modules["torchvision"]
+    tv.transforms.Resize = ResizeTensor
+    sys.path.insert(0, REF)
+    import object_reasoning as orz
+    if not hasattr(orz, "torchvision"):
+        orz.torchvision = tv
+    orz.transforms.Resize = ResizeTensor
+    od = orz.Object_Discovery.__new__(orz.Object_Discovery)
+    od.args, od.device = args, torch.device("cpu")
+    od.objectness_model, od.binary_classifier_model = FieldsFromCrop(), ObjectFraction()
+    return od
+
+
+SCENES = {"a": (240, 320, 0, 4), "b": (200, 288, 5, 6)}      # tests/test_object_discovery_gpu.py reads the same table
+
+
+def main():
+    args = Namespace(class_score_thres=0.1, center_score_max_thres=0.009, analyze_cc=False, max_sdf_thres=0.5, max_shrink_threshold=16,
+                     delta_ratio=0.5, n_round=50, proposal_area_thres=50)            # the reference's defaults, object_reasoning.py:701-710
+    od = reference_instance(args)
+    save = {}
+    for tag, (H, W, seed, nobj) in SCENES.items():
+        image = torch.from_numpy(synth.reasoning_scene(H, W, seed, nobj))
+        od.height, od.width = H, W
+        p0 = od.generate_random_proposal(height=H, width=W)
+        save[f"{tag}_proposals0"] = p0
+        proposals = torch.tensor(p0)
+        ex = od.existence_checking(image, proposals)["existence_scores"]
+        save[f"{tag}_existence0"] = ex.numpy()
+        proposals = proposals[ex >= args.class_score_thres]
+        cr = od.center_reasoning(image, proposals)
+        passed, split = cr["proposals_pass_singularity"], cr["splited_new_proposals"]
+        save[f"{tag}_pass1"], save[f"{tag}_split1"] = passed.numpy(), split.numpy()
+        ex2 = od.existence_checking(image, split)["existence_scores"]
+        save[f"{tag}_existence1"] = ex2.numpy()
+        split = split[ex2 >= args.class_score_thres]
+        cr2 = od.center_reasoning(image, split)
+        save[f"{tag}_pass2"], save[f"{tag}_split2"] = cr2["proposals_pass_singularity"].numpy(), cr2["splited_new_proposals"].numpy()
+        proposals = torch.cat((passed, cr2["proposals_pass_singularity"]), dim=0)
+        save[f"{tag}_boundary_in"] = proposals.numpy()
+        # the first three rounds one by one (what boundary_reasoning does per round, :598-606), then the whole loop
+        cur, labels = proposals, torch.zeros(len(proposals))
+        for r in range(3):
+            cur, labels = od.filter_small_proposal(cur, labels)
+            out = od.optimize_one_image_single_round(image, cur, labels)
+            cur, labels = out["updated_bboxes"], out["labels"]
+            save[f"{tag}_round{r}_boxes"], save[f"{tag}_round{r}_labels"] = cur.numpy(), labels.numpy()
+        br = od.boundary_reasoning(image, proposals, n_round=args.n_round)
+        save[f"{tag}_final_boxes"], save[f"{tag}_final_labels"] = br["proposals"].numpy(), br["labels"].numpy()
+        lab = br["labels"]
+        print(tag, f"{len(p0)} proposals -> {int((ex >= args.class_score_thres).sum())} exist -> pass {len(passed)} / split {len(cr['splited_new_proposals'])}"
+              f" -> pass2 {len(cr2['proposals_pass_singularity'])} -> boundary in {len(proposals)} -> out {len(lab)}: "
+              f"good {int((lab == 1).sum())}, moving {int((lab == 0).sum())}, dropped {int((lab == -1).sum())}; dtypes {split.dtype} {br['proposals'].dtype}")
+    # helpers on their own
+    boxes = torch.tensor([[10.0, 20.0, 74.0, 52.0], [0.0, 0.0, 320.0, 240.0], [100.5, 30.25, 131.0, 200.0]], dtype=torch.float64)
+    deltas = torch.tensor([[-3.0, 2.0, 5.5, -1.25], [0.0, 0.0, 0.0, 0.0], [7.0, -7.0, 0.5, 12.0]], dtype=torch.float32)
+    save["ppbu_boxes"], save["ppbu_deltas"] = boxes.numpy(), deltas.numpy()
+    save["ppbu_out64"] = od.post_process_bbox_update(boxes, deltas).numpy()
+    save["ppbu_out32"] = od.post_process_bbox_update(boxes.to(torch.float32), deltas).numpy()
+    save["enlarge_out"] = np.array(od.enlarge_proposals([[10, 20, 74, 52], [0, 0, 320, 240], [300, 200, 318, 238]], (240, 320), ratio=1.5))
+    save["proposals_640x480"] = od.generate_random_proposal(height=480, width=640)
+    path = os.path.join(HERE, "discovery.npz")
+    np.savez_compressed(path, **save)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,204 @@
+"""unmore_amd.object_discovery.Object_Discovery on the GPU against the REFERENCE's `Object_Discovery` (object_reasoning.py:43-665) run on
+the CPU (tests/golden/discovery.npz, made by tests/golden/make_golden_r6_discovery.py): the same stand-in "networks" on both sides
+(tests/discovery_stubs.py read object-like fields back out of the crop), so what is compared is everything AROUND the networks --
+crops, existence threshold, union mask / erosion / anti-centre score / peak, the box splits, the boundary rounds with their filters and
+label rules -- on two scenes.  Then the pieces the reference run cannot pin: NMS against the oracle's restatement, the sdf-only
+forward against the full forward, and the fixed-point carry against evaluating every box in every round."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from discovery_stubs import FieldsFromCrop, ObjectFraction
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "discovery.npz"))
+SCENES = {"a": (240, 320, 0, 4), "b": (200, 288, 5, 6)}      # tests/golden/make_golden_r6_discovery.py::SCENES
+# the crops differ from F.interpolate's in the last bits (another order of the same four products); a pixel that sits on a threshold
+# may fall on the other side: scores that are pixel counts are compared to a few pixels, box coordinates to a hundredth of a pixel
+PIX = 1.0 / (128 * 128)
+
+
+def _od():
+    from unmore_amd.object_discovery import Object_Discovery
+    args = Namespace()                                        # the reference's defaults (object_reasoning.py:701-710)
+    return Object_Discovery(args, DEV, objectness_model=FieldsFromCrop(), binary_classifier_model=ObjectFraction())
+
+
+def _image(tag):
+    from unmore_amd import synth
+    H, W, seed, nobj = SCENES[tag]
+    return torch.from_numpy(synth.reasoning_scene(H, W, seed, nobj)).to(DEV)
+
+
+@pytest.mark.parametrize("tag", list(SCENES))
+def test_existence_and_centre_reasoning_equal_the_reference(tag):
+    od = _od()
+    image = _image(tag)
+    od.height, od.width = image.shape[-2], image.shape[-1]
+    p0 = torch.tensor(od.generate_random_proposal(height=od.height, width=od.width)).to(DEV)
+    ex = od.existence_checking(image, p0)["existence_scores"]
+    ref_ex = torch.from_numpy(G[f"{tag}_existence0"])
+    assert float((ex - ref_ex).abs().max()) <= 4 * PIX
+    thr = od.args.class_score_thres
+    assert float((ref_ex - thr).abs().min()) > 8 * PIX, "fixture: a score sits on the existence threshold"
+    keep = (ex >= thr)
+    assert torch.equal(keep, ref_ex >= thr)
+    cr = od.center_reasoning(image, p0[keep.to(DEV)])
+    passed, split = cr["proposals_pass_singularity"], cr["splited_new_proposals"]
+    # which boxes pass, and where the others are cut (the peak index decides the cut: bit-exact or a different box)
+    assert passed.dtype == torch.float64 and np.array_equal(passed.cpu().numpy(), G[f"{tag}_pass1"])
+    assert split.dtype == torch.float64 and split.shape == G[f"{tag}_split1"].shape
+    assert np.array_equal(split.cpu().numpy(), G[f"{tag}_split1"])
+    # second pass on the split boxes (main_object_discovery :632-638)
+    ex2 = od.existence_checking(image, split)["existence_scores"]
+    ref_ex2 = torch.from_numpy(G[f"{tag}_existence1"])
+    assert float((ex2 - ref_ex2).abs().max()) <= 4 * PIX
+    sure = (ref_ex2 - thr).abs() > 8 * PIX
+    assert torch.equal((ex2 >= thr)[sure], (ref_ex2 >= thr)[sure])
+    props2 = split[(ref_ex2 >= thr).to(DEV)]
+    cr2 = od.center_reasoning(image, props2)
+    assert np.array_equal(cr2["proposals_pass_singularity"].cpu().numpy(), G[f"{tag}_pass2"])
+    got2, ref2 = cr2["splited_new_proposals"].cpu().numpy(), G[f"{tag}_split2"]
+    assert got2.shape == ref2.shape
+    # the split boxes of this pass include slivers a few pixels high stretched to 128 rows: neighbouring rows of their score maps agree
+    # to 1e-10, and which of two such rows is "the" maximum hangs on the crop's last bit.  Rows must be identical wherever the peak
+    # leads by more than 1e-6; where it does not, the reference's cut must be one of the tied pixels
+    from unmore_amd import reasoning
+    sdf, cen = od.get_prediction_with_proposals(props2, image)
+    mx, am, sc = reasoning.center_peaks(sdf, cen, return_scores=True)
+    fail = torch.nonzero(mx > od.args.center_score_max_thres).flatten()
+    top2 = torch.topk(sc[fail].flatten(1), 2, dim=1).values
+    tied = ((top2[:, 0] - top2[:, 1]) <= 1e-6).cpu().numpy()
+    differs = (got2 != ref2).any(axis=1).reshape(-1, 4).any(axis=1)
+    assert not bool((differs & ~tied).any()), np.nonzero(differs & ~tied)[0]
+    assert int(differs.sum()) <= 0.05 * len(differs)
+    for b in np.nonzero(differs)[0]:
+        box = props2[fail[b]].cpu().numpy()
+        xr = (ref2[4 * b, 2] - box[0]) / (box[2] - box[0]) * 128            # the reference's peak, back on the 128 x 128 map
+        yr = (ref2[4 * b + 2, 3] - box[1]) / (box[3] - box[1]) * 128
+        assert abs(xr - round(xr)) < 1e-6 and abs(yr - round(yr)) < 1e-6
+        assert float(top2[b, 0] - sc[fail[b], int(round(yr)), int(round(xr))]) <= 1e-6
+
+
+@pytest.mark.parametrize("tag", list(SCENES))
+def test_boundary_rounds_equal_the_reference(tag):
+    od = _od()
+    image = _image(tag)
+    cur = torch.from_numpy(G[f"{tag}_boundary_in"]).to(DEV)
+    labels = torch.zeros(len(cur), device=DEV)
+    for r in range(3):                                   # round by round, as boundary_reasoning does (:598-606)
+        cur, labels = od.filter_small_proposal(cur, labels)
+        out = od.optimize_one_image_single_round(image, cur, labels)
+        cur, labels = out["updated_bboxes"], out["labels"]
+        ref_b, ref_l = G[f"{tag}_round{r}_boxes"], G[f"{tag}_round{r}_labels"]
+        assert cur.dtype == torch.float32 and cur.shape == ref_b.shape
+        assert np.array_equal(labels.cpu().numpy(), ref_l), (r, int((labels.cpu().numpy() != ref_l).sum()))
+        assert float(np.abs(cur.cpu().numpy() - ref_b).max()) <= 1e-2, r
+    res = od.boundary_reasoning(image, torch.from_numpy(G[f"{tag}_boundary_in"]).to(DEV), n_round=od.args.n_round)
+    ref_b, ref_l = G[f"{tag}_final_boxes"], G[f"{tag}_final_labels"]
+    assert res["proposals"].shape == ref_b.shape and np.array_equal(res["labels"].cpu().numpy(), ref_l)
+    err = float(np.abs(res["proposals"].cpu().numpy() - ref_b).max())
+    print(f"scene {tag}: {len(ref_l)} boxes after {od.args.n_round} rounds ({int((ref_l == 1).sum())} good), max box error {err:.2e} px; "
+          f"rounds evaluated {od.stats['boundary_rounds']}, crops {od.stats['boundary_crops']} (the reference evaluates {od.args.n_round} x all)")
+    assert err <= 2e-2
+
+
+@pytest.mark.parametrize("tag", list(SCENES))
+def test_fixed_point_carry_changes_nothing(tag):
+    """boxes that a round labels good and leaves where they were are not evaluated again (object_discovery.py): bit-identical to
+    evaluating every box in every round, with fewer crops"""
+    od = _od()
+    image = _image(tag)
+    start = torch.from_numpy(G[f"{tag}_boundary_in"]).to(DEV)
+    a = od.boundary_reasoning(image, start)
+    s_carry = dict(od.stats)
+    od.carry_fixed_points = False
+    b = od.boundary_reasoning(image, start)
+    s_full = dict(od.stats)
+    assert torch.equal(a["proposals"], b["proposals"]) and torch.equal(a["labels"], b["labels"])
+    assert s_full["boundary_rounds"] == od.args.n_round and s_carry["boundary_crops"] < 0.5 * s_full["boundary_crops"], (s_carry, s_full)
+
+
+def test_discover_image_end_to_end_and_nms():
+    """the whole per-image sequence (main_object_discovery :619-662): the boxes that reach NMS are the fixture's good boxes, and the
+    kept ones are what the oracle's NMS keeps of them"""
+    from oracle import objectness_oracle as orc
+    od = _od()
+    boxes = od.discover_image(_image("a"))
+    ref_in = G["a_final_boxes"][G["a_final_labels"] == 1]
+    keep = orc.nms(ref_in, np.ones(len(ref_in)), 0.5)
+    assert boxes is not None and boxes.dtype == torch.float32 and len(boxes) == len(keep)
+    assert float(np.abs(boxes.cpu().numpy() - ref_in[keep]).max()) <= 2e-2
+    out = od.main_object_discovery([(7, _image("a")), (9, torch.full((3, 64, 64), -1.0))])     # second image: nothing exists -> skipped
+    assert list(out) == [7] and np.array_equal(out[7], boxes.cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1500])
+def test_nms_kernel_equals_the_oracle(n):
+    from oracle import objectness_oracle as orc
+    from unmore_amd import reasoning
+    rng = np.random.default_rng(n)
+    c = rng.uniform(0, 200, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 60, (n, 2)).astype(np.float32)
+    b = np.concatenate([c - wh / 2, c + wh / 2], axis=1).astype(np.float32)
+    if n >= 4:
+        b[n // 2] = b[0]                                  # an exact duplicate
+        b[n // 3, 2:] = b[n // 3, :2]                     # a degenerate (zero-area) box
+    for scores in (np.ones(n, np.float32), rng.uniform(0, 1, n).astype(np.float32), np.round(rng.uniform(0, 1, n) * 4).astype(np.float32) / 4):
+        for thr in (0.3, 0.5):
+            got = reasoning.nms(torch.from_numpy(b).to(DEV), torch.from_numpy(scores).to(DEV), thr)
+            ref = orc.nms(b, scores, thr)
+            assert got.dtype == torch.int64 and got.cpu().numpy().tolist() == ref.tolist(), (n, thr)
+    assert reasoning.nms(torch.zeros((0, 4), device=DEV), torch.zeros(0, device=DEV), 0.5).numel() == 0
+
+
+@pytest.mark.parametrize("backbone,dtype_name", [("dpt_tiny", "float32"), ("dpt_base", "float32"), ("dpt_base", "bfloat16")])
+def test_single_head_prediction_equals_the_full_prediction(backbone, dtype_name):
+    """get_prediction(heads=("sdf_maps",)) -- what the boundary rounds call -- returns the full call's map bit for bit (eager and
+    replayed from its own graph), and only that key; likewise for the centre field"""
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.objectness_net import ObjectnessNet
+    net = ObjectnessNet(DEV, 128, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh"))
+    tag = {"dpt_tiny": "tiny", "dpt_base": "base"}[backbone]
+    net.load_state_dict({k: torch.from_numpy(hash_init(k, tuple(v.shape), tag)) for k, v in net.state_dict().items()}, strict=True)
+    net = net.to(DEV).eval()
+    net.set_compute_dtype(getattr(torch, dtype_name))
+    x = torch.rand(6, 3, 128, 128, device=DEV)
+    with torch.no_grad():
+        full = net.get_prediction(x)
+        for _ in range(4):                                # eager, eager, capture + replay, replay
+            only_s = net.get_prediction(x, heads=("sdf_maps",))
+            only_c = net.get_prediction(x, heads=("center_fields",))
+            assert list(only_s) == ["sdf_maps"] and list(only_c) == ["center_fields"]
+            assert torch.equal(only_s["sdf_maps"], full["sdf_maps"]) and torch.equal(only_c["center_fields"], full["center_fields"])
+        both = net.get_prediction(x, heads=("center_fields", "sdf_maps"))
+        assert torch.equal(both["sdf_maps"], full["sdf_maps"]) and torch.equal(both["center_fields"], full["center_fields"])
+        with pytest.raises(ValueError):
+            net.get_prediction(x, heads=("sdf",))
+    for p in net.parameters():
+        p.requires_grad = True
+    with pytest.raises(RuntimeError):
+        net.get_prediction(x, heads=("sdf_maps",))
+
+
+def test_discovery_with_the_real_networks_runs():
+    """Object_Discovery around unmore_amd's own ObjectnessNet and Binary_Classifier (hash-initialised: the boxes mean nothing, the
+    plumbing -- crops on the device, sdf-only rounds, graphs per batch shape, NMS -- is what runs)"""
+    from unmore_amd.binary_classifier import Binary_Classifier
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.object_discovery import Object_Discovery
+    from unmore_amd.objectness_net import ObjectnessNet
+    from unmore_amd import synth
+    args = Namespace(use_bg_sdf=True, sdf_activation="tanh", n_round=4, class_score_thres=0.0, max_sdf_thres=-2.0)
+    net = ObjectnessNet(DEV, 128, "dpt_tiny", args)
+    net.load_state_dict({k: torch.from_numpy(hash_init(k, tuple(v.shape), "tiny")) for k, v in net.state_dict().items()}, strict=True)
+    clf = Binary_Classifier(DEV, 128, args)
+    od = Object_Discovery(args, DEV, objectness_model=net.to(DEV), binary_classifier_model=clf.to(DEV))
+    image = torch.from_numpy(synth.blob_images(1, 96, 128, seed=3)[0]).to(DEV)
+    boxes = od.discover_image(image)
+    assert boxes is None or (boxes.dim() == 2 and boxes.shape[1] == 4 and bool(torch.isfinite(boxes).all()))
+    assert od.stats.get("boundary_rounds", 0) <= 4

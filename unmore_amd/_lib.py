@@ -116,6 +116,8 @@ _SIGS = {
     "umr_center_peaks": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_center_peaks_certified": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, ctypes.c_double, _vp],
     "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "umr_nms_workspace": [_i32],
+    "umr_nms": [_vp, _vp, _i32, _f32, _vp, _i64, _vp, _vp, _vp],
     "umr_linear_head_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_linear_head_bwd_data": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "umr_linear_head_bwd_weight_workspace": [_i64, _i32],
@@ -162,7 +164,7 @@ def lib():
         _set_argtypes(_lib)
         for fn in ("umr_gemm_tn_workspace", "umr_layernorm_bwd_workspace", "umr_head_out_bwd_workspace", "umr_loss_workspace",
                    "umr_linear_head_bwd_weight_workspace", "umr_linear_head_shift9_workspace", "umr_label_synthesis_workspace", "umr_attention_bwd_workspace",
-                   "umr_distance_transform_workspace", "umr_gemm_nt_workspace", "umr_gemm_nt_x3_workspace"):
+                   "umr_distance_transform_workspace", "umr_gemm_nt_workspace", "umr_gemm_nt_x3_workspace", "umr_nms_workspace"):
             getattr(_lib, fn).restype = ctypes.c_int64
     return _lib
 

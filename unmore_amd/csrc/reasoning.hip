@@ -305,6 +305,48 @@ __global__ __launch_bounds__(256) void boundary_deltas_kernel(const float* __res
     }
 }
 
+
+// ---- greedy non-maximum suppression (object_reasoning.py:661: torchvision.ops.nms(boxes, scores, iou_threshold)) -------------
+// Rank r = position in `order` (the caller's descending-score order).  Pass 1: one bit per (rank i, rank j > i) -- does box i
+// suppress box j, i.e. IoU(i, j) > threshold, in torchvision's own f32 formula (inter / (area_i + area_j - inter)).  Pass 2: one
+// wave walks the ranks in order; lane l holds word l of the "removed" bit set (n <= 4096 boxes), a rank that is not removed is kept
+// and ORs its row into the set.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ order, int n, float thr,
+                                                      unsigned long long* __restrict__ mask, int words) {
+    const int i = blockIdx.y, wj = blockIdx.x;
+    const int j = wj * 64 + threadIdx.x;
+    const float* a = boxes + order[i] * 4;
+    const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+    bool sup = false;
+    if (j < n && j > i) {
+        const float* b = boxes + order[j] * 4;
+        const float left = fmaxf(a0, b[0]), right = fminf(a2, b[2]);
+        const float top = fmaxf(a1, b[1]), bottom = fminf(a3, b[3]);
+        const float w = fmaxf(right - left, 0.f), h = fmaxf(bottom - top, 0.f);
+        const float inter = w * h;
+        const float sa = (a2 - a0) * (a3 - a1), sb = (b[2] - b[0]) * (b[3] - b[1]);
+        sup = (inter / (sa + sb - inter)) > thr;
+    }
+    const unsigned long long bits = __ballot(sup);
+    if (threadIdx.x == 0) mask[(int64_t)i * words + wj] = bits;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask, const int64_t* __restrict__ order, int n, int words,
+                                                      int64_t* __restrict__ keep, int32_t* __restrict__ n_keep) {
+    const int lane = threadIdx.x;
+    unsigned long long removed = 0ull;      // word `lane` of the set
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long wi = __shfl(removed, i >> 6);
+        if (!((wi >> (i & 63)) & 1ull)) {   // wave-uniform
+            if (lane == 0) keep[kept] = order[i];
+            ++kept;
+            if (lane < words) removed |= mask[(int64_t)i * words + lane];
+        }
+    }
+    if (lane == 0) *n_keep = kept;
+}
+
 }  // namespace
 
 extern "C" int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* out, int N, int H, int W, int S,
@@ -353,6 +395,21 @@ extern "C" int umr_center_peaks_certified(const float* sdf_maps, const float* ce
 extern "C" int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int W, umr_stream_t stream) {
     UMR_CHECK_ARG(sdf_maps && deltas && B > 0 && H > 1 && W > 1, "boundary_deltas: bad arguments");
     hipLaunchKernelGGL(boundary_deltas_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, sdf_maps, deltas, H, W);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int64_t umr_nms_workspace(int n) { return n > 0 ? (int64_t)n * ((n + 63) / 64) * 8 : 0; }
+
+extern "C" int umr_nms(const float* boxes, const int64_t* order, int n, float iou_threshold, void* workspace, int64_t workspace_bytes,
+                       int64_t* keep, int32_t* n_keep, umr_stream_t stream) {
+    UMR_CHECK_ARG(boxes && order && keep && n_keep && n > 0, "nms: bad arguments");
+    if (n > 4096) return umr_set_error(UMR_ERR_UNSUPPORTED, "nms: at most 4096 boxes (one wave holds the removed set)");
+    UMR_CHECK_ARG(workspace && workspace_bytes >= umr_nms_workspace(n) && ((uintptr_t)workspace & 7) == 0, "nms: workspace smaller than umr_nms_workspace(n) or misaligned");
+    const int words = (n + 63) / 64;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(words, n), dim3(64), 0, (hipStream_t)stream, boxes, order, n, iou_threshold, (unsigned long long*)workspace, words);
+    UMR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)workspace, order, n, words, keep, n_keep);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -598,12 +598,15 @@ class Engine(X3Path):
         return p
 
     # ------------------------------------------------------------------ forward
-    def forward(self, P, images, save):
+    def forward(self, P, images, save, skip=()):
         """P: dict name -> fp32 parameter tensor on the GPU (reference state-dict names).
-        images: [B,3,H,W] fp32 on the GPU.  Returns (center [B,2,H,W] f32, sdf [B,1,H,W] f32, saved)."""
+        images: [B,3,H,W] fp32 on the GPU.  Returns (center [B,2,H,W] f32, sdf [B,1,H,W] f32, saved).
+        skip (inference only): head module names that are not evaluated (their output is None) -- the boundary-reasoning rounds of
+        object_reasoning.py:379-487 read the boundary-distance map alone, and the centre head is most of a 128x128 crop's forward."""
         cfg, dt = self.cfg, self.dt
+        assert not (skip and save), "skip: inference only"
         if _X3_ALL and dt == torch.float32 and ops.get_f32_mode() in ("x3", "x3_fast"):
-            return self.forward_x3(P, images, save)      # fp32 parity mode on the bf16-plane kernels (engine_x3.py)
+            return self.forward_x3(P, images, save, skip)      # fp32 parity mode on the bf16-plane kernels (engine_x3.py)
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
         images = images.contiguous()
         B, _, H, W = images.shape
@@ -780,6 +783,9 @@ class Engine(X3Path):
         # f32 activations (its backward reads them), and the exact-f32 mode keeps the f32 MFMA.
         featp = None
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
+            if name in skip:
+                outs.append(None)
+                continue
             idx = lay["conv_idx"]
             # in training the plane form serves the heads that keep no activation for their backward (algebraic backward)
             alg_ = save and not lay["relu"] and lay["final"] != "sine" and self.linear_head_backward == "algebraic"

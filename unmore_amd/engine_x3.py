@@ -153,7 +153,7 @@ class X3Path:
         return None
 
     # ------------------------------------------------------------------ forward
-    def forward_x3(self, P, images, save):
+    def forward_x3(self, P, images, save, skip=()):
         from .engine import _COMMUTE_RESIZE
         cfg = self.cfg
         assert images.is_cuda and images.dtype == torch.float32 and images.dim() == 4 and images.shape[1] == 3
@@ -328,6 +328,9 @@ class X3Path:
         feat2 = None if lowres else feat.view(M, 256)
         nbp, php, pwp = path.shape[0], path.shape[1], path.shape[2]
         for name, lay in (("center_field_prediction_head", self.center_layout), ("sdf_prediction_head", self.sdf_layout)):
+            if name in skip:
+                outs.append(None)
+                continue
             idx = lay["conv_idx"]
             if self._collapse(lay, save):
                 if lowres:

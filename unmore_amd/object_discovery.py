@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's `Object_Discovery` (object_reasoning.py:43-665) -- the caller of the ObjectnessNet hot path at
+inference: proposal grid -> existence checking -> centre reasoning (split the boxes that hold more than one centre) -> boundary
+reasoning (up to `n_round` rounds of "crop, predict the boundary-distance map, move the box edges") -> NMS.  Same class name, method
+names, argument meaning and return dictionaries; what is NOT mirrored: the COCO dataset object, the results folder and the JSON dump
+(`main_object_discovery` takes the images and returns the dictionary the reference would have written).
+
+Design (MI355X-first, not a transliteration): the reference walks every box in Python (crop, Resize, list append, per-box tensors) and
+indexes with boolean masks after every step, each a host synchronisation.  Here a round is a handful of launches over ALL boxes -- one
+crop+resize kernel per batch of 50 (csrc/reasoning.hip), the net, one boundary-delta kernel, masked element-wise box arithmetic on the
+device -- with ONE host synchronisation per round (the survivors' count).  Two things the reference's loop does not have:
+  * the boundary rounds read `sdf_maps` only, so the centre head -- most of a 128x128 crop's forward -- is not evaluated
+    (`ObjectnessNet.get_prediction(heads=("sdf_maps",))`);
+  * a box that a round labels "good" (1) and leaves exactly where it was is a fixed point of the round (same crop, same map, same
+    label, zero delta), so it is carried through the remaining rounds without being evaluated again; when every box is such a fixed
+    point the remaining rounds are skipped.  Results are what the reference's fifty full rounds produce.
+Arithmetic that decides something (thresholds, label rules, the order of operations in the box updates, dtypes: float64 proposals on
+the first round, float32 afterwards) follows the reference line by line; each method cites its lines."""
+import math
+
+import numpy as np
+import torch
+
+from . import reasoning
+
+_DEFAULTS = dict(class_score_thres=0.1, center_score_max_thres=0.009, analyze_cc=False, max_sdf_thres=0.5, max_shrink_threshold=16,
+                 delta_ratio=0.5, n_round=50, proposal_area_thres=50, image_size=128)       # object_reasoning.py:701-710,681
+
+
+class Object_Discovery:
+    def __init__(self, args, device, objectness_model=None, binary_classifier_model=None):
+        """object_reasoning.py:44-107.  args: the reference's namespace (missing reasoning hyper-parameters take the reference's
+        defaults).  The two models are built and restored from `args.objectness_resume` / `args.binary_classifier_resume` as the
+        reference does (:58-88) unless they are handed in."""
+        self.args = args
+        self.device = torch.device(device)
+        for k, v in _DEFAULTS.items():
+            if not hasattr(args, k):
+                setattr(args, k, v)
+        if objectness_model is None:
+            from .objectness_net import ObjectnessNet
+            objectness_model = ObjectnessNet(device=self.device, image_size=args.image_size, backbone_type=args.backbone_type, args=args)
+            objectness_model = objectness_model.to(self.device)
+            ckpt = torch.load(args.objectness_resume, map_location=self.device)
+            objectness_model.load_state_dict(ckpt["model_state_dict"], strict=True)
+            objectness_model = objectness_model.to(torch.float32)
+        if binary_classifier_model is None:
+            from .binary_classifier import Binary_Classifier
+            binary_classifier_model = Binary_Classifier(device=self.device, image_size=args.image_size, args=args).to(self.device)
+            ckpt = torch.load(args.binary_classifier_resume, map_location=self.device)
+            binary_classifier_model.load_state_dict(ckpt["model_state_dict"], strict=True)
+            binary_classifier_model = binary_classifier_model.to(torch.float32)
+        self.objectness_model = objectness_model
+        self.binary_classifier_model = binary_classifier_model
+        for m in (self.objectness_model, self.binary_classifier_model):
+            if isinstance(m, torch.nn.Module):
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+        self.stats = {}       # per image: rounds run, crops evaluated (tools / tests read it; the reference prints counts instead)
+        self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
+
+    # ------------------------------------------------------------------ static helpers
+    @staticmethod
+    def generate_random_proposal(height, width):
+        """object_reasoning.py:109-137: for grid sizes 32 ... 512 a square (2g x 2g), a tall (g x 2g) and a wide (2g x g) anchor around
+        every grid point (x fastest, the three shapes innermost), clipped to the image, plus the whole image.  float64 [N, 4]."""
+        out = []
+        for g in (32, 64, 128, 256, 512):
+            ys = np.arange(0, height, g, dtype=int)
+            xs = np.arange(0, width, g, dtype=int)
+            cx, cy = np.meshgrid(xs, ys)
+            c = np.stack([cx.ravel(), cy.ravel(), cx.ravel(), cy.ravel()], axis=1).astype(np.float64)          # [P, 4]
+            base = np.array([[-g, -g, g, g], [-g / 2, -g, g / 2, g], [-g, -g / 2, g, g / 2]], dtype=np.float64)
+            out.append((c[:, None, :] + base[None, :, :]).reshape(-1, 4))
+        out = np.concatenate(out, axis=0)
+        out[:, 0] = np.where(out[:, 0] < 0, 0, out[:, 0])
+        out[:, 1] = np.where(out[:, 1] < 0, 0, out[:, 1])
+        out[:, 2] = np.where(out[:, 2] >= width, width, out[:, 2])
+        out[:, 3] = np.where(out[:, 3] >= height, height, out[:, 3])
+        return np.concatenate((out, np.array([[0, 0, width, height]], dtype=np.float64)), axis=0)
+
+    @staticmethod
+    def update_bbox_with_boundary_fields(sdf_maps):
+        """object_reasoning.py:139-174 on the device (one launch): (delta_x1, delta_y1, delta_x2, delta_y2), each [B]"""
+        return reasoning.update_bbox_with_boundary_fields(sdf_maps)
+
+    @staticmethod
+    def post_process_bbox_update(original_bboxes, delta_bboxes, delta_scale_x=128, delta_scale_y=128):
+        """object_reasoning.py:176-197: deltas measured on the 128 x 128 map, scaled to the box's own extent.  The result has the
+        boxes' dtype (the column assignments of the reference cast back to it)."""
+        x_ratio = (original_bboxes[:, 2] - original_bboxes[:, 0]) / delta_scale_x
+        y_ratio = (original_bboxes[:, 3] - original_bboxes[:, 1]) / delta_scale_y
+        ratio = torch.stack([x_ratio, y_ratio, x_ratio, y_ratio], dim=1)
+        return (original_bboxes + delta_bboxes * ratio).to(original_bboxes.dtype)
+
+    @staticmethod
+    def unravel_index(index, shape):
+        """object_reasoning.py:198-204"""
+        out = []
+        for dim in reversed(shape):
+            out.append(index % dim)
+            index = index // dim
+        return tuple(reversed(out))
+
+    @staticmethod
+    def separate_connected_components(binary_masks):
+        """object_reasoning.py:206-257 (only reached with --analyze_cc): 8-connected components of every mask on the HOST with
+        scipy.ndimage, exactly as the reference does it; boxes [x1, y1, x2, y2) of the components of the masks that have several,
+        and per mask whether it has exactly one."""
+        from scipy.ndimage import find_objects, label
+        combined = {"single": [], "multi": []}
+        single = []
+        structure = np.ones((3, 3), dtype=int)
+        for m in binary_masks.detach().cpu().numpy():
+            labeled, n = label(m, structure)
+            boxes = [[sl[1].start, sl[0].start, sl[1].stop, sl[0].stop] for sl in find_objects(labeled) if sl is not None]
+            if n == 1 and boxes:
+                combined["single"].append(boxes[0])
+                single.append(1)
+            else:
+                single.append(0)
+                if n > 1:
+                    combined["multi"].extend(boxes)
+        return combined, single
+
+    @staticmethod
+    def enlarge_proposals(proposals, image_shape, ratio):
+        """object_reasoning.py:259-291: scale every box about its centre, clip to the image, truncate to int"""
+        height, width = image_shape
+        out = []
+        for x1, y1, x2, y2 in proposals:
+            cx, cy = (x1 + x2) / 2, (y1 + y2) / 2
+            nw, nh = (x2 - x1) * ratio, (y2 - y1) * ratio
+            out.append([int(max(cx - nw / 2, 0)), int(max(cy - nh / 2, 0)), int(min(cx + nw / 2, width)), int(min(cy + nh / 2, height))])
+        return out
+
+    def filter_small_proposal(self, proposals, labels):
+        """object_reasoning.py:293-299"""
+        keep = (proposals[:, 2] - proposals[:, 0]) * (proposals[:, 3] - proposals[:, 1]) > self.args.proposal_area_thres
+        return proposals[keep], labels[keep]
+
+    # ------------------------------------------------------------------ the net on proposal crops
+    def _predict(self, crops, heads=None):
+        m = self.objectness_model
+        with torch.no_grad():
+            if heads is not None and hasattr(m, "_HEAD_OF"):          # unmore_amd.ObjectnessNet: evaluate the requested heads only
+                return m.get_prediction(crops, heads=heads)
+            return m(crops)
+
+    def get_prediction_with_proposals(self, proposals, image):
+        """object_reasoning.py:301-337: (sdf_maps [N,128,128], center_fields [N,2,128,128]) of the proposals' 128 x 128 crops, 50 per batch"""
+        sdf, cen = [], []
+        for i in range(0, len(proposals), 50):
+            crops, _ = reasoning.crop_resize(image, proposals[i:i + 50], 128)
+            pred = self._predict(crops.to(torch.float32))
+            sdf.append(pred["sdf_maps"].squeeze(1))
+            cen.append(pred["center_fields"])
+        return torch.cat(sdf, dim=0), torch.cat(cen, dim=0)
+
+    def center_field_to_anti_center_map(self, vote_maps, kernel_size=5):
+        """object_reasoning.py:360-377 (float64 5 x 5 correlation / 24); evaluated on the device inside `center_reasoning`'s kernel --
+        this method exists for callers that want the map itself"""
+        assert kernel_size == 5
+        B, _, H, W = vote_maps.shape
+        ones = torch.ones((B, H, W), dtype=torch.float32, device=vote_maps.device)
+        _, _, sc = reasoning.center_peaks(ones, vote_maps, border=0, erode_rounds=0, return_scores=True)
+        return sc
+
+    def existence_checking(self, image, proposals):
+        """object_reasoning.py:491-523"""
+        return reasoning.existence_checking(self.binary_classifier_model, image, proposals, num_img_per_batch=128)
+
+    # ------------------------------------------------------------------ centre reasoning
+    def center_reasoning(self, image, proposals):
+        """object_reasoning.py:525-580.  Union mask, three 9 x 9 erosions, anti-centre score, 10-pixel border, per-map maximum and first
+        flat argmax are ONE launch (reasoning.center_peaks); a box whose maximum exceeds `center_score_max_thres` holds more than one
+        centre and is replaced by its left / right / top / bottom parts at the peak (in that order, box after box)."""
+        a = self.args
+        proposals = torch.as_tensor(proposals).to(self.device)
+        sdf_maps, center_fields = self.get_prediction_with_proposals(proposals, image)
+        mx, am = reasoning.center_peaks(sdf_maps, center_fields)
+        H, W = sdf_maps.shape[-2], sdf_maps.shape[-1]
+        fail = mx > a.center_score_max_thres
+        passed = proposals[~fail]
+        split = []
+        if bool(fail.any()):
+            pf, idx = proposals[fail], am[fail]
+            # (y, x) of the peak as fractions of the map: an int64 tensor divided by a Python int is float32 in torch (:553-554), and
+            # the box arithmetic promotes to the proposals' dtype
+            y_ratio = ((idx // W) / H).to(torch.float32)
+            x_ratio = ((idx % W) / W).to(torch.float32)
+            x1, y1, x2, y2 = pf[:, 0], pf[:, 1], pf[:, 2], pf[:, 3]
+            xs = x1 + (x2 - x1) * x_ratio
+            ys = y1 + (y2 - y1) * y_ratio
+            left = torch.stack([x1, y1, xs, y2], dim=1)
+            right = torch.stack([xs, y1, x2, y2], dim=1)
+            top = torch.stack([x1, y1, x2, ys], dim=1)
+            bottom = torch.stack([x1, ys, x2, y2], dim=1)
+            # (torch.tensor([...]) of 0-dim tensors keeps their dtype, :555-558: float64 rows for the float64 proposal grid)
+            split = torch.stack([left, right, top, bottom], dim=1).reshape(-1, 4)
+        if a.analyze_cc:
+            union = ((torch.sigmoid(sdf_maps) > 0.5) | (torch.norm(center_fields, dim=1) > 0.5)).to(torch.int64)
+            cc, _single = self.separate_connected_components(union[~fail])
+            multi = self.enlarge_proposals(cc["multi"], (self.height, self.width), ratio=1.5)
+            extra = torch.tensor(multi, dtype=torch.float32, device=self.device).reshape(-1, 4)
+            # (the reference concatenates onto its split list and fails when that list is empty, :571; here the extra boxes stand alone then)
+            split = torch.cat((split, extra), dim=0) if len(split) else extra
+        return {"proposals_pass_singularity": passed, "splited_new_proposals": split}
+
+    # ------------------------------------------------------------------ boundary reasoning
+    def _round(self, image, proposals):
+        """one round for `proposals` [N,4] on the device, nothing synchronises: -> (updated boxes f32 [N,4] (zeros where filtered out),
+        labels f32 [N]: -1 filtered out / 0 keep updating / 1 good)"""
+        a = self.args
+        H, W = image.shape[-2], image.shape[-1]
+        sdf, edge = [], []
+        for i in range(0, len(proposals), 50):
+            crops, on_edge = reasoning.crop_resize(image, proposals[i:i + 50], 128)
+            sdf.append(self._predict(crops.to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1))
+            edge.append(on_edge.to(self.device))
+        sdf = torch.cat(sdf, dim=0)
+        on_edge = torch.cat(edge, dim=0).to(torch.float32)
+        keep = torch.amax(sdf, dim=(1, 2)).to(torch.float32) > a.max_sdf_thres                                        # :421-427
+        dx1, dy1, dx2, dy2 = reasoning.update_bbox_with_boundary_fields(sdf)                                             # :441
+        signed = torch.stack([-dx1, -dy1, dx2, dy2], dim=1)                      # > 0 expands, < 0 shrinks          # :444-445
+        signed = torch.where((signed > 0) & (on_edge == 1), 0, 1).to(torch.float32) * signed
+        max_expansion, max_shrink = torch.amax(signed, dim=1), torch.amin(signed, dim=1)                                # :446-447
+        good = (max_expansion <= 0) & (max_shrink >= -a.max_shrink_threshold)                                           # :450-452
+        dx1 = dx1 - torch.abs(dx1) * a.delta_ratio                                                                       # :457-460
+        dy1 = dy1 - torch.abs(dy1) * a.delta_ratio
+        dx2 = dx2 + torch.abs(dx2) * a.delta_ratio
+        dy2 = dy2 + torch.abs(dy2) * a.delta_ratio
+        delta = torch.stack([dx1, dy1, dx2, dy2], dim=1)
+        delta = torch.where(good[:, None], torch.zeros_like(delta), delta)                                              # :463
+        upd = self.post_process_bbox_update(proposals, delta, delta_scale_x=128, delta_scale_y=128)                      # :466
+        lo = torch.zeros((), dtype=upd.dtype, device=upd.device)
+        upd = torch.stack([torch.maximum(upd[:, 0], lo), torch.maximum(upd[:, 1], lo),                                  # :468-471
+                           torch.minimum(upd[:, 2], lo + W), torch.minimum(upd[:, 3], lo + H)], dim=1)
+        out = torch.where(keep[:, None], upd.to(torch.float32), torch.zeros((), dtype=torch.float32, device=upd.device))   # :480
+        labels = torch.where(keep, good.to(torch.float32), torch.full((), -1.0, device=upd.device))
+        return out, labels
+
+    def optimize_one_image_single_round(self, image, proposals, labels):
+        """object_reasoning.py:379-487 (the incoming `labels` are overwritten there too, :392)"""
+        proposals = torch.as_tensor(proposals).to(self.device)
+        out, lab = self._round(image, proposals)
+        return {"updated_bboxes": out, "labels": lab}
+
+    def boundary_reasoning(self, image, proposals, n_round=50):
+        """object_reasoning.py:582-612 (like the reference, the loop runs `args.n_round` rounds).  One host synchronisation per round;
+        fixed points are carried, not re-evaluated (module docstring)."""
+        a = self.args
+        cur = torch.as_tensor(proposals).to(self.device)
+        labels = torch.zeros(len(cur), device=self.device)
+        frozen = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
+        rounds = crops = 0
+        for _ in range(a.n_round):
+            keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                            # :598 / :293-299
+            cur, labels, frozen = cur[keep], labels[keep], frozen[keep]
+            if len(cur) == 0:                                               # (the boolean index above is the round's host sync)
+                self.stats.update(boundary_rounds=rounds, boundary_crops=crops)
+                return {"proposals": [], "labels": []}
+            if self.carry_fixed_points and bool(frozen.all()):
+                break                                                       # every box is a fixed point: the remaining rounds change nothing
+            active = ~frozen
+            out, lab = self._round(image, cur[active])
+            rounds += 1
+            crops += int(active.sum())
+            new = torch.zeros((len(cur), 4), dtype=torch.float32, device=self.device)
+            new_lab = torch.empty(len(cur), dtype=torch.float32, device=self.device)
+            new[active], new_lab[active] = out, lab
+            new[frozen], new_lab[frozen] = cur[frozen].to(torch.float32), labels[frozen]
+            # a fixed point of the round: labelled good and returned bit for bit where it came from (from the second round on the boxes
+            # are float32 on both sides; a float64 box of the first round is frozen only if the cast did not move it)
+            now_fixed = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
+            now_fixed[active] = (lab == 1) & (out.to(cur.dtype) == cur[active]).all(dim=1)
+            if self.carry_fixed_points:
+                frozen = frozen | now_fixed
+            cur, labels = new, new_lab
+        self.stats.update(boundary_rounds=rounds, boundary_crops=crops)
+        return {"proposals": cur, "labels": labels}
+
+    # ------------------------------------------------------------------ one image, all images
+    def discover_image(self, image):
+        """the body of main_object_discovery's loop (object_reasoning.py:619-662) for one [3,H,W] image on the GPU: the discovered boxes
+        [K,4] (float32, on the GPU), or None where the reference `continue`s"""
+        a = self.args
+        image = image.to(self.device, torch.float32)
+        self.height, self.width = image.shape[-2], image.shape[-1]
+        self.stats = {}
+        proposals = torch.tensor(self.generate_random_proposal(height=self.height, width=self.width)).to(self.device)   # Step 0
+        scores = self.existence_checking(image, proposals)["existence_scores"]                                        # Step 1
+        proposals = proposals[(scores >= a.class_score_thres).to(self.device)]
+        if len(proposals) == 0:
+            return None
+        res = self.center_reasoning(image, proposals)                                                                   # Step 2
+        passed, split = res["proposals_pass_singularity"], res["splited_new_proposals"]
+        if len(split) > 0:      # (the reference stacks an empty list and raises when no box failed the singularity check, :633 -> :513)
+            scores = self.existence_checking(image, split)["existence_scores"]
+            split = split[(scores >= a.class_score_thres).to(self.device)]
+        if len(split) > 0:
+            res2 = self.center_reasoning(image, split)
+            proposals = torch.cat((passed, res2["proposals_pass_singularity"]), dim=0)
+        else:
+            proposals = passed
+        if len(proposals) == 0:
+            return None
+        res = self.boundary_reasoning(image, proposals, n_round=a.n_round)                                              # Step 3
+        proposals, labels = res["proposals"], res["labels"]
+        if len(proposals) == 0:
+            return None
+        good = labels == 1
+        proposals = proposals[good]
+        if len(proposals) == 0:
+            return None
+        keep = reasoning.nms(proposals.to(torch.float32), labels[good], iou_threshold=0.5)                             # :661
+        return proposals[keep]
+
+    def main_object_discovery(self, images):
+        """object_reasoning.py:615-665 without the dataset object and the JSON file: `images` yields (image_id, image [3,H,W]); returns
+        {image_id: boxes as a numpy array} -- the dictionary the reference dumps to discovery_results.json"""
+        results = {}
+        for image_id, image in images:
+            boxes = self.discover_image(image)
+            if boxes is not None:
+                results[image_id] = boxes.cpu().numpy()
+        return results

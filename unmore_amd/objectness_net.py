@@ -259,9 +259,16 @@ class ObjectnessNet(nn.Module):
                     out.add(n)
         return out
 
-    def _run(self, images):
+    _HEAD_OF = {"center_fields": "center_field_prediction_head", "sdf_maps": "sdf_prediction_head"}
+
+    def _run(self, images, heads=None):
         if self.backbone_type not in CONFIGS:
             raise NotImplementedError
+        if heads is not None:
+            heads = tuple(heads)
+            if not heads or any(h not in self._HEAD_OF for h in heads):
+                raise ValueError(f"heads: a non-empty subset of {tuple(self._HEAD_OF)}, got {heads}")
+        skip = () if heads is None else tuple(sorted(m for k, m in self._HEAD_OF.items() if k not in heads))
         if not images.is_cuda:
             raise RuntimeError("unmore_amd.ObjectnessNet runs on the MI355X only (no CPU fallback); move the model and inputs to the GPU")
         in_dtype = images.dtype
@@ -269,18 +276,23 @@ class ObjectnessNet(nn.Module):
             # an empty batch (the train loop's filter can drop every image, train_objectness_net.py:190-207): the reference's convs
             # return empty maps; so do we, without a launch
             B0, _, H0, W0 = images.shape
-            return {"center_fields": images.new_zeros((0, 2, H0, W0)), "sdf_maps": images.new_zeros((0, 1, H0, W0))}
+            empty = {"center_fields": images.new_zeros((0, 2, H0, W0)), "sdf_maps": images.new_zeros((0, 1, H0, W0))}
+            return {k: v for k, v in empty.items() if heads is None or k in heads}
         x = images.float()
         named = list(self.named_parameters())
         names = tuple(n for n, _ in named)
         params = tuple(p for _, p in named)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            if skip:
+                raise RuntimeError("get_prediction(heads=...): inference only (call under torch.no_grad() / with frozen parameters)")
             center, sdf = _NetFunction.apply(x, self, names, *params)
         else:
-            center, sdf = self._forward_nograd(x, names, params)
+            center, sdf = self._forward_nograd(x, names, params, skip)
         out_dict = {}
-        out_dict["center_fields"] = center.to(in_dtype)  ## [B, 2, H, W]
-        out_dict["sdf_maps"] = sdf.to(in_dtype)  ## [B, 1, H, W]
+        if center is not None:
+            out_dict["center_fields"] = center.to(in_dtype)  ## [B, 2, H, W]
+        if sdf is not None:
+            out_dict["sdf_maps"] = sdf.to(in_dtype)  ## [B, 1, H, W]
         return out_dict
 
     def set_graph_mode(self, mode):
@@ -298,8 +310,13 @@ class ObjectnessNet(nn.Module):
         self._inf_graphs = {}
         return self
 
-    def _forward_nograd(self, x, names, params):
+    def _forward_nograd(self, x, names, params, skip=()):
         eng = self._engine()
+
+        def both(outs):       # the captured call returns the evaluated heads only; put them back in (center, sdf) order
+            it = iter(outs)
+            return tuple(None if m in skip else next(it) for m in ("center_field_prediction_head", "sdf_prediction_head"))
+
         P = dict(zip(names, params))
         B, _, H, W = x.shape
         mode = getattr(self, "graph_mode", None)
@@ -311,12 +328,11 @@ class ObjectnessNet(nn.Module):
             if store.get("sig") != sig:
                 store.clear()
                 store["sig"] = sig
-            key = (tuple(x.shape), ops.get_f32_mode(), torch.cuda.current_stream(x.device).cuda_stream)
+            key = (tuple(x.shape), ops.get_f32_mode(), torch.cuda.current_stream(x.device).cuda_stream, skip)
             ent = store.get(key)
             if isinstance(ent, graphs.Captured):
                 if ent.valid():
-                    center, sdf = ent.replay(x)
-                    return center.clone(), sdf.clone()
+                    return both(t.clone() for t in ent.replay(x))
                 if ent.failed is None:
                     ent = None
             if not isinstance(ent, graphs.Captured):
@@ -329,17 +345,18 @@ class ObjectnessNet(nn.Module):
                         for k in [k for k, v in store.items() if isinstance(v, graphs.Captured)]:
                             del store[k]
                         graphs.release_dropped()
-                    cap = graphs.Captured(lambda xs: eng.forward(P, xs, save=False)[:2], (x,), generation_of=eng.cache.generation,
-                                          on_fail=eng.cache.purge_capture)
+                    cap = graphs.Captured(lambda xs: tuple(t for t in eng.forward(P, xs, save=False, skip=skip)[:2] if t is not None), (x,),
+                                          generation_of=eng.cache.generation, on_fail=eng.cache.purge_capture)
                     store[key] = cap
                     if cap.failed is None:
-                        center, sdf = cap.replay(x)
-                        return center.clone(), sdf.clone()
-        center, sdf, _ = eng.forward(P, x, save=False)
+                        return both(t.clone() for t in cap.replay(x))
+        center, sdf, _ = eng.forward(P, x, save=False, skip=skip)
         return center, sdf
 
     def forward(self, images):
         return self._run(images)
 
-    def get_prediction(self, images):
-        return self._run(images)
+    def get_prediction(self, images, heads=None):
+        """objectness_net.py:188-203.  heads (extension, inference only): a subset of ('center_fields', 'sdf_maps') -- only those heads are
+        evaluated and only those keys returned (object_reasoning.py:379-487 reads 'sdf_maps' alone, fifty rounds per image)."""
+        return self._run(images, heads)

@@ -14,12 +14,15 @@ from .ops import _p, _stream, _need_gpu
 def crop_resize(image, boxes, size=128):
     """object_reasoning.py:311-323 -- for every box: floor/ceil the corners, crop `image[:, y1:y2, x1:x2]`, resize to
     (size, size) with bilinear interpolation (torchvision tensor Resize, no antialias).  image: [3,H,W] f32 on the GPU,
-    boxes: [N,4] (x1,y1,x2,y2) any float/int tensor.  Returns ([N,3,size,size] f32, on_edge_flags [N,4] bool)."""
+    boxes: [N,4] (x1,y1,x2,y2) any float/int tensor, on the host or the GPU.  Returns ([N,3,size,size] f32, on_edge_flags [N,4] bool on
+    the boxes' device)."""
     _need_gpu(image)
     assert image.dim() == 3 and image.shape[0] == 3 and image.dtype == torch.float32
     image = image.contiguous()
     H, W = image.shape[1], image.shape[2]
-    b = boxes.detach().to("cpu", torch.float64)
+    # corners as the reference takes them (int(math.floor(x1)) ... int(math.ceil(y2))), where the boxes live: boxes on the GPU stay
+    # there -- the boundary-reasoning rounds (object_discovery.py) feed each round's boxes to the next without a host round trip
+    b = boxes.detach().to(torch.float64)
     ib = torch.stack([torch.floor(b[:, 0]), torch.floor(b[:, 1]), torch.ceil(b[:, 2]), torch.ceil(b[:, 3])], 1).to(torch.int32)
     # python slicing semantics of image[:, y1:y2, x1:x2]: negative starts would wrap; the reference clips boxes beforehand
     ib[:, 0].clamp_(0, W); ib[:, 2].clamp_(0, W); ib[:, 1].clamp_(0, H); ib[:, 3].clamp_(0, H)
@@ -89,6 +92,24 @@ def update_bbox_with_boundary_fields(sdf_maps):
     d = torch.empty((B, 4), dtype=torch.float32, device=sdf.device)
     L.check(L.lib().umr_boundary_deltas(_p(sdf), _p(d), B, H, W, _stream()), "umr_boundary_deltas")
     return d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms as object_reasoning.py:661 uses it: indices of the kept boxes, by descending score; equal scores keep their
+    input order (the reference passes its labels -- all ones -- as scores; torchvision leaves the order of ties to its sort).
+    boxes [N,4] f32 (x1,y1,x2,y2), scores [N], on the GPU.  Returns an int64 tensor on the GPU (one host sync for the kept count)."""
+    _need_gpu(boxes)
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    b = boxes.detach().to(torch.float32).contiguous()
+    order = torch.sort(scores.detach().to(boxes.device), descending=True, stable=True).indices.contiguous()
+    ws_bytes = int(L.lib().umr_nms_workspace(n))
+    ws = torch.empty(ws_bytes // 8, dtype=torch.int64, device=boxes.device)
+    keep = torch.empty(n, dtype=torch.int64, device=boxes.device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=boxes.device)
+    L.check(L.lib().umr_nms(_p(b), _p(order), n, float(iou_threshold), _p(ws), ws_bytes, _p(keep), _p(cnt), _stream()), "umr_nms")
+    return keep[:int(cnt.item())]
 
 
 def existence_checking(binary_classifier_model, image, proposals, num_img_per_batch=128):

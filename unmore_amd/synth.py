@@ -108,3 +108,30 @@ def peak_edited_state_dict(spec, wtag):
     sd["center_field_prediction_head.6.weight"] = sd["center_field_prediction_head.6.weight"] * np.float32(scale)
     sd["center_field_prediction_head.6.bias"] = sd["center_field_prediction_head.6.bias"] * np.float32(scale)
     return sd
+
+
+def reasoning_scene(H, W, seed=0, n_objects=4):
+    """A [3,H,W] float32 "image" whose channels ARE object-like fields, for exercising the object-reasoning loop
+    (object_reasoning.py:615-665) end to end without a trained net (tests/discovery_stubs.py reads them back out of the resized
+    crops): channel 0 = a boundary-distance-like field in (-1, 1), positive inside `n_objects` ellipses and falling off outside;
+    channels 1, 2 = the unit vector (row, column offset) from the nearest ellipse's centre inside the ellipses, zero outside.
+    Deterministic numpy (hashrng), so the golden generator and the tests rebuild the same array."""
+    u = uniform01(f"scene:{seed}", (n_objects, 4))
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    field = np.full((H, W), -1.0, np.float32)
+    cf = np.zeros((2, H, W), np.float32)
+    best = np.full((H, W), np.inf, np.float32)
+    for k in range(n_objects):
+        cy, cx = np.float32((0.15 + 0.7 * u[k, 0]) * H), np.float32((0.15 + 0.7 * u[k, 1]) * W)
+        ry, rx = np.float32(H / 14 + u[k, 2] * H / 7), np.float32(W / 14 + u[k, 3] * W / 7)
+        oy, ox = yy - cy, xx - cx
+        r = np.sqrt((oy / ry) ** 2 + (ox / rx) ** 2).astype(np.float32)          # 1 on the ellipse
+        f = np.tanh(np.float32(2.5) * (np.float32(1.0) - r)).astype(np.float32)
+        field = np.maximum(field, f)
+        n = (np.sqrt(oy * oy + ox * ox) + np.float32(1e-6)).astype(np.float32)
+        near = r < best
+        inside = r <= 1.0
+        cf[0] = np.where(near & inside, oy / n, np.where(near, 0.0, cf[0]))
+        cf[1] = np.where(near & inside, ox / n, np.where(near, 0.0, cf[1]))
+        best = np.minimum(best, r)
+    return np.concatenate([field[None], cf], axis=0).astype(np.float32)

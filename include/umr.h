@@ -355,6 +355,17 @@ int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int 
  * equal scores -- the reference passes its labels, all ones -- keep their input order), greedy: a box is kept unless an earlier kept one
  * overlaps it with IoU > iou_threshold (f32: inter / (area_a + area_b - inter)).  keep[0 .. *n_keep) = the kept boxes' indices in rank
  * order; keep has room for n, n_keep is one int32 on the device.  n <= 4096; workspace: umr_nms_workspace(n) bytes, 8-byte aligned. */
+/* object scoring (object_scoring.py:172-272).  Per proposal, from its S x S fields: the two binary masks (||center|| > 0.5,
+ * sigmoid(sdf) > 0.5), each resized to the proposal's box (integer corners, already clipped to the image) as torchvision's Resize
+ * does for integer tensors -- bilinear, align_corners=False, then round half to even -- and OR-ed (:189-222).
+ * mask_paste_stats: stats[n] = {x_min, y_min, x_max + 1, y_max + 1, area} of that pasted union mask in image coordinates (the tight
+ *   box of :225-229; all zero for an empty mask), maxima[n] = {max ||center||, max sdf} over the crop (:184-188).  Nothing image-sized
+ *   is written.
+ * mask_paste: the pasted union masks of the K selected proposals, masks [K,H,W] u8 (what survives NMS, :233-234). */
+int umr_mask_paste_stats(const float* sdf_maps, const float* center_fields, const int32_t* boxes, int N, int S, int H, int W,
+                         int32_t* stats, float* maxima, umr_stream_t stream);
+int umr_mask_paste(const float* sdf_maps, const float* center_fields, const int32_t* boxes, const int64_t* select, int K, int S, int H, int W,
+                   uint8_t* masks, umr_stream_t stream);
 int64_t umr_nms_workspace(int n);
 int umr_nms(const float* boxes, const int64_t* order, int n, float iou_threshold, void* workspace, int64_t workspace_bytes,
             int64_t* keep, int32_t* n_keep, umr_stream_t stream);

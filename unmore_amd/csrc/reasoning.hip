@@ -347,6 +347,115 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
     if (lane == 0) *n_keep = kept;
 }
 
+
+// ---- object scoring (object_scoring.py:172-272): the two binary masks of a proposal (||center|| > 0.5, sigmoid(sdf) > 0.5, on its
+// S x S crop) are resized to the proposal's box with torchvision's tensor Resize -- for an integer tensor: bilinear in f32
+// (align_corners=False), then torch.round (half to even: 1 iff the value exceeds 0.5) -- pasted into an image-sized canvas and OR-ed
+// (:189-222).  Both masks live in LDS as bytes; the bilinear arithmetic is PyTorch's, unfused: h0 * (w0 * p00 + w1 * p01) + h1 * (...).
+struct PasteAxis { int i0, i1; float l0, l1; };
+__device__ __forceinline__ PasteAxis paste_axis(int o, int out_size, int S) {
+    const float scale = (float)S / (float)out_size;
+    const float src = fmaxf(__fsub_rn(__fmul_rn(scale, (float)o + 0.5f), 0.5f), 0.f);
+    int i0 = (int)floorf(src);
+    if (i0 > S - 1) i0 = S - 1;
+    const float l1 = fminf(fmaxf(__fsub_rn(src, (float)i0), 0.f), 1.f);
+    return PasteAxis{i0, i0 < S - 1 ? i0 + 1 : i0, __fsub_rn(1.f, l1), l1};
+}
+__device__ __forceinline__ bool paste_bit(const unsigned char* m, int S, const PasteAxis& ay, const PasteAxis& ax) {
+    const float p00 = (float)m[ay.i0 * S + ax.i0], p01 = (float)m[ay.i0 * S + ax.i1];
+    const float p10 = (float)m[ay.i1 * S + ax.i0], p11 = (float)m[ay.i1 * S + ax.i1];
+    const float top = __fadd_rn(__fmul_rn(ax.l0, p00), __fmul_rn(ax.l1, p01));
+    const float bot = __fadd_rn(__fmul_rn(ax.l0, p10), __fmul_rn(ax.l1, p11));
+    return __fadd_rn(__fmul_rn(ay.l0, top), __fmul_rn(ay.l1, bot)) > 0.5f;
+}
+// fills the two LDS mask planes of proposal b; returns (this thread's) partial maxima of ||center|| and sdf
+__device__ __forceinline__ void paste_masks_to_lds(const float* __restrict__ sdf, const float* __restrict__ center, int b, int S, unsigned char* mc,
+                                                   unsigned char* mb, float& max_norm, float& max_sdf) {
+    const int SS = S * S;
+    const float* s = sdf + (int64_t)b * SS;
+    const float* c0 = center + (int64_t)b * 2 * SS;
+    const float* c1 = c0 + SS;
+    for (int i = threadIdx.x; i < SS; i += blockDim.x) {
+        const float sv = s[i];
+        const float sg = 1.0f / (1.0f + expf(-sv));
+        const float nr = sqrtf(c0[i] * c0[i] + c1[i] * c1[i]);
+        mc[i] = nr > 0.5f ? 1 : 0;
+        mb[i] = sg > 0.5f ? 1 : 0;
+        max_norm = fmaxf(max_norm, nr);
+        max_sdf = fmaxf(max_sdf, sv);
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_paste_stats_kernel(const float* __restrict__ sdf, const float* __restrict__ center, const int32_t* __restrict__ boxes,
+                                                               int S, int32_t* __restrict__ stats, float* __restrict__ maxima) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int r_xmin[256], r_ymin[256], r_xmax[256], r_ymax[256], r_area[256];
+    __shared__ float r_mn[256], r_ms[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned char* mc = lds;
+    unsigned char* mb = lds + S * S;
+    float mn = -INFINITY, ms = -INFINITY;
+    paste_masks_to_lds(sdf, center, b, S, mc, mb, mn, ms);
+    __syncthreads();
+    const int x1 = boxes[b * 4 + 0], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
+    const int hb = y2 - y1, wb = x2 - x1;
+    int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1, area = 0;
+    if (hb > 0 && wb > 0) {
+        const int64_t total = (int64_t)hb * wb;
+        for (int64_t i = tid; i < total; i += 256) {
+            const int oy = (int)(i / wb), ox = (int)(i - (int64_t)oy * wb);
+            const PasteAxis ay = paste_axis(oy, hb, S), ax = paste_axis(ox, wb, S);
+            if (paste_bit(mc, S, ay, ax) || paste_bit(mb, S, ay, ax)) {
+                const int x = x1 + ox, y = y1 + oy;
+                xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
+                ++area;
+            }
+        }
+    }
+    r_xmin[tid] = xmin; r_ymin[tid] = ymin; r_xmax[tid] = xmax; r_ymax[tid] = ymax; r_area[tid] = area; r_mn[tid] = mn; r_ms[tid] = ms;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            r_xmin[tid] = min(r_xmin[tid], r_xmin[tid + st]); r_ymin[tid] = min(r_ymin[tid], r_ymin[tid + st]);
+            r_xmax[tid] = max(r_xmax[tid], r_xmax[tid + st]); r_ymax[tid] = max(r_ymax[tid], r_ymax[tid + st]);
+            r_area[tid] += r_area[tid + st];
+            r_mn[tid] = fmaxf(r_mn[tid], r_mn[tid + st]); r_ms[tid] = fmaxf(r_ms[tid], r_ms[tid + st]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool any = r_area[0] > 0;      // an empty mask has the box [0, 0, 0, 0] (pycocotools toBbox of an empty RLE)
+        stats[b * 5 + 0] = any ? r_xmin[0] : 0; stats[b * 5 + 1] = any ? r_ymin[0] : 0;
+        stats[b * 5 + 2] = any ? r_xmax[0] + 1 : 0; stats[b * 5 + 3] = any ? r_ymax[0] + 1 : 0;
+        stats[b * 5 + 4] = r_area[0];
+        maxima[b * 2 + 0] = r_mn[0]; maxima[b * 2 + 1] = r_ms[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict__ sdf, const float* __restrict__ center, const int32_t* __restrict__ boxes,
+                                                         const int64_t* __restrict__ select, int S, int H, int W, unsigned char* __restrict__ masks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int b = (int)select[k];
+    unsigned char* mc = lds;
+    unsigned char* mb = lds + S * S;
+    float mn = 0.f, ms = 0.f;
+    paste_masks_to_lds(sdf, center, b, S, mc, mb, mn, ms);
+    __syncthreads();
+    const int x1 = boxes[b * 4 + 0], y1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 2], y2 = boxes[b * 4 + 3];
+    const int hb = y2 - y1, wb = x2 - x1;
+    unsigned char* out = masks + (int64_t)k * H * W;
+    for (int64_t i = tid; i < (int64_t)H * W; i += 256) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        unsigned char v = 0;
+        if (hb > 0 && wb > 0 && x >= x1 && x < x2 && y >= y1 && y < y2) {
+            const PasteAxis ay = paste_axis(y - y1, hb, S), ax = paste_axis(x - x1, wb, S);
+            v = (paste_bit(mc, S, ay, ax) || paste_bit(mb, S, ay, ax)) ? 1 : 0;
+        }
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* out, int N, int H, int W, int S,
@@ -410,6 +519,26 @@ extern "C" int umr_nms(const float* boxes, const int64_t* order, int n, float io
     hipLaunchKernelGGL(nms_mask_kernel, dim3(words, n), dim3(64), 0, (hipStream_t)stream, boxes, order, n, iou_threshold, (unsigned long long*)workspace, words);
     UMR_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)workspace, order, n, words, keep, n_keep);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_mask_paste_stats(const float* sdf_maps, const float* center_fields, const int32_t* boxes, int N, int S, int H, int W,
+                                    int32_t* stats, float* maxima, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && center_fields && boxes && stats && maxima && N > 0 && S > 0 && H > 0 && W > 0, "mask_paste_stats: bad arguments");
+    if ((int64_t)S * S * 2 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "mask_paste_stats: crop larger than the LDS mask planes (S <= 277)");
+    UMR_SET_MAX_LDS_ONCE(mask_paste_stats_kernel, 150 * 1024);
+    hipLaunchKernelGGL(mask_paste_stats_kernel, dim3(N), dim3(256), (size_t)S * S * 2, (hipStream_t)stream, sdf_maps, center_fields, boxes, S, stats, maxima);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_mask_paste(const float* sdf_maps, const float* center_fields, const int32_t* boxes, const int64_t* select, int K, int S, int H, int W,
+                              uint8_t* masks, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && center_fields && boxes && select && masks && K > 0 && S > 0 && H > 0 && W > 0, "mask_paste: bad arguments");
+    if ((int64_t)S * S * 2 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "mask_paste: crop larger than the LDS mask planes (S <= 277)");
+    UMR_SET_MAX_LDS_ONCE(mask_paste_kernel, 150 * 1024);
+    hipLaunchKernelGGL(mask_paste_kernel, dim3(K), dim3(256), (size_t)S * S * 2, (hipStream_t)stream, sdf_maps, center_fields, boxes, select, S, H, W, masks);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

@@ -7,7 +7,8 @@ of the crop), so the CONTROL FLOW -- how many boxes exist, split, survive each b
 instead of whatever random weights would say.  Three arms, same boxes out:
    reference_flow : every surviving box evaluated in every round, both heads every time (what object_reasoning.py does, on these kernels)
    sdf_only       : + the boundary rounds evaluate the boundary-distance head only
-   sdf_only+carry : + boxes that are fixed points of a round are carried (the default)
+   sdf_only+carry : + boxes that are fixed points of a round are carried
+   default        : + 200 crops per net call in the boundary rounds instead of 50
 python tools/discovery_bench.py [fp32|bf16] [backbone=dpt_large]"""
 import json
 import os
@@ -63,10 +64,11 @@ class RealClassifierStubAnswer(torch.nn.Module):
 H, W = 480, 640
 image = torch.from_numpy(synth.reasoning_scene(H, W, seed=2, n_objects=6)).to(dev)
 rows, ref_boxes = [], None
-for name, honour, carry in (("reference_flow", False, False), ("sdf_only", True, False), ("sdf_only+carry", True, True)):
+for name, honour, carry, nb in (("reference_flow", False, False, 50), ("sdf_only", True, False, 50), ("sdf_only+carry", True, True, 50),
+                                ("default (sdf_only+carry+batch200)", True, True, 200)):
     model = RealWorkStubAnswer(honour)
     od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
-    od.carry_fixed_points = carry
+    od.carry_fixed_points, od.boundary_batch = carry, nb
     boxes = od.discover_image(image)          # warm-up: packs weights, captures the graphs of the recurring batch shapes
     torch.cuda.synchronize()
     model.calls = model.crops = 0

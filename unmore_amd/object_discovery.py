@@ -6,13 +6,14 @@ names, argument meaning and return dictionaries; what is NOT mirrored: the COCO 
 
 Design (MI355X-first, not a transliteration): the reference walks every box in Python (crop, Resize, list append, per-box tensors) and
 indexes with boolean masks after every step, each a host synchronisation.  Here a round is a handful of launches over ALL boxes -- one
-crop+resize kernel per batch of 50 (csrc/reasoning.hip), the net, one boundary-delta kernel, masked element-wise box arithmetic on the
+crop+resize kernel per batch (csrc/reasoning.hip), the net, one boundary-delta kernel, masked element-wise box arithmetic on the
 device -- with ONE host synchronisation per round (the survivors' count).  Two things the reference's loop does not have:
   * the boundary rounds read `sdf_maps` only, so the centre head -- most of a 128x128 crop's forward -- is not evaluated
     (`ObjectnessNet.get_prediction(heads=("sdf_maps",))`);
   * a box that a round labels "good" (1) and leaves exactly where it was is a fixed point of the round (same crop, same map, same
     label, zero delta), so it is carried through the remaining rounds without being evaluated again; when every box is such a fixed
     point the remaining rounds are skipped.  Results are what the reference's fifty full rounds produce.
+(And a batch is 200 crops in the boundary rounds, not 50: `boundary_batch`.)
 Arithmetic that decides something (thresholds, label rules, the order of operations in the box updates, dtypes: float64 proposals on
 the first round, float32 afterwards) follows the reference line by line; each method cites its lines."""
 import math
@@ -22,6 +23,8 @@ import torch
 
 from . import reasoning
 
+BOUNDARY_BATCH = 200      # crops per net call in the boundary rounds (the reference: 50, object_reasoning.py:397): dpt_large's sdf-only forward
+                          # does 2 813 crops/s at 50 and 3 317 at 200 in fp32, 7 966 and 13 388 in bf16 (tools/probe/sdf_only_batch.py)
 _DEFAULTS = dict(class_score_thres=0.1, center_score_max_thres=0.009, analyze_cc=False, max_sdf_thres=0.5, max_shrink_threshold=16,
                  delta_ratio=0.5, n_round=50, proposal_area_thres=50, image_size=128)       # object_reasoning.py:701-710,681
 
@@ -57,6 +60,7 @@ class Object_Discovery:
                 for p in m.parameters():
                     p.requires_grad = False
         self.stats = {}       # per image: rounds run, crops evaluated (tools / tests read it; the reference prints counts instead)
+        self.boundary_batch = int(getattr(args, "boundary_batch", BOUNDARY_BATCH))
         self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
 
     # ------------------------------------------------------------------ static helpers
@@ -214,8 +218,9 @@ class Object_Discovery:
         a = self.args
         H, W = image.shape[-2], image.shape[-1]
         sdf, edge = [], []
-        for i in range(0, len(proposals), 50):
-            crops, on_edge = reasoning.crop_resize(image, proposals[i:i + 50], 128)
+        nb = self.boundary_batch
+        for i in range(0, len(proposals), nb):
+            crops, on_edge = reasoning.crop_resize(image, proposals[i:i + nb], 128)
             sdf.append(self._predict(crops.to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1))
             edge.append(on_edge.to(self.device))
         sdf = torch.cat(sdf, dim=0)

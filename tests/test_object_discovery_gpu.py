@@ -202,3 +202,30 @@ def test_discovery_with_the_real_networks_runs():
     boxes = od.discover_image(image)
     assert boxes is None or (boxes.dim() == 2 and boxes.shape[1] == 4 and bool(torch.isfinite(boxes).all()))
     assert od.stats.get("boundary_rounds", 0) <= 4
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "bfloat16"])
+def test_centre_reasoning_through_the_pipelined_sweep_equals_the_plain_path(dtype_name):
+    """with unmore_amd's own net, center_reasoning runs the proposals through reasoning.sweep_proposals (three streams; fp32:
+    certificate-driven precision): the boxes that pass and the split boxes are those of the plain batch-by-batch path"""
+    from unmore_amd import synth
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.object_discovery import Object_Discovery
+    from unmore_amd.objectness_net import ObjectnessNet
+    args = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+    net = ObjectnessNet(DEV, 128, "dpt_base", args)
+    spec = {k: tuple(v.shape) for k, v in net.state_dict().items()}          # hash weights + the documented edits that give peaks
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.peak_edited_state_dict(spec, "base").items()}, strict=True)
+    net = net.to(DEV)
+    net.set_compute_dtype(getattr(torch, dtype_name))
+    od = Object_Discovery(args, DEV, objectness_model=net, binary_classifier_model=ObjectFraction())
+    image = torch.from_numpy(synth.blob_images(1, 240, 320, seed=11)[0]).to(DEV)
+    props = torch.tensor(od.generate_random_proposal(240, 320)).to(DEV)
+    a = od.center_reasoning(image, props)
+    od.pipelined_center_sweep = False
+    b = od.center_reasoning(image, props)
+    n_pass, n_split = len(a["proposals_pass_singularity"]), len(a["splited_new_proposals"])
+    print(f"{dtype_name}: {len(props)} proposals -> {n_pass} pass, {n_split // 4} split")
+    assert n_pass > 0 and n_split > 0, "the fixture should exercise both outcomes"
+    assert torch.equal(a["proposals_pass_singularity"], b["proposals_pass_singularity"])
+    assert torch.equal(torch.as_tensor(a["splited_new_proposals"]), torch.as_tensor(b["splited_new_proposals"]))

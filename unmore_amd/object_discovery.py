@@ -61,6 +61,7 @@ class Object_Discovery:
                     p.requires_grad = False
         self.stats = {}       # per image: rounds run, crops evaluated (tools / tests read it; the reference prints counts instead)
         self.boundary_batch = int(getattr(args, "boundary_batch", BOUNDARY_BATCH))
+        self.pipelined_center_sweep = True   # centre reasoning through reasoning.sweep_proposals when the net is unmore_amd's own
         self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
 
     # ------------------------------------------------------------------ static helpers
@@ -181,9 +182,18 @@ class Object_Discovery:
         centre and is replaced by its left / right / top / bottom parts at the peak (in that order, box after box)."""
         a = self.args
         proposals = torch.as_tensor(proposals).to(self.device)
-        sdf_maps, center_fields = self.get_prediction_with_proposals(proposals, image)
-        mx, am = reasoning.center_peaks(sdf_maps, center_fields)
-        H, W = sdf_maps.shape[-2], sdf_maps.shape[-1]
+        from .objectness_net import ObjectnessNet
+        if self.pipelined_center_sweep and isinstance(self.objectness_model, ObjectnessNet) and not a.analyze_cc:
+            # unmore_amd's own net: the batches of 50 go round three HIP streams, and in fp32 the sweep is certificate-driven -- three-term
+            # products first, six-term only for the proposals whose peak index / side of the threshold is not PROVABLY the six-term one
+            # (reasoning.sweep_proposals: 1.7x on a 1 225-proposal image, same indices and decisions; bench.py --workload cfg5)
+            mx, am, _ = reasoning.sweep_proposals(self.objectness_model, image, proposals, precision="certified")
+            H = W = 128
+            sdf_maps = center_fields = None
+        else:
+            sdf_maps, center_fields = self.get_prediction_with_proposals(proposals, image)
+            mx, am = reasoning.center_peaks(sdf_maps, center_fields)
+            H, W = sdf_maps.shape[-2], sdf_maps.shape[-1]
         fail = mx > a.center_score_max_thres
         passed = proposals[~fail]
         split = []

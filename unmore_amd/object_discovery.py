@@ -16,7 +16,6 @@ device -- with ONE host synchronisation per round (the survivors' count).  Two t
 (And a batch is 200 crops in the boundary rounds, not 50: `boundary_batch`.)
 Arithmetic that decides something (thresholds, label rules, the order of operations in the box updates, dtypes: float64 proposals on
 the first round, float32 afterwards) follows the reference line by line; each method cites its lines."""
-import math
 
 import numpy as np
 import torch

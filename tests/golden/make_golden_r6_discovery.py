@@ -102,6 +102,16 @@ def main():
         print(tag, f"{len(p0)} proposals -> {int((ex >= args.class_score_thres).sum())} exist -> pass {len(passed)} / split {len(cr['splited_new_proposals'])}"
               f" -> pass2 {len(cr2['proposals_pass_singularity'])} -> boundary in {len(proposals)} -> out {len(lab)}: "
               f"good {int((lab == 1).sum())}, moving {int((lab == 0).sum())}, dropped {int((lab == -1).sum())}; dtypes {split.dtype} {br['proposals'].dtype}")
+    # --analyze_cc (:562-573): connected components of the union masks of the boxes that pass, enlarged, appended to the split list
+    H, W, seed, nobj = SCENES["a"]
+    image = torch.from_numpy(synth.reasoning_scene(H, W, seed, nobj))
+    od.height, od.width = H, W
+    od.args.analyze_cc = True
+    props = torch.tensor(save["a_proposals0"])[torch.from_numpy(save["a_existence0"]) >= args.class_score_thres]
+    cc = od.center_reasoning(image, props)
+    od.args.analyze_cc = False
+    save["a_cc_pass"], save["a_cc_split"] = cc["proposals_pass_singularity"].numpy(), cc["splited_new_proposals"].numpy()
+    print("analyze_cc:", save["a_cc_split"].shape, "split + component boxes (", save["a_split1"].shape[0], "of them from the peaks ), dtype", cc["splited_new_proposals"].dtype)
     # helpers on their own
     boxes = torch.tensor([[10.0, 20.0, 74.0, 52.0], [0.0, 0.0, 320.0, 240.0], [100.5, 30.25, 131.0, 200.0]], dtype=torch.float64)
     deltas = torch.tensor([[-3.0, 2.0, 5.5, -1.25], [0.0, 0.0, 0.0, 0.0], [7.0, -7.0, 0.5, 12.0]], dtype=torch.float32)

@@ -229,3 +229,23 @@ def test_centre_reasoning_through_the_pipelined_sweep_equals_the_plain_path(dtyp
     assert n_pass > 0 and n_split > 0, "the fixture should exercise both outcomes"
     assert torch.equal(a["proposals_pass_singularity"], b["proposals_pass_singularity"])
     assert torch.equal(torch.as_tensor(a["splited_new_proposals"]), torch.as_tensor(b["splited_new_proposals"]))
+
+
+def test_analyze_cc_branch_equals_the_reference():
+    """--analyze_cc (object_reasoning.py:562-573): the connected components (scipy, on the host, as in the reference) of the union masks of
+    the boxes that pass, enlarged 1.5x and appended to the split boxes -- rows and dtype of the reference's result"""
+    od = _od()
+    od.args.analyze_cc = True
+    image = _image("a")
+    od.height, od.width = image.shape[-2], image.shape[-1]
+    props = torch.from_numpy(G["a_proposals0"])[torch.from_numpy(G["a_existence0"]) >= od.args.class_score_thres].to(DEV)
+    cr = od.center_reasoning(image, props)
+    got, ref = cr["splited_new_proposals"].cpu().numpy(), G["a_cc_split"]
+    assert np.array_equal(cr["proposals_pass_singularity"].cpu().numpy(), G["a_cc_pass"])
+    assert got.dtype == ref.dtype and got.shape == ref.shape
+    n_peak = G["a_split1"].shape[0]
+    assert np.array_equal(got[:n_peak], ref[:n_peak])
+    # the component boxes come from masks whose threshold pixels may differ in the last bit of a crop: all but a few rows identical
+    same = (got[n_peak:] == ref[n_peak:]).all(axis=1)
+    print(f"analyze_cc: {len(ref) - n_peak} component boxes, {int(same.sum())} identical")
+    assert same.mean() >= 0.95 and float(np.abs(got[n_peak:] - ref[n_peak:]).max()) <= 3

@@ -69,9 +69,23 @@ for name, honour, carry, nb in (("reference_flow", False, False, 50), ("sdf_only
     model = RealWorkStubAnswer(honour)
     od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
     od.carry_fixed_points, od.boundary_batch = carry, nb
+    phases = {}
+
+    def timed(name, fn):
+        def run(*a, **k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            phases[name] = phases.get(name, 0.0) + time.perf_counter() - t
+            return r
+        return run
+    for meth in ("existence_checking", "center_reasoning", "boundary_reasoning"):
+        setattr(od, meth, timed(meth, getattr(od, meth)))
     boxes = od.discover_image(image)          # warm-up: packs weights, captures the graphs of the recurring batch shapes
     torch.cuda.synchronize()
     model.calls = model.crops = 0
+    phases.clear()
     t0 = time.perf_counter()
     boxes = od.discover_image(image)
     torch.cuda.synchronize()
@@ -81,5 +95,6 @@ for name, honour, carry, nb in (("reference_flow", False, False, 50), ("sdf_only
     same = boxes is not None and ref_boxes is not None and boxes.shape == ref_boxes.shape and bool(torch.equal(boxes, ref_boxes))
     rows.append({"arm": name, "backbone": backbone, "dtype": dt, "image": [H, W], "seconds_per_image": round(dtm, 3), "net_calls": model.calls,
                  "crops_through_the_net": model.crops, "boundary_rounds": od.stats.get("boundary_rounds"), "boundary_crops": od.stats.get("boundary_crops"),
-                 "boxes_out": None if boxes is None else len(boxes), "same_boxes_as_reference_flow": same})
+                 "boxes_out": None if boxes is None else len(boxes), "same_boxes_as_reference_flow": same,
+                 "seconds_by_phase": {k: round(v, 3) for k, v in phases.items()}})
     print(json.dumps(rows[-1]), flush=True)

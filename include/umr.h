@@ -366,6 +366,12 @@ int umr_mask_paste_stats(const float* sdf_maps, const float* center_fields, cons
                          int32_t* stats, float* maxima, umr_stream_t stream);
 int umr_mask_paste(const float* sdf_maps, const float* center_fields, const int32_t* boxes, const int64_t* select, int K, int S, int H, int W,
                    uint8_t* masks, umr_stream_t stream);
+/* mask_components: 8-connected components of every map's union mask (sigmoid(sdf) > 0.5 | ||center|| > 0.5) in scipy.ndimage.label's
+ * order (by first pixel in raster order) -- object_reasoning.py:206-257, the --analyze_cc branch of center_reasoning (README.md:176).
+ * counts[b] = the number of components of map b; boxes[b][i] = [x1, y1, x2, y2) of component i for i < min(counts[b], max_components),
+ * zeros beyond.  S * S * 8 + max_components * 16 bytes of LDS (<= 150 KiB). */
+int umr_mask_components(const float* sdf_maps, const float* center_fields, int B, int S, int max_components, int32_t* counts, int32_t* boxes,
+                        umr_stream_t stream);
 int64_t umr_nms_workspace(int n);
 int umr_nms(const float* boxes, const int64_t* order, int n, float iou_threshold, void* workspace, int64_t workspace_bytes,
             int64_t* keep, int32_t* n_keep, umr_stream_t stream);

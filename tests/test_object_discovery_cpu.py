@@ -32,15 +32,6 @@ def test_box_update_and_enlargement_equal_the_reference():
     assert OD.unravel_index(torch.tensor(130), (128, 128)) == (torch.tensor(1), torch.tensor(2))
 
 
-def test_connected_components_split():
-    from unmore_amd.object_discovery import Object_Discovery as OD
-    m = torch.zeros((3, 12, 12), dtype=torch.int64)
-    m[0, 2:5, 2:6] = 1                              # one component
-    m[1, 1:3, 1:3] = 1; m[1, 8:11, 6:9] = 1        # two  # noqa: E702
-    cc, single = OD.separate_connected_components(m)
-    assert single == [1, 0, 0] and cc["single"] == [[2, 2, 6, 5]] and cc["multi"] == [[1, 1, 3, 3], [6, 8, 9, 11]]
-
-
 def test_oracle_nms_known_answers():
     from oracle import objectness_oracle as orc
     b = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10], [21, 21, 29, 29]], np.float32)

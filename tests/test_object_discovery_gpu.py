@@ -249,3 +249,61 @@ def test_analyze_cc_branch_equals_the_reference():
     same = (got[n_peak:] == ref[n_peak:]).all(axis=1)
     print(f"analyze_cc: {len(ref) - n_peak} component boxes, {int(same.sum())} identical")
     assert same.mean() >= 0.95 and float(np.abs(got[n_peak:] - ref[n_peak:]).max()) <= 3
+
+
+def test_connected_components_kernel_equals_scipy_label():
+    """umr_mask_components against scipy.ndimage.label + find_objects (what object_reasoning.py:206-257 calls; here only the checker):
+    counts, numbering and boxes on blobs, noise, a spiral whose ends are ~4000 steps apart, a full and an empty mask, 1024 isolated
+    pixels (the recorded maximum) -- and the documented failure beyond it"""
+    from scipy.ndimage import find_objects, label
+    from unmore_amd import reasoning
+    from unmore_amd.object_discovery import Object_Discovery as OD
+    S = 128
+    rng = np.random.default_rng(0)
+    masks = []
+    yy, xx = np.mgrid[0:S, 0:S]
+    blobs = np.zeros((S, S), bool)
+    for _ in range(9):
+        cy, cx, r = rng.uniform(10, 118), rng.uniform(10, 118), rng.uniform(3, 14)
+        blobs |= (yy - cy) ** 2 + (xx - cx) ** 2 <= r * r
+    masks.append(blobs)
+    masks.append(rng.uniform(size=(S, S)) > 0.6)                       # noise: hundreds of components, diagonal contacts
+    masks.append(rng.uniform(size=(S, S)) > 0.45)                      # denser: a few big tangled ones
+    spiral = np.zeros((S, S), bool)
+    y = x = 0
+    dy, dx, seg = 0, 1, S - 1
+    lo, hi = 0, S - 1
+    while hi - lo >= 2:                                                # a square spiral of one-pixel walls, two pixels apart
+        spiral[lo, lo:hi + 1] = True; spiral[lo:hi + 1, hi] = True     # noqa: E702
+        spiral[hi, lo + 2:hi + 1] = True; spiral[lo + 2:hi + 1, lo + 2] = True   # noqa: E702
+        lo += 2; hi -= 2                                               # noqa: E702
+        spiral[lo, lo] = True
+    masks.append(spiral)
+    masks.append(np.ones((S, S), bool))
+    masks.append(np.zeros((S, S), bool))
+    grid = np.zeros((S, S), bool)
+    grid[::4, ::4] = True                                              # 32 x 32 = 1024 isolated pixels
+    masks.append(grid)
+    m = torch.from_numpy(np.stack(masks)).to(DEV)
+    sdf = torch.where(m, 1.0, -1.0)
+    counts, boxes = reasoning.mask_components(sdf, torch.zeros((len(masks), 2, S, S), device=DEV))
+    counts, boxes = counts.cpu().numpy(), boxes.cpu().numpy()
+    for b, mk in enumerate(masks):
+        lab, n = label(mk, np.ones((3, 3), dtype=int))
+        ref = [[sl[1].start, sl[0].start, sl[1].stop, sl[0].stop] for sl in find_objects(lab)]
+        assert counts[b] == n, (b, counts[b], n)
+        assert boxes[b, :n].tolist() == ref, b
+        assert not boxes[b, n:].any()
+    print("components per mask:", counts.tolist())
+    cc, single = OD.separate_connected_components(m.to(torch.int64))
+    assert single == [int(c == 1) for c in counts] and len(cc["multi"]) == int(sum(c for c in counts if c > 1))
+    # the union of the two field masks, not just the sdf's: a centre field switches on what the sdf leaves off
+    cen = torch.zeros((1, 2, S, S), device=DEV)
+    cen[0, 0, 100:110, 100:110] = 0.8
+    c2, b2 = reasoning.mask_components(sdf[:1], cen)
+    lab, n = label(masks[0] | (cen[0, 0].cpu().numpy() > 0.5), np.ones((3, 3), dtype=int))
+    assert int(c2[0]) == n
+    dense = np.zeros((S, S), bool)
+    dense[::2, ::2] = True                                             # 4096 isolated pixels: more than the kernel records
+    with pytest.raises(RuntimeError, match="more than"):
+        OD.separate_connected_components(torch.from_numpy(dense)[None].to(DEV))

@@ -118,6 +118,7 @@ _SIGS = {
     "umr_boundary_deltas": [_vp, _vp, _i32, _i32, _i32, _vp],
     "umr_mask_paste_stats": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
     "umr_mask_paste": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "umr_mask_components": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "umr_nms_workspace": [_i32],
     "umr_nms": [_vp, _vp, _i32, _f32, _vp, _i64, _vp, _vp, _vp],
     "umr_linear_head_fwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],

@@ -456,6 +456,104 @@ __global__ __launch_bounds__(256) void mask_paste_kernel(const float* __restrict
     }
 }
 
+
+// ---- connected components of the union mask (object_reasoning.py:206-257 with --analyze_cc, README.md:176: scipy.ndimage.label with a
+// 3 x 3 structure = 8-connectivity, find_objects) -- one workgroup per map, labels in LDS.  Label equivalence (Hawick et al.): every mask
+// pixel starts as its own root (label = flat index + 1); a sweep lowers a pixel's label to the smallest label among its 8 neighbours and
+// hands that label to its old root, a compression pass makes every pixel point at its root; repeat until a sweep changes nothing.  At the
+// end a component's label is its first pixel in raster order -- scipy numbers components in exactly that order -- so rank = number of roots
+// before it.  Boxes [x1, y1, x2, y2) of the first `maxc` components, and the true count.
+__global__ __launch_bounds__(256) void mask_components_kernel(const float* __restrict__ sdf, const float* __restrict__ center, int S, int maxc,
+                                                              int32_t* __restrict__ counts, int32_t* __restrict__ boxes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int changed, chunk_roots[256];
+    const int SS = S * S, b = blockIdx.x, tid = threadIdx.x;
+    int* Lb = (int*)lds;                 // label plane
+    int* Rk = Lb + SS;                   // rank of a root pixel
+    int* bx = Rk + SS;                   // [maxc][4]: xmin, ymin, xmax, ymax
+    const float* s = sdf + (int64_t)b * SS;
+    const float* c0 = center + (int64_t)b * 2 * SS;
+    const float* c1 = c0 + SS;
+    for (int i = tid; i < SS; i += 256) {
+        const float sg = 1.0f / (1.0f + expf(-s[i]));
+        const float nr = sqrtf(c0[i] * c0[i] + c1[i] * c1[i]);
+        Lb[i] = (sg > 0.5f || nr > 0.5f) ? i + 1 : 0;
+    }
+    for (int i = tid; i < maxc * 4; i += 256) bx[i] = (i & 2) ? -1 : 0x7FFFFFFF;
+    __syncthreads();
+    for (int guard = 0; guard < 4 * SS; ++guard) {        // (terminates long before: every sweep that changes something lowers a label)
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < SS; i += 256) {
+            const int l = Lb[i];
+            if (l == 0) continue;
+            const int y = i / S, x = i - y * S;
+            int m = l;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= S) continue;
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= S) continue;
+                    const int q = Lb[yy * S + xx];
+                    if (q != 0 && q < m) m = q;
+                }
+            }
+            if (m < l) {
+                atomicMin(&Lb[l - 1], m);      // the old root learns of the smaller label
+                atomicMin(&Lb[i], m);
+                changed = 1;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < SS; i += 256) {  // compression: follow the chain to a pixel that is its own root
+            int l = Lb[i];
+            if (l == 0) continue;
+            int r = Lb[l - 1];
+            while (r < l) { l = r; r = Lb[l - 1]; }
+            Lb[i] = l;
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    // ranks of the roots in raster order: thread t owns the contiguous chunk of pixels [t * per, (t + 1) * per)
+    const int per = (SS + 255) / 256;
+    const int lo = tid * per, hi = min(SS, lo + per);
+    int n_mine = 0;
+    for (int i = lo; i < hi; ++i) n_mine += (Lb[i] == i + 1);
+    chunk_roots[tid] = n_mine;
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int t = 0; t < 256; ++t) { const int v = chunk_roots[t]; chunk_roots[t] = acc; acc += v; }
+        counts[b] = acc;
+    }
+    __syncthreads();
+    int rank = chunk_roots[tid];
+    for (int i = lo; i < hi; ++i) {
+        if (Lb[i] == i + 1) Rk[i] = rank++;
+    }
+    __syncthreads();
+    for (int i = tid; i < SS; i += 256) {
+        const int l = Lb[i];
+        if (l == 0) continue;
+        const int r = Rk[l - 1];
+        if (r < maxc) {
+            const int y = i / S, x = i - y * S;
+            atomicMin(&bx[r * 4 + 0], x); atomicMin(&bx[r * 4 + 1], y);
+            atomicMax(&bx[r * 4 + 2], x); atomicMax(&bx[r * 4 + 3], y);
+        }
+    }
+    __syncthreads();
+    const int n = min(counts[b], maxc);
+    for (int i = tid; i < maxc; i += 256) {
+        int32_t* o = boxes + ((int64_t)b * maxc + i) * 4;
+        if (i < n) { o[0] = bx[i * 4 + 0]; o[1] = bx[i * 4 + 1]; o[2] = bx[i * 4 + 2] + 1; o[3] = bx[i * 4 + 3] + 1; }
+        else { o[0] = o[1] = o[2] = o[3] = 0; }
+    }
+}
+
 }  // namespace
 
 extern "C" int umr_crop_resize_bilinear(const float* image, const int32_t* boxes, float* out, int N, int H, int W, int S,
@@ -539,6 +637,17 @@ extern "C" int umr_mask_paste(const float* sdf_maps, const float* center_fields,
     if ((int64_t)S * S * 2 > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "mask_paste: crop larger than the LDS mask planes (S <= 277)");
     UMR_SET_MAX_LDS_ONCE(mask_paste_kernel, 150 * 1024);
     hipLaunchKernelGGL(mask_paste_kernel, dim3(K), dim3(256), (size_t)S * S * 2, (hipStream_t)stream, sdf_maps, center_fields, boxes, select, S, H, W, masks);
+    UMR_LAUNCH_CHECK();
+    return UMR_OK;
+}
+
+extern "C" int umr_mask_components(const float* sdf_maps, const float* center_fields, int B, int S, int max_components, int32_t* counts,
+                                   int32_t* boxes, umr_stream_t stream) {
+    UMR_CHECK_ARG(sdf_maps && center_fields && counts && boxes && B > 0 && S > 0 && max_components > 0, "mask_components: bad arguments");
+    const size_t lds = (size_t)S * S * 8 + (size_t)max_components * 16;
+    if (lds > 150 * 1024) return umr_set_error(UMR_ERR_UNSUPPORTED, "mask_components: S * S * 8 + max_components * 16 bytes of LDS exceed 150 KiB (S = 128: up to 1408 components)");
+    UMR_SET_MAX_LDS_ONCE(mask_components_kernel, 150 * 1024);
+    hipLaunchKernelGGL(mask_components_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, sdf_maps, center_fields, S, max_components, counts, boxes);
     UMR_LAUNCH_CHECK();
     return UMR_OK;
 }

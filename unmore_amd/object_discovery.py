@@ -108,24 +108,23 @@ class Object_Discovery:
 
     @staticmethod
     def separate_connected_components(binary_masks):
-        """object_reasoning.py:206-257 (only reached with --analyze_cc): 8-connected components of every mask on the HOST with
-        scipy.ndimage, exactly as the reference does it; boxes [x1, y1, x2, y2) of the components of the masks that have several,
-        and per mask whether it has exactly one."""
-        from scipy.ndimage import find_objects, label
-        combined = {"single": [], "multi": []}
-        single = []
-        structure = np.ones((3, 3), dtype=int)
-        for m in binary_masks.detach().cpu().numpy():
-            labeled, n = label(m, structure)
-            boxes = [[sl[1].start, sl[0].start, sl[1].stop, sl[0].stop] for sl in find_objects(labeled) if sl is not None]
-            if n == 1 and boxes:
-                combined["single"].append(boxes[0])
-                single.append(1)
-            else:
-                single.append(0)
-                if n > 1:
-                    combined["multi"].extend(boxes)
-        return combined, single
+        """object_reasoning.py:206-257 (--analyze_cc, README.md:176): 8-connected components of every mask (scipy.ndimage.label with a
+        3 x 3 structure there; csrc/reasoning.hip::mask_components_kernel here, same numbering); boxes [x1, y1, x2, y2) of the components
+        of the masks that have several, and per mask whether it has exactly one.  binary_masks [B,S,S] on the GPU."""
+        m = binary_masks.to(torch.float32)
+        counts, boxes = reasoning.mask_components(torch.where(m > 0, 1.0, -1.0), torch.zeros((m.shape[0], 2) + tuple(m.shape[1:]), device=m.device))
+        return Object_Discovery._components_to_lists(counts, boxes)
+
+    @staticmethod
+    def _components_to_lists(counts, boxes):
+        counts_h = counts.cpu()
+        if int(counts_h.max()) > boxes.shape[1]:
+            raise RuntimeError(f"separate_connected_components: a mask has {int(counts_h.max())} components, more than the {boxes.shape[1]} the kernel records")
+        boxes_h = boxes.cpu()
+        combined = {"single": [boxes_h[b, 0].tolist() for b in torch.nonzero(counts_h == 1).flatten().tolist()], "multi": []}
+        for b in torch.nonzero(counts_h > 1).flatten().tolist():
+            combined["multi"].extend(boxes_h[b, :int(counts_h[b])].tolist())
+        return combined, (counts_h == 1).to(torch.int64).tolist()
 
     @staticmethod
     def enlarge_proposals(proposals, image_shape, ratio):
@@ -212,8 +211,8 @@ class Object_Discovery:
             # (torch.tensor([...]) of 0-dim tensors keeps their dtype, :555-558: float64 rows for the float64 proposal grid)
             split = torch.stack([left, right, top, bottom], dim=1).reshape(-1, 4)
         if a.analyze_cc:
-            union = ((torch.sigmoid(sdf_maps) > 0.5) | (torch.norm(center_fields, dim=1) > 0.5)).to(torch.int64)
-            cc, _single = self.separate_connected_components(union[~fail])
+            counts, cboxes = reasoning.mask_components(sdf_maps[~fail], center_fields[~fail])      # the union masks' components, on the device
+            cc, _single = self._components_to_lists(counts, cboxes)
             multi = self.enlarge_proposals(cc["multi"], (self.height, self.width), ratio=1.5)
             extra = torch.tensor(multi, dtype=torch.float32, device=self.device).reshape(-1, 4)
             # (the reference concatenates onto its split list and fails when that list is empty, :571; here the extra boxes stand alone then)

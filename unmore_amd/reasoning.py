@@ -94,6 +94,21 @@ def update_bbox_with_boundary_fields(sdf_maps):
     return d[:, 0], d[:, 1], d[:, 2], d[:, 3]
 
 
+def mask_components(sdf_maps, center_fields, max_components=1024):
+    """8-connected components of every map's union mask, in scipy.ndimage.label's order (object_reasoning.py:206-257).
+    sdf_maps [B,S,S], center_fields [B,2,S,S] f32 on the GPU.  Returns (counts [B] int32, boxes [B,max_components,4] int32 [x1,y1,x2,y2),
+    zeros beyond a map's count) on the device."""
+    _need_gpu(sdf_maps, center_fields)
+    sdf = sdf_maps.contiguous().float()
+    cen = center_fields.contiguous().float()
+    B, S = sdf.shape[0], sdf.shape[-1]
+    counts = torch.empty(B, dtype=torch.int32, device=sdf.device)
+    boxes = torch.empty((B, max_components, 4), dtype=torch.int32, device=sdf.device)
+    if B:
+        L.check(L.lib().umr_mask_components(_p(sdf), _p(cen), B, S, max_components, _p(counts), _p(boxes), _stream()), "umr_mask_components")
+    return counts, boxes
+
+
 def nms(boxes, scores, iou_threshold):
     """torchvision.ops.nms as object_reasoning.py:661 uses it: indices of the kept boxes, by descending score; equal scores keep their
     input order (the reference passes its labels -- all ones -- as scores; torchvision leaves the order of ties to its sort).

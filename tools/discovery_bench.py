@@ -8,7 +8,8 @@ instead of whatever random weights would say.  Three arms, same boxes out:
    reference_flow : every surviving box evaluated in every round, both heads every time (what object_reasoning.py does, on these kernels)
    sdf_only       : + the boundary rounds evaluate the boundary-distance head only
    sdf_only+carry : + boxes that are fixed points of a round are carried
-   default        : + 200 crops per net call in the boundary rounds instead of 50
+   +batch200      : + 200 crops per net call in the boundary rounds instead of 50
+   default        : + boxes with the same integer corners (= the same crop) are evaluated once per round
 python tools/discovery_bench.py [fp32|bf16] [backbone=dpt_large]"""
 import json
 import os
@@ -40,6 +41,7 @@ for m in (net, clf):
 
 class RealWorkStubAnswer(torch.nn.Module):
     _HEAD_OF = ObjectnessNet._HEAD_OF          # Object_Discovery asks for single heads when the model can do that
+    compute_dtype = property(lambda self: net.compute_dtype)     # ... and sweeps centre reasoning over three streams (fp32: certified precision)
 
     def __init__(self, honour_heads):
         super().__init__()
@@ -64,11 +66,13 @@ class RealClassifierStubAnswer(torch.nn.Module):
 H, W = 480, 640
 image = torch.from_numpy(synth.reasoning_scene(H, W, seed=2, n_objects=6)).to(dev)
 rows, ref_boxes = [], None
-for name, honour, carry, nb in (("reference_flow", False, False, 50), ("sdf_only", True, False, 50), ("sdf_only+carry", True, True, 50),
-                                ("default (sdf_only+carry+batch200)", True, True, 200)):
+for name, honour, carry, nb, share in (("reference_flow", False, False, 50, False), ("sdf_only", True, False, 50, False),
+                                       ("sdf_only+carry", True, True, 50, False), ("sdf_only+carry+batch200", True, True, 200, False),
+                                       ("default (+equal crops shared)", True, True, 200, True)):
     model = RealWorkStubAnswer(honour)
     od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
-    od.carry_fixed_points, od.boundary_batch = carry, nb
+    od.carry_fixed_points, od.boundary_batch, od.share_equal_crops = carry, nb, share
+    od.pipelined_center_sweep = share          # (the last arm = every default)
     phases = {}
 
     def timed(name, fn):
@@ -94,7 +98,7 @@ for name, honour, carry, nb in (("reference_flow", False, False, 50), ("sdf_only
         ref_boxes = boxes
     same = boxes is not None and ref_boxes is not None and boxes.shape == ref_boxes.shape and bool(torch.equal(boxes, ref_boxes))
     rows.append({"arm": name, "backbone": backbone, "dtype": dt, "image": [H, W], "seconds_per_image": round(dtm, 3), "net_calls": model.calls,
-                 "crops_through_the_net": model.crops, "boundary_rounds": od.stats.get("boundary_rounds"), "boundary_crops": od.stats.get("boundary_crops"),
+                 "crops_through_the_net": model.crops, "boundary_rounds": od.stats.get("boundary_rounds"), "boundary_crops": od.stats.get("boundary_crops"), "boundary_distinct_crops": od.stats.get("boundary_distinct_crops"),
                  "boxes_out": None if boxes is None else len(boxes), "same_boxes_as_reference_flow": same,
                  "seconds_by_phase": {k: round(v, 3) for k, v in phases.items()}})
     print(json.dumps(rows[-1]), flush=True)

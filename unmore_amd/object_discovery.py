@@ -13,6 +13,9 @@ device -- with ONE host synchronisation per round (the survivors' count).  Two t
   * a box that a round labels "good" (1) and leaves exactly where it was is a fixed point of the round (same crop, same map, same
     label, zero delta), so it is carried through the remaining rounds without being evaluated again; when every box is such a fixed
     point the remaining rounds are skipped.  Results are what the reference's fifty full rounds produce.
+  * what the net sees of a box is its crop, cut at floor / ceil of the corners: boxes that share those four integers share the crop and
+    everything computed from it, so a round evaluates each DISTINCT crop once (late rounds hold hundreds of boxes clustered on a few
+    objects).
 (And a batch is 200 crops in the boundary rounds, not 50: `boundary_batch`.)
 Arithmetic that decides something (thresholds, label rules, the order of operations in the box updates, dtypes: float64 proposals on
 the first round, float32 afterwards) follows the reference line by line; each method cites its lines."""
@@ -61,6 +64,7 @@ class Object_Discovery:
         self.stats = {}       # per image: rounds run, crops evaluated (tools / tests read it; the reference prints counts instead)
         self.boundary_batch = int(getattr(args, "boundary_batch", BOUNDARY_BATCH))
         self.pipelined_center_sweep = True   # centre reasoning through reasoning.sweep_proposals when the net is unmore_amd's own
+        self.share_equal_crops = True      # boundary rounds: boxes with the same integer corners are cropped and evaluated once
         self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
 
     # ------------------------------------------------------------------ static helpers
@@ -180,8 +184,8 @@ class Object_Discovery:
         centre and is replaced by its left / right / top / bottom parts at the peak (in that order, box after box)."""
         a = self.args
         proposals = torch.as_tensor(proposals).to(self.device)
-        from .objectness_net import ObjectnessNet
-        if self.pipelined_center_sweep and isinstance(self.objectness_model, ObjectnessNet) and not a.analyze_cc:
+        m = self.objectness_model
+        if self.pipelined_center_sweep and hasattr(m, "_HEAD_OF") and hasattr(m, "compute_dtype") and not a.analyze_cc:
             # unmore_amd's own net: the batches of 50 go round three HIP streams, and in fp32 the sweep is certificate-driven -- three-term
             # products first, six-term only for the proposals whose peak index / side of the threshold is not PROVABLY the six-term one
             # (reasoning.sweep_proposals: 1.7x on a 1 225-proposal image, same indices and decisions; bench.py --workload cfg5)
@@ -225,16 +229,30 @@ class Object_Discovery:
         labels f32 [N]: -1 filtered out / 0 keep updating / 1 good)"""
         a = self.args
         H, W = image.shape[-2], image.shape[-1]
+        # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:401-402): boxes that share those
+        # four integers share crop, map, maximum and deltas.  Late rounds hold hundreds of boxes clustered on a few objects -- the net
+        # runs once per DISTINCT crop and the per-box arithmetic below picks its crop's results up (torch.unique: one host sync)
+        inv = None
+        eval_boxes = proposals
+        if self.share_equal_crops and len(proposals) > 1:
+            b64 = proposals.detach().to(torch.float64)
+            corners = torch.stack([torch.floor(b64[:, 0]), torch.floor(b64[:, 1]), torch.ceil(b64[:, 2]), torch.ceil(b64[:, 3])], 1)
+            eval_boxes, inv = torch.unique(corners, dim=0, return_inverse=True)
+        self.stats["boundary_distinct_crops"] = self.stats.get("boundary_distinct_crops", 0) + len(eval_boxes)
         sdf, edge = [], []
         nb = self.boundary_batch
-        for i in range(0, len(proposals), nb):
-            crops, on_edge = reasoning.crop_resize(image, proposals[i:i + nb], 128)
+        for i in range(0, len(eval_boxes), nb):
+            crops, on_edge = reasoning.crop_resize(image, eval_boxes[i:i + nb], 128)
             sdf.append(self._predict(crops.to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1))
             edge.append(on_edge.to(self.device))
         sdf = torch.cat(sdf, dim=0)
         on_edge = torch.cat(edge, dim=0).to(torch.float32)
-        keep = torch.amax(sdf, dim=(1, 2)).to(torch.float32) > a.max_sdf_thres                                        # :421-427
+        max_sdf = torch.amax(sdf, dim=(1, 2)).to(torch.float32)
         dx1, dy1, dx2, dy2 = reasoning.update_bbox_with_boundary_fields(sdf)                                             # :441
+        if inv is not None:
+            on_edge, max_sdf = on_edge[inv], max_sdf[inv]
+            dx1, dy1, dx2, dy2 = dx1[inv], dy1[inv], dx2[inv], dy2[inv]
+        keep = max_sdf > a.max_sdf_thres                                                                                # :421-427
         signed = torch.stack([-dx1, -dy1, dx2, dy2], dim=1)                      # > 0 expands, < 0 shrinks          # :444-445
         signed = torch.where((signed > 0) & (on_edge == 1), 0, 1).to(torch.float32) * signed
         max_expansion, max_shrink = torch.amax(signed, dim=1), torch.amin(signed, dim=1)                                # :446-447
@@ -267,6 +285,7 @@ class Object_Discovery:
         labels = torch.zeros(len(cur), device=self.device)
         frozen = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
         rounds = crops = 0
+        self.stats["boundary_distinct_crops"] = 0
         for _ in range(a.n_round):
             keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                            # :598 / :293-299
             cur, labels, frozen = cur[keep], labels[keep], frozen[keep]

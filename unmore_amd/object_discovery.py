@@ -229,7 +229,7 @@ class Object_Discovery:
         labels f32 [N]: -1 filtered out / 0 keep updating / 1 good)"""
         a = self.args
         H, W = image.shape[-2], image.shape[-1]
-        # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:401-402): boxes that share those
+        # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:404): boxes that share those
         # four integers share crop, map, maximum and deltas.  Late rounds hold hundreds of boxes clustered on a few objects -- the net
         # runs once per DISTINCT crop and the per-box arithmetic below picks its crop's results up (torch.unique: one host sync)
         inv = None
@@ -327,7 +327,7 @@ class Object_Discovery:
             return None
         res = self.center_reasoning(image, proposals)                                                                   # Step 2
         passed, split = res["proposals_pass_singularity"], res["splited_new_proposals"]
-        if len(split) > 0:      # (the reference stacks an empty list and raises when no box failed the singularity check, :633 -> :513)
+        if len(split) > 0:      # (the reference stacks an empty list and raises when no box failed the singularity check, :639 -> :513)
             scores = self.existence_checking(image, split)["existence_scores"]
             split = split[(scores >= a.class_score_thres).to(self.device)]
         if len(split) > 0:

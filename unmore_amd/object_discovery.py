@@ -267,7 +267,7 @@ class Object_Discovery:
         lo = torch.zeros((), dtype=upd.dtype, device=upd.device)
         upd = torch.stack([torch.maximum(upd[:, 0], lo), torch.maximum(upd[:, 1], lo),                                  # :468-471
                            torch.minimum(upd[:, 2], lo + W), torch.minimum(upd[:, 3], lo + H)], dim=1)
-        out = torch.where(keep[:, None], upd.to(torch.float32), torch.zeros((), dtype=torch.float32, device=upd.device))   # :480
+        out = torch.where(keep[:, None], upd.to(torch.float32), torch.zeros((), dtype=torch.float32, device=upd.device))   # :479
         labels = torch.where(keep, good.to(torch.float32), torch.full((), -1.0, device=upd.device))
         return out, labels
 

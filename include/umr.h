@@ -357,11 +357,11 @@ int umr_boundary_deltas(const float* sdf_maps, float* deltas, int B, int H, int 
  * order; keep has room for n, n_keep is one int32 on the device.  n <= 4096; workspace: umr_nms_workspace(n) bytes, 8-byte aligned. */
 /* object scoring (object_scoring.py:172-272).  Per proposal, from its S x S fields: the two binary masks (||center|| > 0.5,
  * sigmoid(sdf) > 0.5), each resized to the proposal's box (integer corners, already clipped to the image) as torchvision's Resize
- * does for integer tensors -- bilinear, align_corners=False, then round half to even -- and OR-ed (:189-222).
+ * does for integer tensors -- bilinear, align_corners=False, then round half to even -- and OR-ed (:196-228).
  * mask_paste_stats: stats[n] = {x_min, y_min, x_max + 1, y_max + 1, area} of that pasted union mask in image coordinates (the tight
- *   box of :225-229; all zero for an empty mask), maxima[n] = {max ||center||, max sdf} over the crop (:184-188).  Nothing image-sized
+ *   box of :231-235; all zero for an empty mask), maxima[n] = {max ||center||, max sdf} over the crop (:189-193).  Nothing image-sized
  *   is written.
- * mask_paste: the pasted union masks of the K selected proposals, masks [K,H,W] u8 (what survives NMS, :233-234). */
+ * mask_paste: the pasted union masks of the K selected proposals, masks [K,H,W] u8 (what survives NMS, :238-240). */
 int umr_mask_paste_stats(const float* sdf_maps, const float* center_fields, const int32_t* boxes, int N, int S, int H, int W,
                          int32_t* stats, float* maxima, umr_stream_t stream);
 int umr_mask_paste(const float* sdf_maps, const float* center_fields, const int32_t* boxes, const int64_t* select, int K, int S, int H, int W,

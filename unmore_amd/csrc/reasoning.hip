@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 // ---- object scoring (object_scoring.py:172-272): the two binary masks of a proposal (||center|| > 0.5, sigmoid(sdf) > 0.5, on its
 // S x S crop) are resized to the proposal's box with torchvision's tensor Resize -- for an integer tensor: bilinear in f32
 // (align_corners=False), then torch.round (half to even: 1 iff the value exceeds 0.5) -- pasted into an image-sized canvas and OR-ed
-// (:189-222).  Both masks live in LDS as bytes; the bilinear arithmetic is PyTorch's, unfused: h0 * (w0 * p00 + w1 * p01) + h1 * (...).
+// (:196-228).  Both masks live in LDS as bytes; the bilinear arithmetic is PyTorch's, unfused: h0 * (w0 * p00 + w1 * p01) + h1 * (...).
 struct PasteAxis { int i0, i1; float l0, l1; };
 __device__ __forceinline__ PasteAxis paste_axis(int o, int out_size, int S) {
     const float scale = (float)S / (float)out_size;

@@ -44,7 +44,7 @@ class Object_Scoring:
         return {k: out[k] for k in ("pred_boundary_fields", "pred_center_fields", "pred_existence_scores")}
 
     def score_image(self, image, raw_proposals):
-        """object_scoring.py:181-256 for one image.  image [3,H,W] f32 (moved to the GPU), raw_proposals: N boxes [x1,y1,x2,y2].
+        """object_scoring.py:182-255 for one image.  image [3,H,W] f32 (moved to the GPU), raw_proposals: N boxes [x1,y1,x2,y2].
         Returns a dict of what the reference writes per surviving box, in NMS order: 'tight_bboxes' [K,4] f32 (x1,y1,x2,y2), 'masks'
         [K,H,W] u8 on the GPU, and numpy arrays 'score' (f64), 'existence_score', 'center_score', 'boundary_score' (f32), 'area_score' (f64)."""
         image = image.to(self.device, torch.float32)
@@ -57,31 +57,31 @@ class Object_Scoring:
         sdf = pred["pred_boundary_fields"].contiguous().float()
         cen = pred["pred_center_fields"].contiguous().float()
         S = sdf.shape[-1]
-        # the box a mask is pasted into: floor / ceil corners (:194-196), clipped like the slice `canvas[y1:y2, x1:x2]` clips them
+        # the box a mask is pasted into: floor / ceil corners (:200-202), clipped like the slice `canvas[y1:y2, x1:x2]` clips them
         ib = torch.stack([torch.floor(props[:, 0]), torch.floor(props[:, 1]), torch.ceil(props[:, 2]), torch.ceil(props[:, 3])], 1).to(torch.int32)
         ib[:, 0].clamp_(0, W); ib[:, 2].clamp_(0, W); ib[:, 1].clamp_(0, H); ib[:, 3].clamp_(0, H)   # noqa: E702
         ib = ib.to(self.device).contiguous()
         stats = torch.empty((N, 5), dtype=torch.int32, device=self.device)
         maxima = torch.empty((N, 2), dtype=torch.float32, device=self.device)
         L.check(L.lib().umr_mask_paste_stats(_p(sdf), _p(cen), _p(ib), N, S, H, W, _p(stats), _p(maxima), _stream()), "umr_mask_paste_stats")
-        tight = stats[:, :4].to(torch.float32)                                   # torch.FloatTensor(tight_bboxes), :230
-        max_center, max_boundary = maxima[:, 0], maxima[:, 1]                    # :184-188
-        keep = reasoning.nms(tight, max_boundary, iou_threshold=0.5)            # :233
+        tight = stats[:, :4].to(torch.float32)                                   # torch.FloatTensor(tight_bboxes), :235
+        max_center, max_boundary = maxima[:, 0], maxima[:, 1]                    # :189-193
+        keep = reasoning.nms(tight, max_boundary, iou_threshold=0.5)            # :238
         K = len(keep)
         masks = torch.empty((K, H, W), dtype=torch.uint8, device=self.device)
         L.check(L.lib().umr_mask_paste(_p(sdf), _p(cen), _p(ib), _p(keep.contiguous()), K, S, H, W, _p(masks), _stream()), "umr_mask_paste")
-        area = stats[:, 4][keep].cpu().numpy().astype(np.int64)                  # final_binary_masks.sum(1).sum(1), :239-240
+        area = stats[:, 4][keep].cpu().numpy().astype(np.int64)                  # final_binary_masks.sum(1).sum(1), :244-245
         existence = pred["pred_existence_scores"][keep].cpu().numpy()
         center = max_center[keep].cpu().numpy()
         boundary = max_boundary[keep].cpu().numpy()
         mask_scores = area / area.max()
         area_score = np.power(mask_scores, 0.25)
-        score = existence * center * boundary * area_score                      # :252
+        score = existence * center * boundary * area_score                      # :255
         return {"tight_bboxes": tight[keep], "masks": masks, "score": score, "existence_score": existence, "center_score": center,
                 "boundary_score": boundary, "area_score": area_score, "keep": keep}
 
     def annotations(self, image_id, scored):
-        """the reference's per-box records (:254-266) without 'segmentation' (a pycocotools RLE string there; `scored['masks']` here)"""
+        """the reference's per-box records (:257-267) without 'segmentation' (a pycocotools RLE string there; `scored['masks']` here)"""
         out = []
         if scored is None:
             return out

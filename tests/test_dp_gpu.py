@@ -187,9 +187,14 @@ def _worker_rccl_one_rank(rank, world, port, out_dir, backbone, B, H, W, dtype_n
     dist.all_reduce(warm)                        # the communicator is created by its first collective: outside every timed / compared region
     torch.cuda.synchronize()
     assert float(warm.sum()) == float(1 << 20)
+    from unmore_amd import trainer as trainer_mod
+    lag0 = trainer_mod._DP_ADAM_LAG
     for name, force, mode, wire in (("plain", "0", "off", None), ("rccl_eager", "1", "off", None), ("rccl_chain", "1", "auto", None),
-                                    ("rccl_chain_traced", "1", "auto", None), ("rccl_chain_bf16", "1", "auto", torch.bfloat16)):
+                                    ("rccl_chain_traced", "1", "auto", None), ("rccl_chain_bf16", "1", "auto", torch.bfloat16),
+                                    ("rccl_chain_lag1", "1", "auto", None), ("rccl_chain_lag100", "1", "auto", None)):
         os.environ["UMR_DP_FORCE"] = force
+        # stages between a bucket's all-reduce and its optimizer launch (UMR_DP_ADAM_LAG): 1 = the very next stage, 100 = every stage after finish()
+        trainer_mod._DP_ADAM_LAG = {"rccl_chain_lag1": 1, "rccl_chain_lag100": 100}.get(name, lag0)
         net = ObjectnessNet("cuda:0", H, backbone, Namespace(use_bg_sdf=True, sdf_activation="tanh"))
         net.load_state_dict(init, strict=True)
         net = net.to("cuda:0")
@@ -212,6 +217,12 @@ def _worker_rccl_one_rank(rank, world, port, out_dir, backbone, B, H, W, dtype_n
             assert step.graph_replays == 4, step.graph_replays
             caps = [c for c in step._graphs.values() if isinstance(c, graphs.StagedCaptured)]
             assert len(caps) == 1 and any(l == "scall" for l, _ in caps[0].segments) and any(l == "call" for l, _ in caps[0].segments)
+            n_scall = sum(l == "scall" for l, _ in caps[0].segments)
+            nb = step.comm.num_buckets
+            if name == "rccl_chain_lag100":
+                assert n_scall == nb, (n_scall, nb)                      # one ready() per bucket, every update after finish()
+            elif name in ("rccl_chain", "rccl_chain_lag1"):
+                assert n_scall > nb, (n_scall, nb)                       # + one wait() per stage that is updated on the weight-gradient lane
         if trace is not None:
             assert len(trace["buckets"]) == step.comm.num_buckets and all(r["done_ms"] >= r["issue_ms"] for r in trace["buckets"]), trace
         torch.save({"flat_p": step.flat_p.cpu(), "flat_g": step.flat_g.cpu(), "first_g": first_g, "losses": torch.stack(losses), "trace": trace},
@@ -231,8 +242,9 @@ def test_gradient_exchange_through_rccl_in_a_group_of_one_rank(tmp_path, backbon
     wire's dtype.  A sum over one rank is the identity: six steps, eager and replayed from the chain of per-stage graphs, must equal the
     step without any exchange bit for bit; the bf16 wire differs by one rounding of the gradient."""
     mp.spawn(_worker_rccl_one_rank, args=(1, _free_port(), str(tmp_path), backbone, B, H, W, dtype_name), nprocs=1, join=True)
-    r = {n: torch.load(os.path.join(tmp_path, f"{n}.pt")) for n in ("plain", "rccl_eager", "rccl_chain", "rccl_chain_traced", "rccl_chain_bf16")}
-    for n in ("rccl_eager", "rccl_chain", "rccl_chain_traced"):
+    r = {n: torch.load(os.path.join(tmp_path, f"{n}.pt")) for n in ("plain", "rccl_eager", "rccl_chain", "rccl_chain_traced", "rccl_chain_bf16",
+                                                                    "rccl_chain_lag1", "rccl_chain_lag100")}
+    for n in ("rccl_eager", "rccl_chain", "rccl_chain_traced", "rccl_chain_lag1", "rccl_chain_lag100"):
         assert torch.equal(r["plain"]["losses"], r[n]["losses"]), n
         assert torch.equal(r["plain"]["flat_g"], r[n]["flat_g"]) and torch.equal(r["plain"]["flat_p"], r[n]["flat_p"]), n
     print(backbone, "per-bucket trace of one replayed step through RCCL (world 1):", r["rccl_chain_traced"]["trace"])

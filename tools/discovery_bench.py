@@ -10,14 +10,15 @@ instead of whatever random weights would say.  Three arms, same boxes out:
    sdf_only+carry : + boxes that are fixed points of a round are carried
    +batch200      : + 200 crops per net call in the boundary rounds instead of 50
    default        : + boxes with the same integer corners (= the same crop) are evaluated once per round
-python tools/discovery_bench.py [fp32|bf16] [backbone=dpt_large]"""
+python tools/discovery_bench.py [fp32|bf16] [backbone=dpt_large] [arm prefix, e.g. default]"""
 import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
-sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from argparse import Namespace
 from discovery_stubs import FieldsFromCrop, ObjectFraction
@@ -28,6 +29,7 @@ from unmore_amd.objectness_net import ObjectnessNet
 
 dt = sys.argv[1] if len(sys.argv) > 1 else "fp32"
 backbone = sys.argv[2] if len(sys.argv) > 2 else "dpt_large"
+only = sys.argv[3] if len(sys.argv) > 3 else None          # e.g. "default": that arm alone (for a profile)
 dev = "cuda:0"
 args = Namespace(use_bg_sdf=True, sdf_activation="tanh")
 torch.manual_seed(0)
@@ -69,6 +71,8 @@ rows, ref_boxes = [], None
 for name, honour, carry, nb, share in (("reference_flow", False, False, 50, False), ("sdf_only", True, False, 50, False),
                                        ("sdf_only+carry", True, True, 50, False), ("sdf_only+carry+batch200", True, True, 200, False),
                                        ("default (+equal crops shared)", True, True, 200, True)):
+    if only is not None and not name.startswith(only):
+        continue
     model = RealWorkStubAnswer(honour)
     od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
     od.carry_fixed_points, od.boundary_batch, od.share_equal_crops = carry, nb, share

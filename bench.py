@@ -42,6 +42,17 @@ WORKLOADS = {
     "ref": dict(kind="train", backbone="dpt_large", H=128, W=128, batch=20, name="ObjectnessNet ViT-L/16 (dpt_large) 128x128 bf16 batch=20 train (the reference's recipe)"),
     "tiny": dict(kind="train", backbone="dpt_tiny", H=64, W=64, batch=2, name="miniature plumbing config"),
 }
+# what the reference itself has for each backbone name: said next to every number of an extension config
+REFERENCE_STATUS = {
+    "dpt_large": "the reference's own backbone (objectness_net.py:62-73)",
+    "dpt_base": "the reference's DPT wiring 'vitb16_384' (models/dpt/models.py:45, blocks.py:45-54) under a backbone_type name this build adds; "
+                "ObjectnessNet's own switch (objectness_net.py:51-107) does not offer it",
+    "dpt_small": "EXTENSION: no ViT-S/16 in the reference; DPT-small convention (D 384, hooks [2,5,8,11], features [48,96,192,384]); semantics are this build's",
+    "dpt_large14": "EXTENSION: no patch-14 backbone in the reference (patch size 16 is hard-coded, models/dpt/vit.py:262,339; an odd token grid breaks its skip "
+                   "additions, blocks.py:372); resizing to the skip's size and the 37x37 position grid are this build's semantics -- no reference result exists "
+                   "for this configuration",
+    "dpt_tiny": "miniature of the reference's wiring for plumbing tests",
+}
 SWEEP_CHECK = (600, 620)   # cfg5: the proposals the CPU oracle is TIMED on (20 of 1225: a bounded sample)
 # cfg5: the proposals whose peak indices the CPU oracle re-derives (untimed): every sixth anchor of the 32-pixel grid (proposals
 # 0..899) and every anchor of the 64 / 128 / 256 / 512-pixel grids plus the whole image (900..1224, object_reasoning.py:109-137)
@@ -596,7 +607,8 @@ def run_rank(a):
             "vs_baseline": None,
             "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": name, "backbone": wl["backbone"], "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
+            "config": {"workload": name, "backbone": wl["backbone"], "reference_status": REFERENCE_STATUS[wl["backbone"]],
+                       "per_gpu_batch": B, "global_batch": world * B, "image": [H, W],
                        "parallelism": (f"dp{world}" if kind == "train" else f"replicas x{world}")},
             "collective": coll,
             "cu_budget": a.cu_budget,

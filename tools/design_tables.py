@@ -43,6 +43,11 @@ def lines():
                 pc = cb["peak_check"]
                 alts.append(f"CPU re-derivation of {pc['proposals_checked']} proposals: {pc['peak_index_mismatches']} peak-index mismatches, {pc['certified']} certified")
         name = d["config"]["workload"] + ("" if hg.get("mode", "auto") == "auto" else f" (--graphs {hg.get('mode')})")
+        # configurations the reference does not have are marked where their numbers stand (bench.py::REFERENCE_STATUS; lines taken before
+        # the key existed are marked from the backbone name)
+        ext = {"dpt_large14": " -- **extension: the reference has no patch-14 backbone (patch 16 is hard-coded, `vit.py:262,339`); the semantics are this build's, no reference result exists**",
+               "dpt_small": " -- **extension: no ViT-S/16 in the reference (DPT-small convention)**"}.get(d["config"].get("backbone"), "")
+        name += ext
         print(f"| {name} | {d['dtype']} | **{d['value']:.2f}** {unit}{extra_v} | {d['ms_per_step']:.2f} | {rf['avg_launch_ms']:.2f} ms, {rf['achieved']:.0f} {rf['unit']}, "
               f"**{rf['frac']:.3f}** of {rf['peak']:.0f} | {'yes: ' + hg.get('form', '') if hg.get('replayed') else 'no'} | {'; '.join(alts) or '-'} |")
     print()

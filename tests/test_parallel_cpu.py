@@ -112,3 +112,52 @@ def test_bf16_wire_exchange_against_the_f32_exchange_world2(tmp_path):
         assert float((got[lo:hi] - mean[lo:hi]).norm() / mean[lo:hi].norm()) <= 6e-3
     tol = 2.0 ** -7 * torch.maximum(r[0]["local"].abs(), r[1]["local"].abs()).double() / 2 * 2
     assert bool(((got - mean).abs() <= tol + 1e-30).all())
+
+
+def _worker_wait(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unmore_amd.parallel import BucketedAllReduce
+    n = 900
+    bounds = [0, 300, 600, 900]
+    out = {}
+    for wire in (None, torch.bfloat16):
+        g = torch.Generator().manual_seed(7 + rank)
+        flat = torch.randn(n, generator=g)
+        local = flat.clone()
+        comm = BucketedAllReduce(flat, bounds, wire_dtype=wire)
+        comm.ready(0)
+        comm.ready(1)
+        comm.wait(0)                      # bucket 0's exchange is complete (and, bf16 wire, widened) before the others are even sent
+        first = flat[:300].clone()
+        untouched = flat[600:].clone()
+        comm.wait(0)                      # waiting twice, or for a bucket that was never sent, is a no-op
+        comm.wait(2)
+        comm.ready(2)
+        scale = comm.finish()
+        assert not comm._pending and not comm._sent
+        out["f32" if wire is None else "bf16"] = dict(local=local, first=first, untouched=untouched, final=flat.clone(), scale=scale)
+    torch.save(out, os.path.join(out_dir, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_waiting_for_one_bucket_before_finish_world2(tmp_path):
+    """BucketedAllReduce.wait(k): what the stage-by-stage optimizer of small data-parallel steps calls (trainer.TrainStep) -- bucket k is
+    exchanged (bf16 wire: and widened back into the gradient buffer) when it returns, the others are untouched, finish() covers the rest"""
+    world, port = 2, _free_port()
+    mp.spawn(_worker_wait, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(tmp_path, f"w{i}.pt")) for i in range(world)]
+    total = r[0]["f32"]["local"] + r[1]["f32"]["local"]
+    for i in range(world):
+        a = r[i]["f32"]
+        torch.testing.assert_close(a["first"], total[:300])
+        assert torch.equal(a["untouched"], a["local"][600:]) and a["scale"] == 0.5
+        torch.testing.assert_close(a["final"], total)
+        b = r[i]["bf16"]
+        mean = total / 2
+        assert b["scale"] == 1.0 and torch.equal(b["untouched"], b["local"][600:])
+        assert float((b["first"] - mean[:300]).norm() / mean[:300].norm()) <= 6e-3
+        assert float((b["final"] - mean).norm() / mean.norm()) <= 6e-3
+        assert torch.equal(b["final"][:300], b["first"])          # widened once, in wait(); finish() did not touch it again

@@ -121,6 +121,13 @@ def test_fixed_point_carry_changes_nothing(tag):
     s_full = dict(od.stats)
     assert torch.equal(a["proposals"], b["proposals"]) and torch.equal(a["labels"], b["labels"])
     assert s_full["boundary_rounds"] == od.args.n_round and s_carry["boundary_crops"] < 0.5 * s_full["boundary_crops"], (s_carry, s_full)
+    # sharing within a round only (no memory of earlier rounds): the same again
+    od.carry_fixed_points, od.remember_crops = True, False
+    d = od.boundary_reasoning(image, start)
+    s_round = dict(od.stats)
+    od.remember_crops = True
+    assert torch.equal(a["proposals"], d["proposals"]) and torch.equal(a["labels"], d["labels"])
+    assert s_carry["boundary_distinct_crops"] < s_round["boundary_distinct_crops"] <= s_round["boundary_crops"]
     # and with every box cropped on its own (no sharing between boxes with equal integer corners): the same again
     od.carry_fixed_points, od.share_equal_crops = True, False
     c = od.boundary_reasoning(image, start)
@@ -128,7 +135,7 @@ def test_fixed_point_carry_changes_nothing(tag):
     assert torch.equal(a["proposals"], c["proposals"]) and torch.equal(a["labels"], c["labels"])
     assert s_noshare["boundary_distinct_crops"] == s_noshare["boundary_crops"] and s_carry["boundary_distinct_crops"] <= s_carry["boundary_crops"]
     print(f"scene {tag}: crops evaluated -- reference flow {s_full['boundary_crops']}, fixed points carried {s_carry['boundary_crops']}, "
-          f"equal crops shared {s_carry['boundary_distinct_crops']}")
+          f"equal crops shared within a round {s_round['boundary_distinct_crops']}, within the image {s_carry['boundary_distinct_crops']}")
 
 
 def test_discover_image_end_to_end_and_nms():

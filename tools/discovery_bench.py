@@ -9,7 +9,8 @@ instead of whatever random weights would say.  Three arms, same boxes out:
    sdf_only       : + the boundary rounds evaluate the boundary-distance head only
    sdf_only+carry : + boxes that are fixed points of a round are carried
    +batch200      : + 200 crops per net call in the boundary rounds instead of 50
-   default        : + boxes with the same integer corners (= the same crop) are evaluated once per round
+   default        : + boxes with the same integer corners (= the same crop) are evaluated once per IMAGE (shared within a round,
+                    remembered across rounds), and centre reasoning goes through the pipelined, certificate-driven sweep
 python tools/discovery_bench.py [fp32|bf16] [backbone=dpt_large] [arm prefix, e.g. default]"""
 import json
 import os
@@ -70,13 +71,14 @@ image = torch.from_numpy(synth.reasoning_scene(H, W, seed=2, n_objects=6)).to(de
 rows, ref_boxes = [], None
 for name, honour, carry, nb, share in (("reference_flow", False, False, 50, False), ("sdf_only", True, False, 50, False),
                                        ("sdf_only+carry", True, True, 50, False), ("sdf_only+carry+batch200", True, True, 200, False),
-                                       ("default (+equal crops shared)", True, True, 200, True)):
+                                       ("default (+every distinct crop once per image, centre reasoning swept)", True, True, 200, True)):
     if only is not None and not name.startswith(only):
         continue
     model = RealWorkStubAnswer(honour)
     od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
     od.carry_fixed_points, od.boundary_batch, od.share_equal_crops = carry, nb, share
     od.pipelined_center_sweep = share          # (the last arm = every default)
+    od.remember_crops = share
     phases = {}
 
     def timed(name, fn):

@@ -14,8 +14,9 @@ device -- with ONE host synchronisation per round (the survivors' count).  Two t
     label, zero delta), so it is carried through the remaining rounds without being evaluated again; when every box is such a fixed
     point the remaining rounds are skipped.  Results are what the reference's fifty full rounds produce.
   * what the net sees of a box is its crop, cut at floor / ceil of the corners: boxes that share those four integers share the crop and
-    everything computed from it, so a round evaluates each DISTINCT crop once (late rounds hold hundreds of boxes clustered on a few
-    objects).
+    everything computed from it, so each DISTINCT crop is evaluated once per image (late rounds hold hundreds of boxes clustered on
+    a few objects, and the boxes that keep the loop running to its fiftieth round oscillate between a few positions: after their
+    second visit they are looked up, not evaluated).
 (And a batch is 200 crops in the boundary rounds, not 50: `boundary_batch`.)
 Arithmetic that decides something (thresholds, label rules, the order of operations in the box updates, dtypes: float64 proposals on
 the first round, float32 afterwards) follows the reference line by line; each method cites its lines."""
@@ -25,6 +26,7 @@ import torch
 
 from . import reasoning
 
+_KEY = 1 << 15            # integer corners < 32768 pack into one int64 key
 BOUNDARY_BATCH = 200      # crops per net call in the boundary rounds (the reference: 50, object_reasoning.py:397): dpt_large's sdf-only forward
                           # does 2 813 crops/s at 50 and 3 317 at 200 in fp32, 7 966 and 13 388 in bf16 (tools/probe/sdf_only_batch.py)
 _DEFAULTS = dict(class_score_thres=0.1, center_score_max_thres=0.009, analyze_cc=False, max_sdf_thres=0.5, max_shrink_threshold=16,
@@ -64,7 +66,9 @@ class Object_Discovery:
         self.stats = {}       # per image: rounds run, crops evaluated (tools / tests read it; the reference prints counts instead)
         self.boundary_batch = int(getattr(args, "boundary_batch", BOUNDARY_BATCH))
         self.pipelined_center_sweep = True   # centre reasoning through reasoning.sweep_proposals when the net is unmore_amd's own
-        self.share_equal_crops = True      # boundary rounds: boxes with the same integer corners are cropped and evaluated once
+        self.share_equal_crops = True      # boundary rounds: boxes with the same integer corners are cropped and evaluated once ...
+        self.remember_crops = True         # ... per IMAGE, not per round: a crop evaluated in an earlier round is looked up
+        self._memo_keys = self._memo_vals = None
         self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
 
     # ------------------------------------------------------------------ static helpers
@@ -232,12 +236,22 @@ class Object_Discovery:
         # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:404): boxes that share those
         # four integers share crop, map, maximum and deltas.  Late rounds hold hundreds of boxes clustered on a few objects -- the net
         # runs once per DISTINCT crop and the per-box arithmetic below picks its crop's results up (torch.unique: one host sync)
-        inv = None
+        inv = hit = None
         eval_boxes = proposals
         if self.share_equal_crops and len(proposals) > 1:
             b64 = proposals.detach().to(torch.float64)
-            corners = torch.stack([torch.floor(b64[:, 0]), torch.floor(b64[:, 1]), torch.ceil(b64[:, 2]), torch.ceil(b64[:, 3])], 1)
-            eval_boxes, inv = torch.unique(corners, dim=0, return_inverse=True)
+            corners = torch.stack([torch.floor(b64[:, 0]), torch.floor(b64[:, 1]), torch.ceil(b64[:, 2]), torch.ceil(b64[:, 3])], 1).to(torch.int64)
+            corners = torch.minimum(corners.clamp_(min=0), torch.tensor([W, H, W, H], device=corners.device))      # as the crop clips them
+            key = ((corners[:, 0] * _KEY + corners[:, 1]) * _KEY + corners[:, 2]) * _KEY + corners[:, 3]           # one int64 per crop
+            ukey, inv = torch.unique(key, return_inverse=True)
+            new_key = ukey
+            if self.remember_crops and self._memo_keys is not None and len(self._memo_keys):
+                # ... and a crop evaluated in an EARLIER round of this image is not evaluated again either: boxes that oscillate between
+                # a few positions -- the ones that keep the loop running to its fiftieth round -- cost nothing after their second visit
+                pos = torch.searchsorted(self._memo_keys, ukey).clamp_(max=len(self._memo_keys) - 1)
+                hit = self._memo_keys[pos] == ukey
+                new_key = ukey[~hit]
+            eval_boxes = torch.stack([new_key // (_KEY ** 3), (new_key // (_KEY ** 2)) % _KEY, (new_key // _KEY) % _KEY, new_key % _KEY], 1).to(torch.float64)
         self.stats["boundary_distinct_crops"] = self.stats.get("boundary_distinct_crops", 0) + len(eval_boxes)
         sdf, edge = [], []
         nb = self.boundary_batch
@@ -245,13 +259,26 @@ class Object_Discovery:
             crops, on_edge = reasoning.crop_resize(image, eval_boxes[i:i + nb], 128)
             sdf.append(self._predict(crops.to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1))
             edge.append(on_edge.to(self.device))
-        sdf = torch.cat(sdf, dim=0)
-        on_edge = torch.cat(edge, dim=0).to(torch.float32)
-        max_sdf = torch.amax(sdf, dim=(1, 2)).to(torch.float32)
-        dx1, dy1, dx2, dy2 = reasoning.update_bbox_with_boundary_fields(sdf)                                             # :441
+        if len(eval_boxes):
+            sdf = torch.cat(sdf, dim=0)
+            vals = torch.cat([torch.amax(sdf, dim=(1, 2)).to(torch.float32)[:, None],
+                              torch.stack(reasoning.update_bbox_with_boundary_fields(sdf), dim=1),                       # :441
+                              torch.cat(edge, dim=0).to(torch.float32)], dim=1)          # [n, 9]: max sdf | four deltas | four edge flags
+        else:
+            vals = torch.zeros((0, 9), dtype=torch.float32, device=self.device)
         if inv is not None:
-            on_edge, max_sdf = on_edge[inv], max_sdf[inv]
-            dx1, dy1, dx2, dy2 = dx1[inv], dy1[inv], dx2[inv], dy2[inv]
+            if hit is not None:
+                allv = torch.empty((len(ukey), 9), dtype=torch.float32, device=self.device)
+                allv[hit], allv[~hit] = self._memo_vals[pos[hit]], vals
+            else:
+                allv = vals
+            if self.remember_crops and len(new_key):
+                mk = new_key if self._memo_keys is None else torch.cat([self._memo_keys, new_key])
+                mv = vals if self._memo_vals is None else torch.cat([self._memo_vals, vals])
+                order = torch.argsort(mk)
+                self._memo_keys, self._memo_vals = mk[order], mv[order]
+            vals = allv[inv]
+        max_sdf, dx1, dy1, dx2, dy2, on_edge = vals[:, 0], vals[:, 1], vals[:, 2], vals[:, 3], vals[:, 4], vals[:, 5:9]
         keep = max_sdf > a.max_sdf_thres                                                                                # :421-427
         signed = torch.stack([-dx1, -dy1, dx2, dy2], dim=1)                      # > 0 expands, < 0 shrinks          # :444-445
         signed = torch.where((signed > 0) & (on_edge == 1), 0, 1).to(torch.float32) * signed
@@ -286,6 +313,7 @@ class Object_Discovery:
         frozen = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
         rounds = crops = 0
         self.stats["boundary_distinct_crops"] = 0
+        self._memo_keys = self._memo_vals = None        # the crops of THIS image (the memo is keyed by integer corners only)
         for _ in range(a.n_round):
             keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                            # :598 / :293-299
             cur, labels, frozen = cur[keep], labels[keep], frozen[keep]

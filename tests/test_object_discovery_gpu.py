@@ -322,3 +322,22 @@ def test_connected_components_kernel_equals_scipy_label():
     dense[::2, ::2] = True                                             # 4096 isolated pixels: more than the kernel records
     with pytest.raises(RuntimeError, match="more than"):
         OD.separate_connected_components(torch.from_numpy(dense)[None].to(DEV))
+
+
+def test_single_rounds_on_two_images_do_not_share_remembered_crops():
+    """the per-image memory of crop results lives inside boundary_reasoning: optimize_one_image_single_round on image B right after the
+    same boxes on image A returns B's results"""
+    od = _od()
+    a_img, b_img = _image("a"), torch.flip(_image("a"), dims=[-1]).contiguous()
+    boxes = torch.from_numpy(G["a_boundary_in"]).to(DEV)
+    lab = torch.zeros(len(boxes), device=DEV)
+    ra = od.optimize_one_image_single_round(a_img, boxes, lab)
+    rb = od.optimize_one_image_single_round(b_img, boxes, lab)
+    fresh = _od().optimize_one_image_single_round(b_img, boxes, lab)
+    assert torch.equal(rb["updated_bboxes"], fresh["updated_bboxes"]) and torch.equal(rb["labels"], fresh["labels"])
+    assert not torch.equal(ra["updated_bboxes"], rb["updated_bboxes"])
+    # and two boundary_reasoning calls on different images: each starts with an empty memory
+    fa = od.boundary_reasoning(a_img, boxes)
+    fb = od.boundary_reasoning(b_img, boxes)
+    fb2 = _od().boundary_reasoning(b_img, boxes)
+    assert torch.equal(fb["proposals"], fb2["proposals"]) and torch.equal(fb["labels"], fb2["labels"]) and not torch.equal(fa["proposals"], fb["proposals"])

@@ -68,7 +68,6 @@ class Object_Discovery:
         self.pipelined_center_sweep = True   # centre reasoning through reasoning.sweep_proposals when the net is unmore_amd's own
         self.share_equal_crops = True      # boundary rounds: boxes with the same integer corners are cropped and evaluated once ...
         self.remember_crops = True         # ... per IMAGE, not per round: a crop evaluated in an earlier round is looked up
-        self._memo_keys = self._memo_vals = None
         self.carry_fixed_points = True     # False: every surviving box is evaluated in every round, as the reference does (tests compare)
 
     # ------------------------------------------------------------------ static helpers
@@ -228,9 +227,10 @@ class Object_Discovery:
         return {"proposals_pass_singularity": passed, "splited_new_proposals": split}
 
     # ------------------------------------------------------------------ boundary reasoning
-    def _round(self, image, proposals):
+    def _round(self, image, proposals, memo=None):
         """one round for `proposals` [N,4] on the device, nothing synchronises: -> (updated boxes f32 [N,4] (zeros where filtered out),
-        labels f32 [N]: -1 filtered out / 0 keep updating / 1 good)"""
+        labels f32 [N]: -1 filtered out / 0 keep updating / 1 good).  memo: the dict in which boundary_reasoning keeps the results of the
+        crops of ITS image (keys: sorted int64 corner codes, vals: [n, 9]); None = nothing is remembered across calls"""
         a = self.args
         H, W = image.shape[-2], image.shape[-1]
         # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:404): boxes that share those
@@ -245,11 +245,11 @@ class Object_Discovery:
             key = ((corners[:, 0] * _KEY + corners[:, 1]) * _KEY + corners[:, 2]) * _KEY + corners[:, 3]           # one int64 per crop
             ukey, inv = torch.unique(key, return_inverse=True)
             new_key = ukey
-            if self.remember_crops and self._memo_keys is not None and len(self._memo_keys):
+            if memo is not None and memo.get("keys") is not None and len(memo["keys"]):
                 # ... and a crop evaluated in an EARLIER round of this image is not evaluated again either: boxes that oscillate between
                 # a few positions -- the ones that keep the loop running to its fiftieth round -- cost nothing after their second visit
-                pos = torch.searchsorted(self._memo_keys, ukey).clamp_(max=len(self._memo_keys) - 1)
-                hit = self._memo_keys[pos] == ukey
+                pos = torch.searchsorted(memo["keys"], ukey).clamp_(max=len(memo["keys"]) - 1)
+                hit = memo["keys"][pos] == ukey
                 new_key = ukey[~hit]
             eval_boxes = torch.stack([new_key // (_KEY ** 3), (new_key // (_KEY ** 2)) % _KEY, (new_key // _KEY) % _KEY, new_key % _KEY], 1).to(torch.float64)
         self.stats["boundary_distinct_crops"] = self.stats.get("boundary_distinct_crops", 0) + len(eval_boxes)
@@ -269,14 +269,14 @@ class Object_Discovery:
         if inv is not None:
             if hit is not None:
                 allv = torch.empty((len(ukey), 9), dtype=torch.float32, device=self.device)
-                allv[hit], allv[~hit] = self._memo_vals[pos[hit]], vals
+                allv[hit], allv[~hit] = memo["vals"][pos[hit]], vals
             else:
                 allv = vals
-            if self.remember_crops and len(new_key):
-                mk = new_key if self._memo_keys is None else torch.cat([self._memo_keys, new_key])
-                mv = vals if self._memo_vals is None else torch.cat([self._memo_vals, vals])
+            if memo is not None and len(new_key):
+                mk = new_key if memo.get("keys") is None else torch.cat([memo["keys"], new_key])
+                mv = vals if memo.get("vals") is None else torch.cat([memo["vals"], vals])
                 order = torch.argsort(mk)
-                self._memo_keys, self._memo_vals = mk[order], mv[order]
+                memo["keys"], memo["vals"] = mk[order], mv[order]
             vals = allv[inv]
         max_sdf, dx1, dy1, dx2, dy2, on_edge = vals[:, 0], vals[:, 1], vals[:, 2], vals[:, 3], vals[:, 4], vals[:, 5:9]
         keep = max_sdf > a.max_sdf_thres                                                                                # :421-427
@@ -313,7 +313,7 @@ class Object_Discovery:
         frozen = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
         rounds = crops = 0
         self.stats["boundary_distinct_crops"] = 0
-        self._memo_keys = self._memo_vals = None        # the crops of THIS image (the memo is keyed by integer corners only)
+        memo = {} if (self.remember_crops and self.share_equal_crops) else None     # the crops of THIS image, this call (keyed by corners only)
         for _ in range(a.n_round):
             keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                            # :598 / :293-299
             cur, labels, frozen = cur[keep], labels[keep], frozen[keep]
@@ -323,7 +323,7 @@ class Object_Discovery:
             if self.carry_fixed_points and bool(frozen.all()):
                 break                                                       # every box is a fixed point: the remaining rounds change nothing
             active = ~frozen
-            out, lab = self._round(image, cur[active])
+            out, lab = self._round(image, cur[active], memo)
             rounds += 1
             crops += int(active.sum())
             new = torch.zeros((len(cur), 4), dtype=torch.float32, device=self.device)

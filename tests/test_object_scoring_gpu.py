@@ -106,3 +106,30 @@ def test_pasted_mask_equals_torch_resize_of_a_random_mask():
             assert stats[n].cpu().tolist() == want, n
     print("pasted pixels differing from torch's resize:", bad, "of", N * H * W)
     assert bad <= 4        # values exactly on 0.5 (a 2x upscale puts many there) round the same way; only last-bit cases may differ
+
+
+def test_scoring_with_the_real_networks_runs():
+    """Object_Scoring around unmore_amd's own ObjectnessNet and Binary_Classifier (hash-initialised: the scores mean nothing, the plumbing is
+    what runs): shapes, dtypes, finite scores, masks inside their tight boxes"""
+    from unmore_amd import synth
+    from unmore_amd.binary_classifier import Binary_Classifier
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.object_scoring import Object_Scoring
+    from unmore_amd.objectness_net import ObjectnessNet
+    args = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+    net = ObjectnessNet(DEV, 128, "dpt_base", args)
+    spec = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth.peak_edited_state_dict(spec, "base").items()}, strict=True)
+    osc = Object_Scoring(args, DEV, objectness_model=net.to(DEV), binary_classifier_model=Binary_Classifier(DEV, 128, args).to(DEV))
+    image = torch.from_numpy(synth.blob_images(1, 160, 224, seed=4)[0]).to(DEV)
+    raw = [[10.3, 12.7, 90.2, 80.9], [100.0, 20.0, 220.5, 150.1], [0.0, 0.0, 224.0, 160.0], [30.0, 90.0, 60.0, 120.0]]
+    out = osc.score_image(image, raw)
+    K = len(out["keep"])
+    assert 1 <= K <= len(raw) and out["masks"].shape == (K, 160, 224) and out["tight_bboxes"].shape == (K, 4)
+    assert np.isfinite(out["score"]).all() and out["score"].dtype == np.float64
+    for k in range(K):
+        ys, xs = torch.nonzero(out["masks"][k], as_tuple=True)
+        x1, y1, x2, y2 = out["tight_bboxes"][k].tolist()
+        if len(ys):
+            assert [int(xs.min()), int(ys.min()), int(xs.max()) + 1, int(ys.max()) + 1] == [int(x1), int(y1), int(x2), int(y2)]
+    assert osc.score_image(image, []) is None

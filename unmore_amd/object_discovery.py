@@ -107,11 +107,11 @@ class Object_Discovery:
     @staticmethod
     def unravel_index(index, shape):
         """object_reasoning.py:198-204"""
-        out = []
-        for dim in reversed(shape):
-            out.append(index % dim)
-            index = index // dim
-        return tuple(reversed(out))
+        coords = [None] * len(shape)
+        for axis in range(len(shape) - 1, -1, -1):      # last axis varies fastest
+            coords[axis] = index % shape[axis]
+            index = index // shape[axis]
+        return tuple(coords)
 
     @staticmethod
     def separate_connected_components(binary_masks):

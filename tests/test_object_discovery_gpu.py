@@ -341,3 +341,24 @@ def test_single_rounds_on_two_images_do_not_share_remembered_crops():
     fb = od.boundary_reasoning(b_img, boxes)
     fb2 = _od().boundary_reasoning(b_img, boxes)
     assert torch.equal(fb["proposals"], fb2["proposals"]) and torch.equal(fb["labels"], fb2["labels"]) and not torch.equal(fa["proposals"], fb["proposals"])
+
+
+def test_images_in_lock_step_equal_images_one_at_a_time():
+    """discover_images / boundary_reasoning_many: the boundary rounds of several images share their net calls; per image the result is
+    bit for bit the one-at-a-time result (images of different sizes, one of them without any object)"""
+    od = _od()
+    imgs = [_image("a"), _image("b"), torch.full((3, 96, 128), -1.0, device=DEV), torch.flip(_image("a"), dims=[-1]).contiguous()]
+    one = [od.discover_image(im) for im in imgs]
+    many = od.discover_images(imgs)
+    assert one[2] is None and many[2] is None
+    for o, m in zip(one, many):
+        assert (o is None) == (m is None)
+        if o is not None:
+            assert torch.equal(o, m)
+    starts = [torch.from_numpy(G["a_boundary_in"]).to(DEV), torch.from_numpy(G["b_boundary_in"]).to(DEV)]
+    sep = [od.boundary_reasoning(imgs[0], starts[0]), od.boundary_reasoning(imgs[1], starts[1])]
+    tog = od.boundary_reasoning_many(imgs[:2], starts)
+    for s_, t_ in zip(sep, tog):
+        assert torch.equal(s_["proposals"], t_["proposals"]) and torch.equal(s_["labels"], t_["labels"])
+    res = od.main_object_discovery(list(enumerate(imgs)), images_in_lock_step=3)
+    assert sorted(res) == [0, 1, 3] and all(np.array_equal(res[i], one[i].cpu().numpy()) for i in res)

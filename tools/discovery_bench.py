@@ -108,3 +108,20 @@ for name, honour, carry, nb, share in (("reference_flow", False, False, 50, Fals
                  "boxes_out": None if boxes is None else len(boxes), "same_boxes_as_reference_flow": same,
                  "seconds_by_phase": {k: round(v, 3) for k, v in phases.items()}})
     print(json.dumps(rows[-1]), flush=True)
+
+# ---- several images: one at a time against their boundary rounds in lock-step (discover_images), every default on
+if only is None or only.startswith("lock"):
+    scenes = [torch.from_numpy(synth.reasoning_scene(H, W, seed=sd, n_objects=6)).to(dev) for sd in (2, 3, 4, 5)]
+    model = RealWorkStubAnswer(True)
+    od = Object_Discovery(Namespace(), dev, objectness_model=model, binary_classifier_model=RealClassifierStubAnswer())
+    for name, fn in (("4 images, one at a time", lambda: [od.discover_image(im) for im in scenes]),
+                     ("4 images, boundary rounds in lock-step", lambda: od.discover_images(scenes))):
+        fn()
+        torch.cuda.synchronize()
+        model.calls = model.crops = 0
+        t0 = time.perf_counter()
+        boxes = fn()
+        torch.cuda.synchronize()
+        dtm = time.perf_counter() - t0
+        print(json.dumps({"arm": name, "backbone": backbone, "dtype": dt, "image": [H, W], "seconds_per_image": round(dtm / len(scenes), 3),
+                          "net_calls": model.calls, "crops_through_the_net": model.crops, "boxes_out": [None if b is None else len(b) for b in boxes]}), flush=True)

@@ -227,17 +227,13 @@ class Object_Discovery:
         return {"proposals_pass_singularity": passed, "splited_new_proposals": split}
 
     # ------------------------------------------------------------------ boundary reasoning
-    def _round(self, image, proposals, memo=None):
-        """one round for `proposals` [N,4] on the device, nothing synchronises: -> (updated boxes f32 [N,4] (zeros where filtered out),
-        labels f32 [N]: -1 filtered out / 0 keep updating / 1 good).  memo: the dict in which boundary_reasoning keeps the results of the
-        crops of ITS image (keys: sorted int64 corner codes, vals: [n, 9]); None = nothing is remembered across calls"""
-        a = self.args
+    def _round_plan(self, image, proposals, memo):
+        """first third of a round: which crops of this image have to go through the net (one host synchronisation: torch.unique)"""
         H, W = image.shape[-2], image.shape[-1]
         # what the net sees of a box is its crop, and the crop is cut at floor / ceil of the corners (:404): boxes that share those
         # four integers share crop, map, maximum and deltas.  Late rounds hold hundreds of boxes clustered on a few objects -- the net
-        # runs once per DISTINCT crop and the per-box arithmetic below picks its crop's results up (torch.unique: one host sync)
-        inv = hit = None
-        eval_boxes = proposals
+        # runs once per DISTINCT crop and the per-box arithmetic of _round_finish picks its crop's results up
+        plan = dict(image=image, proposals=proposals, H=H, W=W, inv=None, hit=None, pos=None, ukey=None, new_key=None, eval_boxes=proposals)
         if self.share_equal_crops and len(proposals) > 1:
             b64 = proposals.detach().to(torch.float64)
             corners = torch.stack([torch.floor(b64[:, 0]), torch.floor(b64[:, 1]), torch.ceil(b64[:, 2]), torch.ceil(b64[:, 3])], 1).to(torch.int64)
@@ -251,27 +247,45 @@ class Object_Discovery:
                 pos = torch.searchsorted(memo["keys"], ukey).clamp_(max=len(memo["keys"]) - 1)
                 hit = memo["keys"][pos] == ukey
                 new_key = ukey[~hit]
+                plan.update(pos=pos, hit=hit)
             eval_boxes = torch.stack([new_key // (_KEY ** 3), (new_key // (_KEY ** 2)) % _KEY, (new_key // _KEY) % _KEY, new_key % _KEY], 1).to(torch.float64)
-        self.stats["boundary_distinct_crops"] = self.stats.get("boundary_distinct_crops", 0) + len(eval_boxes)
-        sdf, edge = [], []
+            plan.update(inv=inv, ukey=ukey, new_key=new_key, eval_boxes=eval_boxes)
+        self.stats["boundary_distinct_crops"] = self.stats.get("boundary_distinct_crops", 0) + len(plan["eval_boxes"])
+        return plan
+
+    def _round_eval(self, plans):
+        """second third: the crops of ALL the plans (one image each) through the net together, `boundary_batch` crops per call -- several
+        images in lock-step fill the batches that one image's late rounds leave nearly empty.  -> per plan [n, 9]: max sdf | four deltas |
+        four edge flags"""
+        crops, edge = [], []
+        for p in plans:
+            if len(p["eval_boxes"]):
+                c, e = reasoning.crop_resize(p["image"], p["eval_boxes"], 128)
+                crops.append(c)
+                edge.append(e.to(self.device))
+        if not crops:
+            return [torch.zeros((0, 9), dtype=torch.float32, device=self.device) for _ in plans]
+        crops = torch.cat(crops, dim=0) if len(crops) > 1 else crops[0]
         nb = self.boundary_batch
-        for i in range(0, len(eval_boxes), nb):
-            crops, on_edge = reasoning.crop_resize(image, eval_boxes[i:i + nb], 128)
-            sdf.append(self._predict(crops.to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1))
-            edge.append(on_edge.to(self.device))
-        if len(eval_boxes):
-            sdf = torch.cat(sdf, dim=0)
-            vals = torch.cat([torch.amax(sdf, dim=(1, 2)).to(torch.float32)[:, None],
-                              torch.stack(reasoning.update_bbox_with_boundary_fields(sdf), dim=1),                       # :441
-                              torch.cat(edge, dim=0).to(torch.float32)], dim=1)          # [n, 9]: max sdf | four deltas | four edge flags
-        else:
-            vals = torch.zeros((0, 9), dtype=torch.float32, device=self.device)
+        sdf = [self._predict(crops[i:i + nb].to(torch.float32), heads=("sdf_maps",))["sdf_maps"].squeeze(1) for i in range(0, len(crops), nb)]
+        sdf = torch.cat(sdf, dim=0) if len(sdf) > 1 else sdf[0]
+        vals = torch.cat([torch.amax(sdf, dim=(1, 2)).to(torch.float32)[:, None],
+                          torch.stack(reasoning.update_bbox_with_boundary_fields(sdf), dim=1),                           # :441
+                          torch.cat(edge, dim=0).to(torch.float32)], dim=1)
+        return list(torch.split(vals, [len(p["eval_boxes"]) for p in plans], dim=0))
+
+    def _round_finish(self, plan, vals, memo):
+        """last third: every box picks up its crop's results and does its own arithmetic -> (updated boxes f32 [N,4] (zeros where filtered
+        out), labels f32 [N]: -1 filtered out / 0 keep updating / 1 good)"""
+        a = self.args
+        proposals, H, W, inv, hit = plan["proposals"], plan["H"], plan["W"], plan["inv"], plan["hit"]
         if inv is not None:
             if hit is not None:
-                allv = torch.empty((len(ukey), 9), dtype=torch.float32, device=self.device)
-                allv[hit], allv[~hit] = memo["vals"][pos[hit]], vals
+                allv = torch.empty((len(plan["ukey"]), 9), dtype=torch.float32, device=self.device)
+                allv[hit], allv[~hit] = memo["vals"][plan["pos"][hit]], vals
             else:
                 allv = vals
+            new_key = plan["new_key"]
             if memo is not None and len(new_key):
                 mk = new_key if memo.get("keys") is None else torch.cat([memo["keys"], new_key])
                 mv = vals if memo.get("vals") is None else torch.cat([memo["vals"], vals])
@@ -298,6 +312,12 @@ class Object_Discovery:
         labels = torch.where(keep, good.to(torch.float32), torch.full((), -1.0, device=upd.device))
         return out, labels
 
+    def _round(self, image, proposals, memo=None):
+        """one round for `proposals` [N,4] of one image.  memo: the dict in which boundary_reasoning keeps the results of the crops of ITS
+        image (keys: sorted int64 corner codes, vals: [n, 9]); None = nothing is remembered across calls"""
+        plan = self._round_plan(image, proposals, memo)
+        return self._round_finish(plan, self._round_eval([plan])[0], memo)
+
     def optimize_one_image_single_round(self, image, proposals, labels):
         """object_reasoning.py:379-487 (the incoming `labels` are overwritten there too, :392)"""
         proposals = torch.as_tensor(proposals).to(self.device)
@@ -305,49 +325,67 @@ class Object_Discovery:
         return {"updated_bboxes": out, "labels": lab}
 
     def boundary_reasoning(self, image, proposals, n_round=50):
-        """object_reasoning.py:582-612 (like the reference, the loop runs `args.n_round` rounds).  One host synchronisation per round;
-        fixed points are carried, not re-evaluated (module docstring)."""
+        """object_reasoning.py:582-612 (like the reference, the loop runs `args.n_round` rounds).  One host synchronisation per round
+        for the survivors, one for the distinct crops; fixed points are carried, crops remembered (module docstring)."""
+        return self.boundary_reasoning_many([image], [proposals])[0]
+
+    def boundary_reasoning_many(self, images, proposals_list):
+        """boundary_reasoning for several images in lock-step: round r of every image that is still running is planned, then the crops
+        of all of them go through the net TOGETHER, then every image finishes its round -- same results per image as one at a time (a
+        crop's result does not depend on its batch), fuller batches where single images have a few dozen crops left"""
         a = self.args
-        cur = torch.as_tensor(proposals).to(self.device)
-        labels = torch.zeros(len(cur), device=self.device)
-        frozen = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
+        st = []
+        for image, proposals in zip(images, proposals_list):
+            cur = torch.as_tensor(proposals).to(self.device)
+            st.append(dict(image=image, cur=cur, labels=torch.zeros(len(cur), device=self.device),
+                           frozen=torch.zeros(len(cur), dtype=torch.bool, device=self.device), done=False, result=None,
+                           memo={} if (self.remember_crops and self.share_equal_crops) else None))
         rounds = crops = 0
         self.stats["boundary_distinct_crops"] = 0
-        memo = {} if (self.remember_crops and self.share_equal_crops) else None     # the crops of THIS image, this call (keyed by corners only)
         for _ in range(a.n_round):
-            keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                            # :598 / :293-299
-            cur, labels, frozen = cur[keep], labels[keep], frozen[keep]
-            if len(cur) == 0:                                               # (the boolean index above is the round's host sync)
-                self.stats.update(boundary_rounds=rounds, boundary_crops=crops)
-                return {"proposals": [], "labels": []}
-            if self.carry_fixed_points and bool(frozen.all()):
-                break                                                       # every box is a fixed point: the remaining rounds change nothing
-            active = ~frozen
-            out, lab = self._round(image, cur[active], memo)
+            live = []
+            for s_ in st:
+                if s_["done"]:
+                    continue
+                cur, labels, frozen = s_["cur"], s_["labels"], s_["frozen"]
+                keep = (cur[:, 2] - cur[:, 0]) * (cur[:, 3] - cur[:, 1]) > a.proposal_area_thres                        # :598 / :293-299
+                cur, labels, frozen = cur[keep], labels[keep], frozen[keep]
+                s_.update(cur=cur, labels=labels, frozen=frozen)
+                if len(cur) == 0:                                           # (the boolean index above is a host sync)
+                    s_.update(done=True, result={"proposals": [], "labels": []})
+                    continue
+                if self.carry_fixed_points and bool(frozen.all()):
+                    s_["done"] = True                                       # every box is a fixed point: the remaining rounds change nothing
+                    continue
+                s_["active"] = ~frozen
+                s_["plan"] = self._round_plan(s_["image"], cur[s_["active"]], s_["memo"])
+                live.append(s_)
+            if not live:
+                break
             rounds += 1
-            crops += int(active.sum())
-            new = torch.zeros((len(cur), 4), dtype=torch.float32, device=self.device)
-            new_lab = torch.empty(len(cur), dtype=torch.float32, device=self.device)
-            new[active], new_lab[active] = out, lab
-            new[frozen], new_lab[frozen] = cur[frozen].to(torch.float32), labels[frozen]
-            # a fixed point of the round: labelled good and returned bit for bit where it came from (from the second round on the boxes
-            # are float32 on both sides; a float64 box of the first round is frozen only if the cast did not move it)
-            now_fixed = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
-            now_fixed[active] = (lab == 1) & (out.to(cur.dtype) == cur[active]).all(dim=1)
-            if self.carry_fixed_points:
-                frozen = frozen | now_fixed
-            cur, labels = new, new_lab
+            for s_, vals in zip(live, self._round_eval([s_["plan"] for s_ in live])):
+                cur, labels, frozen, active = s_["cur"], s_["labels"], s_["frozen"], s_["active"]
+                out, lab = self._round_finish(s_["plan"], vals, s_["memo"])
+                crops += int(active.sum())
+                new = torch.zeros((len(cur), 4), dtype=torch.float32, device=self.device)
+                new_lab = torch.empty(len(cur), dtype=torch.float32, device=self.device)
+                new[active], new_lab[active] = out, lab
+                new[frozen], new_lab[frozen] = cur[frozen].to(torch.float32), labels[frozen]
+                # a fixed point of the round: labelled good and returned bit for bit where it came from (from the second round on the
+                # boxes are float32 on both sides; a float64 box of the first round is frozen only if the cast did not move it)
+                now_fixed = torch.zeros(len(cur), dtype=torch.bool, device=self.device)
+                now_fixed[active] = (lab == 1) & (out.to(cur.dtype) == cur[active]).all(dim=1)
+                if self.carry_fixed_points:
+                    frozen = frozen | now_fixed
+                s_.update(cur=new, labels=new_lab, frozen=frozen, plan=None)
         self.stats.update(boundary_rounds=rounds, boundary_crops=crops)
-        return {"proposals": cur, "labels": labels}
+        return [s_["result"] if s_["result"] is not None else {"proposals": s_["cur"], "labels": s_["labels"]} for s_ in st]
 
     # ------------------------------------------------------------------ one image, all images
-    def discover_image(self, image):
-        """the body of main_object_discovery's loop (object_reasoning.py:619-662) for one [3,H,W] image on the GPU: the discovered boxes
-        [K,4] (float32, on the GPU), or None where the reference `continue`s"""
+    def _before_boundary(self, image):
+        """Steps 0-2 of main_object_discovery (:619-645) for one image: the proposals that go into boundary reasoning, or None"""
         a = self.args
-        image = image.to(self.device, torch.float32)
         self.height, self.width = image.shape[-2], image.shape[-1]
-        self.stats = {}
         proposals = torch.tensor(self.generate_random_proposal(height=self.height, width=self.width)).to(self.device)   # Step 0
         scores = self.existence_checking(image, proposals)["existence_scores"]                                        # Step 1
         proposals = proposals[(scores >= a.class_score_thres).to(self.device)]
@@ -363,9 +401,11 @@ class Object_Discovery:
             proposals = torch.cat((passed, res2["proposals_pass_singularity"]), dim=0)
         else:
             proposals = passed
-        if len(proposals) == 0:
-            return None
-        res = self.boundary_reasoning(image, proposals, n_round=a.n_round)                                              # Step 3
+        return proposals if len(proposals) else None
+
+    @staticmethod
+    def _after_boundary(res):
+        """:651-662: keep the boxes labelled good, NMS"""
         proposals, labels = res["proposals"], res["labels"]
         if len(proposals) == 0:
             return None
@@ -376,12 +416,39 @@ class Object_Discovery:
         keep = reasoning.nms(proposals.to(torch.float32), labels[good], iou_threshold=0.5)                             # :661
         return proposals[keep]
 
-    def main_object_discovery(self, images):
+    def discover_image(self, image):
+        """the body of main_object_discovery's loop (object_reasoning.py:619-662) for one [3,H,W] image on the GPU: the discovered boxes
+        [K,4] (float32, on the GPU), or None where the reference `continue`s"""
+        return self.discover_images([image])[0]
+
+    def discover_images(self, images):
+        """discover_image for several images whose boundary rounds run in lock-step (boundary_reasoning_many): one result per image,
+        each what discover_image returns for it"""
+        self.stats = {}
+        images = [im.to(self.device, torch.float32) for im in images]
+        starts = [self._before_boundary(im) for im in images]
+        idx = [i for i, p in enumerate(starts) if p is not None]
+        out = [None] * len(images)
+        if idx:
+            for i, res in zip(idx, self.boundary_reasoning_many([images[i] for i in idx], [starts[i] for i in idx])):
+                out[i] = self._after_boundary(res)
+        return out
+
+    def main_object_discovery(self, images, images_in_lock_step=1):
         """object_reasoning.py:615-665 without the dataset object and the JSON file: `images` yields (image_id, image [3,H,W]); returns
-        {image_id: boxes as a numpy array} -- the dictionary the reference dumps to discovery_results.json"""
-        results = {}
-        for image_id, image in images:
-            boxes = self.discover_image(image)
-            if boxes is not None:
-                results[image_id] = boxes.cpu().numpy()
+        {image_id: boxes as a numpy array} -- the dictionary the reference dumps to discovery_results.json.  images_in_lock_step > 1:
+        that many consecutive images share their boundary rounds' net calls (discover_images)."""
+        results, group = {}, []
+
+        def flush():
+            for (image_id, _), boxes in zip(group, self.discover_images([im for _, im in group])):
+                if boxes is not None:
+                    results[image_id] = boxes.cpu().numpy()
+            group.clear()
+        for item in images:
+            group.append(item)
+            if len(group) >= max(1, int(images_in_lock_step)):
+                flush()
+        if group:
+            flush()
         return results

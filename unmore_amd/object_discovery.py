@@ -7,7 +7,8 @@ names, argument meaning and return dictionaries; what is NOT mirrored: the COCO 
 Design (MI355X-first, not a transliteration): the reference walks every box in Python (crop, Resize, list append, per-box tensors) and
 indexes with boolean masks after every step, each a host synchronisation.  Here a round is a handful of launches over ALL boxes -- one
 crop+resize kernel per batch (csrc/reasoning.hip), the net, one boundary-delta kernel, masked element-wise box arithmetic on the
-device -- with ONE host synchronisation per round (the survivors' count).  Two things the reference's loop does not have:
+device -- with three host synchronisations per round and image (the survivors, the distinct crops, the crops not seen before) where the
+reference has several per BOX.  Things the reference's loop does not have:
   * the boundary rounds read `sdf_maps` only, so the centre head -- most of a 128x128 crop's forward -- is not evaluated
     (`ObjectnessNet.get_prediction(heads=("sdf_maps",))`);
   * a box that a round labels "good" (1) and leaves exactly where it was is a fixed point of the round (same crop, same map, same
@@ -325,8 +326,8 @@ class Object_Discovery:
         return {"updated_bboxes": out, "labels": lab}
 
     def boundary_reasoning(self, image, proposals, n_round=50):
-        """object_reasoning.py:582-612 (like the reference, the loop runs `args.n_round` rounds).  One host synchronisation per round
-        for the survivors, one for the distinct crops; fixed points are carried, crops remembered (module docstring)."""
+        """object_reasoning.py:582-612 (like the reference, the loop runs `args.n_round` rounds).  Fixed points are carried, crops shared and
+        remembered (module docstring)."""
         return self.boundary_reasoning_many([image], [proposals])[0]
 
     def boundary_reasoning_many(self, images, proposals_list):

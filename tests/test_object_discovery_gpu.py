@@ -362,3 +362,17 @@ def test_images_in_lock_step_equal_images_one_at_a_time():
         assert torch.equal(s_["proposals"], t_["proposals"]) and torch.equal(s_["labels"], t_["labels"])
     res = od.main_object_discovery(list(enumerate(imgs)), images_in_lock_step=3)
     assert sorted(res) == [0, 1, 3] and all(np.array_equal(res[i], one[i].cpu().numpy()) for i in res)
+
+
+def test_discover_image_with_analyze_cc_runs_end_to_end():
+    """the documented command line has --analyze_cc (README.md:176): the whole per-image sequence with the component boxes in the split list
+    (both centre-reasoning passes), in lock-step with a second image"""
+    od = _od()
+    od.args.analyze_cc = True
+    a, b = od.discover_images([_image("a"), _image("b")])
+    for boxes, tag in ((a, "a"), (b, "b")):
+        H, W = SCENES[tag][0], SCENES[tag][1]
+        assert boxes is not None and boxes.dim() == 2 and boxes.shape[1] == 4 and len(boxes) >= 1 and bool(torch.isfinite(boxes).all())
+        assert float(boxes[:, 0].min()) >= 0 and float(boxes[:, 1].min()) >= 0 and float(boxes[:, 2].max()) <= W and float(boxes[:, 3].max()) <= H
+    one = od.discover_image(_image("a"))
+    assert torch.equal(one, a)

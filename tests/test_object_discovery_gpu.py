@@ -376,3 +376,34 @@ def test_discover_image_with_analyze_cc_runs_end_to_end():
         assert float(boxes[:, 0].min()) >= 0 and float(boxes[:, 1].min()) >= 0 and float(boxes[:, 2].max()) <= W and float(boxes[:, 3].max()) <= H
     one = od.discover_image(_image("a"))
     assert torch.equal(one, a)
+
+
+def test_construction_from_checkpoints_as_the_reference_does(tmp_path):
+    """Object_Discovery(args, device) / Object_Scoring(args, device) without models handed in: both networks are built from `args` and
+    restored from args.objectness_resume / args.binary_classifier_resume ({'model_state_dict': ...}, strict), fp32, eval, frozen
+    (object_reasoning.py:58-88, object_scoring.py:59-90)"""
+    from unmore_amd.binary_classifier import Binary_Classifier
+    from unmore_amd.hashrng import hash_init
+    from unmore_amd.object_discovery import Object_Discovery
+    from unmore_amd.object_scoring import Object_Scoring
+    from unmore_amd.objectness_net import ObjectnessNet
+    base = Namespace(use_bg_sdf=True, sdf_activation="tanh")
+    net = ObjectnessNet("cpu", 128, "dpt_tiny", base)
+    sd = {k: torch.from_numpy(hash_init(k, tuple(v.shape), "tiny")) for k, v in net.state_dict().items()}
+    torch.save({"model_state_dict": sd, "iter": 7}, tmp_path / "obj.ckpt")
+    clf = Binary_Classifier("cpu", 128, base)
+    torch.save({"model_state_dict": clf.state_dict()}, tmp_path / "clf.ckpt")
+    args = Namespace(use_bg_sdf=True, sdf_activation="tanh", image_size=128, backbone_type="dpt_tiny", objectness_resume=str(tmp_path / "obj.ckpt"),
+                     binary_classifier_resume=str(tmp_path / "clf.ckpt"), n_round=2)
+    for cls in (Object_Discovery, Object_Scoring):
+        o = cls(args, DEV)
+        assert isinstance(o.objectness_model, ObjectnessNet) and isinstance(o.binary_classifier_model, Binary_Classifier)
+        assert not o.objectness_model.training and not any(p.requires_grad for p in o.objectness_model.parameters())
+        got = o.objectness_model.state_dict()
+        assert all(torch.equal(got[k].cpu(), sd[k]) for k in sd) and next(o.objectness_model.parameters()).is_cuda
+    x = torch.rand(3, 3, 128, 128, device=DEV)
+    out = o.objectness_model.get_prediction(x)
+    assert out["sdf_maps"].shape == (3, 1, 128, 128) and out["center_fields"].dtype == torch.float32
+    bad = Namespace(**{**vars(args), "backbone_type": "resnet"})
+    with pytest.raises((NotImplementedError, KeyError)):
+        Object_Discovery(bad, DEV)
